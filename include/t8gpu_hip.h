@@ -1,0 +1,117 @@
+/* t8gpu_hip.h -- C ABI of the MI355X (gfx950) backend for t8gpu's finite-volume hot path.
+ *
+ * t8gpu itself has no FFI: its boundary is the C++ template API of t8gpu/ (see include/t8gpu/ for
+ * the HIP-backed mirror of those headers). This C ABI is what those headers -- or any other host
+ * language -- bind to reach the hand-written HIP kernels. Every entry point names the reference
+ * kernel / function it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - suffix _f32 / _f64 selects float_type (reference: t8gpu/memory/memory_manager.h:29, float only).
+ *   - all pointers are DEVICE pointers unless the name says host; `stream` is a hipStream_t (NULL =
+ *     default stream). Calls are asynchronous on that stream and safe to capture in a hipGraph.
+ *   - T8gpuVars_*: the 5 variable planes of one step, exactly the pointers a
+ *     MemoryAccessorOwn<VariableList> holds (memory_manager.h:173): Rho, Rho_v1, Rho_v2, Rho_v3, Rho_e.
+ *   - ghosts: element indices refer to local slots; ghost elements live in mirror slots [N, N+G)
+ *     of the same planes. `indices` (nullable) is the element->slot map of
+ *     MeshConnectivityAccessor::get_element_owner_remote_index (mesh_manager.h:155-157).
+ *   - return value: 0 on success, otherwise the hipError_t (or ncclResult_t + 10000) code; the C++
+ *     wrappers turn non-zero into the reference's print-and-abort (t8gpu/utils/cuda.h:7-15).
+ *   - flux_kind: 0 = KEPES (the flux the reference runs), 1 = HLL (reference dead code,
+ *     examples/subgrid/kernels.inl:263-332).
+ */
+#ifndef T8GPU_HIP_H
+#define T8GPU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T8GPU_FLUX_KEPES 0
+#define T8GPU_FLUX_HLL 1
+
+typedef struct T8gpuVars_f32 { float* p[5]; } T8gpuVars_f32;
+typedef struct T8gpuVars_f64 { double* p[5]; } T8gpuVars_f64;
+
+/* ---- library / device ------------------------------------------------------------------------ */
+int         t8gpu_hip_abi_version(void);
+int         t8gpu_hip_device_count(int* count);
+int         t8gpu_hip_set_device(int device);
+const char* t8gpu_hip_error_string(int code);
+
+/* ---- plain elements, reference-dataflow kernels ("compat" tier) ------------------------------- */
+
+/* kepes_compute_fluxes<<<ceil(F/256),256>>>, examples/compressible_euler/kernels.cu:135-309
+ * (declared kernels.h:22-27). face_neighbors = [2F] (l,r) pairs, face_normals = [normal_dim*F] AoS,
+ * face_surfaces = [F]; scatter-adds -F to l and +F to r; speed_estimates[F] may be NULL. */
+int t8gpu_hip_flux_faces_f32(int flux_kind, int num_faces, int normal_dim, const int32_t* face_neighbors,
+                             const int32_t* indices, const float* face_normals, const float* face_surfaces,
+                             T8gpuVars_f32 state, T8gpuVars_f32 fluxes, float* speed_estimates, void* stream);
+int t8gpu_hip_flux_faces_f64(int flux_kind, int num_faces, int normal_dim, const int32_t* face_neighbors,
+                             const int32_t* indices, const double* face_normals, const double* face_surfaces,
+                             T8gpuVars_f64 state, T8gpuVars_f64 fluxes, double* speed_estimates, void* stream);
+
+/* reflective_boundary_condition<<<ceil(B/256),256>>>, kernels.cu:311-469 (kernels.h:39-44). The
+ * arrays are the SAME arrays as above; boundary entries start after the F interior ones
+ * (t8gpu/mesh/mesh_manager.h:68-70,92-98,132-134). speed_estimates[F + i] written if non-NULL. */
+int t8gpu_hip_flux_boundary_f32(int flux_kind, int num_faces, int num_boundary_faces, int normal_dim,
+                                const int32_t* face_neighbors, const float* face_normals,
+                                const float* face_surfaces, T8gpuVars_f32 state, T8gpuVars_f32 fluxes,
+                                float* speed_estimates, void* stream);
+int t8gpu_hip_flux_boundary_f64(int flux_kind, int num_faces, int num_boundary_faces, int normal_dim,
+                                const int32_t* face_neighbors, const double* face_normals,
+                                const double* face_surfaces, T8gpuVars_f64 state, T8gpuVars_f64 fluxes,
+                                double* speed_estimates, void* stream);
+
+/* timestepping::SSP_3RK_step{1,2,3}<V><<<ceil(N/256),256>>>, t8gpu/timestepping/ssp_runge_kutta.inl:30-99.
+ * stage 1: out = prev + dt/vol*f;  stage 2: out = .75 prev + .25 mid + .25 dt/vol*f;
+ * stage 3: out = c31 prev + c32 mid + c33 dt/vol*f (truncated literals, :12-14,23-25); f := 0. */
+int t8gpu_hip_rk3_stage_f32(int stage, int num_elements, T8gpuVars_f32 prev, T8gpuVars_f32 mid, T8gpuVars_f32 out,
+                            T8gpuVars_f32 fluxes, const float* volume, float delta_t, void* stream);
+int t8gpu_hip_rk3_stage_f64(int stage, int num_elements, T8gpuVars_f64 prev, T8gpuVars_f64 mid, T8gpuVars_f64 out,
+                            T8gpuVars_f64 fluxes, const double* volume, double delta_t, void* stream);
+
+/* ---- Subgrid<4,4> (rank 2) and Subgrid<4,4,4> (rank 3), reference-dataflow kernels ------------- */
+
+/* compute_inner_fluxes<Subgrid><<<N, block_size>>>, examples/subgrid/kernels.inl:335-662. */
+int t8gpu_hip_subgrid_inner_f32(int flux_kind, int rank, int num_elements, T8gpuVars_f32 state, T8gpuVars_f32 fluxes,
+                                const float* volumes, void* stream);
+int t8gpu_hip_subgrid_inner_f64(int flux_kind, int rank, int num_elements, T8gpuVars_f64 state, T8gpuVars_f64 fluxes,
+                                const double* volumes, void* stream);
+
+/* compute_outer_fluxes<Subgrid><<<F, (4,4)|(4)>>>, kernels.inl:664-911. face_level_difference[F],
+ * face_neighbor_offset[rank*F] as in t8gpu/mesh/subgrid_mesh_manager.h:108-126. */
+int t8gpu_hip_subgrid_outer_f32(int flux_kind, int rank, int num_faces, const int32_t* face_neighbors,
+                                const int32_t* indices, const int32_t* face_level_difference,
+                                const int32_t* face_neighbor_offset, const float* face_normals,
+                                const float* face_surfaces, T8gpuVars_f32 state, T8gpuVars_f32 fluxes, void* stream);
+int t8gpu_hip_subgrid_outer_f64(int flux_kind, int rank, int num_faces, const int32_t* face_neighbors,
+                                const int32_t* indices, const int32_t* face_level_difference,
+                                const int32_t* face_neighbor_offset, const double* face_normals,
+                                const double* face_surfaces, T8gpuVars_f64 state, T8gpuVars_f64 fluxes, void* stream);
+
+/* compute_boundary_fluxes<Subgrid><<<B, (4,4)|(4)>>>, kernels.inl:913-1107. */
+int t8gpu_hip_subgrid_boundary_f32(int flux_kind, int rank, int num_faces, int num_boundary_faces,
+                                   const int32_t* face_neighbors, const float* face_normals,
+                                   const float* face_surfaces, T8gpuVars_f32 state, T8gpuVars_f32 fluxes,
+                                   void* stream);
+int t8gpu_hip_subgrid_boundary_f64(int flux_kind, int rank, int num_faces, int num_boundary_faces,
+                                   const int32_t* face_neighbors, const double* face_normals,
+                                   const double* face_surfaces, T8gpuVars_f64 state, T8gpuVars_f64 fluxes,
+                                   void* stream);
+
+/* timestepping::subgrid::SSP_3RK_step{1,2,3}<V,Subgrid><<<N, block_size>>>, ssp_runge_kutta.inl:101-221
+ * (per-subcell volume = volumes[e] / Subgrid::size). */
+int t8gpu_hip_subgrid_rk3_stage_f32(int stage, int rank, int num_elements, T8gpuVars_f32 prev, T8gpuVars_f32 mid,
+                                    T8gpuVars_f32 out, T8gpuVars_f32 fluxes, const float* volumes, float delta_t,
+                                    void* stream);
+int t8gpu_hip_subgrid_rk3_stage_f64(int stage, int rank, int num_elements, T8gpuVars_f64 prev, T8gpuVars_f64 mid,
+                                    T8gpuVars_f64 out, T8gpuVars_f64 fluxes, const double* volumes, double delta_t,
+                                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T8GPU_HIP_H */

@@ -1,0 +1,219 @@
+// flux_math.hpp -- device arithmetic of the compressible-Euler face flux (gfx950).
+//
+// Two formulations of the same flux:
+//   * `*_ref`  : the reference's operation sequence (examples/compressible_euler/kernels.cu:24-133,
+//                220-279; examples/subgrid/kernels.inl:132-332), kept for the reference-dataflow
+//                ("compat") kernels. The eigenvector matrix is applied in its sparse form; dropping
+//                exact zeros and ones leaves every rounding step of the dense loops unchanged.
+//   * `Prim` + `kepes_prim` : per-ELEMENT quantities (1/rho, velocity, p, beta, logs, entropy
+//                variable) are computed once per element and stage, so a face costs no log and a
+//                third of the divisions. Used by the fused tile kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace t8gpu_hip {
+
+#define T8_DEV __device__ __forceinline__
+
+template <class T>
+struct rk3c;
+template <>
+struct rk3c<float> {
+  static constexpr float c21 = 0.75f, c22 = 0.25f, c23 = 0.25f;
+  static constexpr float c31 = 0.33333333333333f, c32 = 0.66666666666666f, c33 = 0.66666666666666f;
+};
+template <>
+struct rk3c<double> {
+  static constexpr double c21 = 0.75, c22 = 0.25, c23 = 0.25;
+  static constexpr double c31 = 0.33333333333333, c32 = 0.66666666666666, c33 = 0.66666666666666;
+};
+
+T8_DEV float  t8_log(float x) { return logf(x); }
+T8_DEV double t8_log(double x) { return log(x); }
+T8_DEV float  t8_sqrt(float x) { return sqrtf(x); }
+T8_DEV double t8_sqrt(double x) { return sqrt(x); }
+T8_DEV float  t8_abs(float x) { return fabsf(x); }
+T8_DEV double t8_abs(double x) { return fabs(x); }
+T8_DEV float  t8_cbrt(float x) { return cbrtf(x); }
+T8_DEV double t8_cbrt(double x) { return cbrt(x); }
+T8_DEV float  t8_min(float a, float b) { return fminf(a, b); }
+T8_DEV double t8_min(double a, double b) { return fmin(a, b); }
+T8_DEV float  t8_max(float a, float b) { return fmaxf(a, b); }
+T8_DEV double t8_max(double a, double b) { return fmax(a, b); }
+
+// logarithmic mean, kernels.cu:24-36
+template <class T>
+T8_DEV T ln_mean_ref(T aL, T aR) {
+  const T xi = aR / aL;
+  const T u  = (xi * (xi - T(2.0)) + T(1.0)) / (xi * (xi + T(2.0)) + T(1.0));
+  if (u < T(1.0e-4)) return (aL + aR) * T(52.50) / (T(105.0) + u * (T(35.0) + u * (T(21.0) + u * T(15.0))));
+  return (aR - aL) / t8_log(xi);
+}
+
+// Total KEPES flux in the face frame: EC flux (kernels.cu:38-93) minus half the matrix
+// dissipation R |L| R^T [v] (kernels.cu:95-133, 224-279). speed = |uHat| + aHat (kernels.cu:222).
+template <class T>
+T8_DEV void kepes_ref(const T uL[5], const T uR[5], T F[5], T& speed) {
+  const T one = T(1), half = T(0.5);
+  const T kappa = T(1.4);
+  const T km1   = kappa - one;
+  const T skm1  = one / km1;
+
+  const T irL = one / uL[0];
+  const T vxL = irL * uL[1], vyL = irL * uL[2], vzL = irL * uL[3];
+  const T irR = one / uR[0];
+  const T vxR = irR * uR[1], vyR = irR * uR[2], vzR = irR * uR[3];
+  const T qL  = half * (vxL * vxL + vyL * vyL + vzL * vzL);
+  const T qR  = half * (vxR * vxR + vyR * vyR + vzR * vzR);
+  const T pL  = km1 * (uL[4] - uL[0] * qL);
+  const T pR  = km1 * (uR[4] - uR[0] * qR);
+  const T bL  = half * uL[0] / pL;
+  const T bR  = half * uR[0] / pR;
+
+  const T rho_mean  = half * (uL[0] + uR[0]);
+  const T rho       = ln_mean_ref<T>(uL[0], uR[0]);
+  const T beta_mean = half * (bL + bR);
+  const T beta_hat  = ln_mean_ref<T>(bL, bR);
+
+  const T u  = half * (vxL + vxR);
+  const T v  = half * (vyL + vyR);
+  const T w  = half * (vzL + vzR);
+  const T a  = t8_sqrt(kappa * half * (pL + pR) / rho);
+  const T h  = kappa / (T(2.0f) * km1 * beta_hat) + half * (vxL * vxR + vyL * vyR + vzL * vzR);
+  const T p1 = half * rho_mean / beta_mean;
+  const T q2 = qL + qR;
+
+  T Fs[5];
+  Fs[0] = rho * u;
+  Fs[1] = Fs[0] * u + p1;
+  Fs[2] = Fs[0] * v;
+  Fs[3] = Fs[0] * w;
+  Fs[4] = Fs[0] * half * (skm1 / beta_hat - q2) + u * Fs[1] + v * Fs[2] + w * Fs[3];
+
+  speed = t8_abs(u) + a;
+
+  const T D0 = half * t8_abs(u - a) * rho / kappa;
+  const T D1 = t8_abs(u) * (km1 / kappa) * rho;
+  const T D2 = t8_abs(u) * p1;
+  const T D4 = half * t8_abs(u + a) * rho / kappa;
+
+  // entropy variables, kernels.cu:227-262 (pressure recomputed the way the kernel does)
+  const T VL[3] = {uL[1] * irL, uL[2] * irL, uL[3] * irL};
+  const T VR[3] = {uR[1] * irR, uR[2] * irR, uR[3] * irR};
+  const T pL2 = km1 * (uL[4] - half * (uL[1] * VL[0] + uL[2] * VL[1] + uL[3] * VL[2]));
+  const T pR2 = km1 * (uR[4] - half * (uR[1] * VR[0] + uR[2] * VR[1] + uR[3] * VR[2]));
+  const T sL  = t8_log(pL2) - kappa * t8_log(uL[0]);
+  const T sR  = t8_log(pR2) - kappa * t8_log(uR[0]);
+  const T rpL = uL[0] / pL2, rpR = uR[0] / pR2;
+  const T v0L = (kappa - sL) / (km1)-half * rpL * (VL[0] * VL[0] + VL[1] * VL[1] + VL[2] * VL[2]);
+  const T v0R = (kappa - sR) / (km1)-half * rpR * (VR[0] * VR[0] + VR[1] * VR[1] + VR[2] * VR[2]);
+  const T J0 = v0R - v0L;
+  const T J1 = rpR * VR[0] - rpL * VL[0];
+  const T J2 = rpR * VR[1] - rpL * VL[1];
+  const T J3 = rpR * VR[2] - rpL * VL[2];
+  const T J4 = (-rpR) - (-rpL);
+
+  const T hm = h - u * a, hp = h + u * a, k2 = static_cast<T>(0.5) * (u * u + v * v + w * w);
+  // d = D o (R^T J), column by column (zeros/ones of R dropped, order of the sums kept)
+  const T d0 = D0 * (J0 + (u - a) * J1 + v * J2 + w * J3 + hm * J4);
+  const T d1 = D1 * (J0 + u * J1 + v * J2 + w * J3 + k2 * J4);
+  const T d2 = D2 * (J2 + v * J4);
+  const T d3 = D2 * (J3 + w * J4);
+  const T d4 = D4 * (J0 + (u + a) * J1 + v * J2 + w * J3 + hp * J4);
+  // R d, row by row
+  F[0] = Fs[0] - half * (d0 + d1 + d4);
+  F[1] = Fs[1] - half * ((u - a) * d0 + u * d1 + (u + a) * d4);
+  F[2] = Fs[2] - half * (v * d0 + v * d1 + d2 + v * d4);
+  F[3] = Fs[3] - half * (w * d0 + w * d1 + d3 + w * d4);
+  F[4] = Fs[4] - half * (hm * d0 + k2 * d1 + v * d2 + w * d3 + hp * d4);
+}
+
+// HLL (reference dead code), kernels.inl:263-332
+template <class T>
+T8_DEV void hll_ref(const T uL[5], const T uR[5], T F[5]) {
+  const T zero = T(0), one = T(1), half = T(0.5);
+  const T g = T(1.4);
+  const T v1l = uL[1] / uL[0], v2l = uL[2] / uL[0], v3l = uL[3] / uL[0];
+  const T pl  = (g - 1) * (uL[4] - half * uL[0] * (v1l * v1l + v2l * v2l + v3l * v3l));
+  const T Hl  = (uL[4] + pl) / uL[0];
+  const T cl  = t8_sqrt((g - 1) * (Hl - half * (v1l * v1l + v2l * v2l + v3l * v3l)));
+  const T v1r = uR[1] / uR[0], v2r = uR[2] / uR[0], v3r = uR[3] / uR[0];
+  const T pr  = (g - one) * (uR[4] - half * uR[0] * (v1r * v1r + v2r * v2r + v3r * v3r));
+  const T Hr  = (uR[4] + pr) / uR[0];
+  const T cr  = t8_sqrt((g - one) * (Hr - half * (v1r * v1r + v2r * v2r + v3r * v3r)));
+  const T wl = t8_sqrt(uL[0]), wr = t8_sqrt(uR[0]);
+  const T ws = wl + wr;
+  const T v1 = (wl * v1l + wr * v1r) / ws;
+  const T v2 = (wl * v2l + wr * v2r) / ws;
+  const T v3 = (wl * v3l + wr * v3r) / ws;
+  const T H  = (wl * Hl + wr * Hr) / ws;
+  const T c  = t8_sqrt((g - one) * (H - half * (v1 * v1 + v2 * v2 + v3 * v3)));
+  const T Sl = t8_min(v1 - c, v1l - cl);
+  const T Sr = t8_max(v1 + c, v1r + cr);
+  const T Fl[5] = {uL[1], uL[1] * uL[1] / uL[0] + pl, uL[1] * v2l, uL[1] * v3l, uL[1] * Hl};
+  const T Fr[5] = {uR[1], uR[1] * uR[1] / uR[0] + pr, uR[1] * v2r, uR[1] * v3r, uR[1] * Hr};
+  const T sl = t8_min(Sl, zero);
+  const T sr = t8_max(Sr, zero);
+#pragma unroll
+  for (int k = 0; k < 5; k++) F[k] = ((sr * Fl[k] - sl * Fr[k]) + sr * sl * (uR[k] - uL[k])) / (sr - sl);
+}
+
+// face frame (n, t1, t2): kernels.cu:174-193 == kernels.inl:133-156
+template <class T>
+T8_DEV void face_basis(const T n[3], T t1[3], T t2[3]) {
+  t1[0] = n[1];
+  t1[1] = n[2];
+  t1[2] = -n[0];
+  const T dp = n[0] * t1[0] + n[1] * t1[1] + n[2] * t1[2];
+  t1[0] -= dp * n[0];
+  t1[1] -= dp * n[1];
+  t1[2] -= dp * n[2];
+  const T nrm = t8_sqrt(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]);
+  t1[0] /= nrm;
+  t1[1] /= nrm;
+  t1[2] /= nrm;
+  t2[0] = n[1] * t1[2] - n[2] * t1[1];
+  t2[1] = n[2] * t1[0] - n[0] * t1[2];
+  t2[2] = n[0] * t1[1] - n[1] * t1[0];
+}
+
+template <class T>
+T8_DEV void to_face_frame(const T n[3], const T t1[3], const T t2[3], const T s[5], T r[5], bool mirror) {
+  r[0]       = s[0];
+  const T mn = s[1] * n[0] + s[2] * n[1] + s[3] * n[2];
+  r[1]       = mirror ? -(mn) : mn;
+  r[2]       = s[1] * t1[0] + s[2] * t1[1] + s[3] * t1[2];
+  r[3]       = s[1] * t2[0] + s[2] * t2[1] + s[3] * t2[2];
+  r[4]       = s[4];
+}
+
+// Face-frame flux of the pair (sL, sR) given in xyz: rotate both states, evaluate the flux.
+// KIND: 0 KEPES, 1 HLL. mirror => right state is the wall reflection of sL
+// (kernels.cu:371-375, kernels.inl:169-176). The caller rotates back with `from_face_frame`;
+// plain kernels scale by the area BEFORE rotating back (kernels.cu:281-290), subgrid kernels
+// AFTER (kernels.inl:395-401).
+template <class T, int KIND>
+T8_DEV void face_frame_flux_ref(const T n[3], const T t1[3], const T t2[3], const T sL[5], const T sR[5],
+                                bool mirror, T Ff[5], T& speed) {
+  T a[5], b[5];
+  to_face_frame<T>(n, t1, t2, sL, a, false);
+  to_face_frame<T>(n, t1, t2, mirror ? sL : sR, b, mirror);
+  if (KIND == 1) {
+    hll_ref<T>(a, b, Ff);
+    speed = T(0);
+  } else {
+    kepes_ref<T>(a, b, Ff, speed);
+  }
+}
+
+template <class T>
+T8_DEV void from_face_frame(const T n[3], const T t1[3], const T t2[3], const T Ff[5], T g[5]) {
+  g[0] = Ff[0];
+  g[1] = Ff[1] * n[0] + Ff[2] * t1[0] + Ff[3] * t2[0];
+  g[2] = Ff[1] * n[1] + Ff[2] * t1[1] + Ff[3] * t2[1];
+  g[3] = Ff[1] * n[2] + Ff[2] * t1[2] + Ff[3] * t2[2];
+  g[4] = Ff[4];
+}
+
+}  // namespace t8gpu_hip

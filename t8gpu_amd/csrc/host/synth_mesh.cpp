@@ -1,0 +1,422 @@
+// synth_mesh.cpp -- t8code-free provider of the hot path's INPUT CONTRACT.
+//
+// The reference builds its face lists by walking a t8code forest
+// (t8gpu/mesh/mesh_manager.inl:333-481, subgrid_mesh_manager.inl:560-961).
+// t8code is not available here, so this file generates the same array formats
+// analytically for a single-tree periodic (or walled) unit square / cube:
+//   * leaves of a 2:1 face-balanced quadtree/octree in Morton (t8code SFC) order,
+//   * face_neighbors / face_normals / face_surfaces (+ face_level_difference,
+//     face_neighbor_offset for Subgrid meshes) with the reference's listing rule
+//     (SURVEY quirk Q4): a same-level face is listed once by the lower-index
+//     element, a hanging face by the finer element; normal outward from the
+//     listing element; t8code face numbering 0:-x 1:+x 2:-y 3:+y 4:-z 5:+z,
+//   * an SFC-contiguous k-way partition with ghost mirror slots appended after
+//     the owned elements and per-peer send/recv lists for the halo exchange.
+// Cross-rank faces are listed on BOTH ranks with the single-rank orientation
+// (redundant flux evaluation instead of remote atomics).
+//
+// Host-only, no HIP: the CPU test-suite and the multi-rank gloo tests use it too.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct Leaf {
+  int32_t  level;
+  uint32_t c[3];
+};
+
+struct Mesh {
+  int    dim = 2, base = 1, lmax = 1, periodic = 1;
+  double band = 0, shrink = 1;
+  std::vector<Leaf>    leaves;
+  std::vector<int32_t> owner;  // finest-level grid -> leaf index
+
+  size_t grid_index(const uint32_t p[3]) const {
+    size_t i = dim == 3 ? p[2] : 0;
+    i        = (i << lmax) + p[1];
+    return (i << lmax) + p[0];
+  }
+
+  bool wants_refine(const Leaf& l) const {
+    if (l.level < base) return true;
+    if (l.level >= lmax) return false;
+    const int    ax = dim - 1;
+    const double h  = std::ldexp(1.0, -l.level);
+    const double c  = (l.c[ax] + 0.5) * h;
+    const double w  = band * std::pow(shrink, l.level - base);
+    const double d0 = std::max(0.0, std::fabs(c - 0.25) - 0.5 * h);
+    const double d1 = std::max(0.0, std::fabs(c - 0.75) - 0.5 * h);
+    return std::min(d0, d1) < w;
+  }
+
+  void push_children(std::vector<Leaf>& out, const Leaf& l) const {
+    for (int ch = 0; ch < (1 << dim); ch++) {
+      Leaf k;
+      k.level = l.level + 1;
+      for (int d = 0; d < 3; d++) k.c[d] = d < dim ? 2 * l.c[d] + ((ch >> d) & 1) : 0;
+      out.push_back(k);
+    }
+  }
+
+  void build_rec(const Leaf& l) {
+    if (wants_refine(l)) {
+      for (int ch = 0; ch < (1 << dim); ch++) {
+        Leaf k;
+        k.level = l.level + 1;
+        for (int d = 0; d < 3; d++) k.c[d] = d < dim ? 2 * l.c[d] + ((ch >> d) & 1) : 0;
+        build_rec(k);
+      }
+    } else {
+      leaves.push_back(l);
+    }
+  }
+
+  void fill_owner() {
+    owner.assign(static_cast<size_t>(1) << (dim * lmax), -1);
+    for (size_t e = 0; e < leaves.size(); e++) {
+      const Leaf&    l = leaves[e];
+      const uint32_t s = 1u << (lmax - l.level);
+      const uint32_t z0 = dim == 3 ? l.c[2] * s : 0, z1 = dim == 3 ? z0 + s : 1;
+      for (uint32_t z = z0; z < z1; z++)
+        for (uint32_t y = l.c[1] * s; y < (l.c[1] + 1) * s; y++) {
+          uint32_t p[3] = {l.c[0] * s, y, z};
+          int32_t* row  = owner.data() + grid_index(p);
+          std::fill(row, row + s, static_cast<int32_t>(e));
+        }
+    }
+  }
+
+  // leaf across face f of leaf e, or -1 at a wall.
+  int32_t across(size_t e, int f) const {
+    const Leaf&    l   = leaves[e];
+    const uint32_t s   = 1u << (lmax - l.level);
+    const uint32_t ext = 1u << lmax;
+    const int      d   = f / 2;
+    uint32_t       p[3] = {l.c[0] * s, l.c[1] * s, dim == 3 ? l.c[2] * s : 0};
+    if (f & 1) {
+      if (p[d] + s >= ext) {
+        if (!periodic) return -1;
+        p[d] = 0;
+      } else {
+        p[d] += s;
+      }
+    } else {
+      if (p[d] == 0) {
+        if (!periodic) return -1;
+        p[d] = ext - 1;
+      } else {
+        p[d] -= 1;
+      }
+    }
+    return owner[grid_index(p)];
+  }
+
+  void build() {
+    leaves.clear();
+    Leaf root{0, {0, 0, 0}};
+    build_rec(root);
+    fill_owner();
+    // 2:1 face balance: a fine leaf marks any face neighbour coarser by >= 2.
+    for (;;) {
+      std::vector<uint8_t> mark(leaves.size(), 0);
+      bool                 any = false;
+      for (size_t e = 0; e < leaves.size(); e++)
+        for (int f = 0; f < 2 * dim; f++) {
+          const int32_t nb = across(e, f);
+          if (nb >= 0 && leaves[nb].level < leaves[e].level - 1) {
+            mark[nb] = 1;
+            any      = true;
+          }
+        }
+      if (!any) break;
+      std::vector<Leaf> next;
+      next.reserve(leaves.size() + leaves.size() / 8);
+      for (size_t e = 0; e < leaves.size(); e++) {
+        if (mark[e])
+          push_children(next, leaves[e]);
+        else
+          next.push_back(leaves[e]);
+      }
+      leaves.swap(next);
+      fill_owner();
+    }
+  }
+};
+
+struct Part {
+  const Mesh* m = nullptr;
+  int         rank = 0, nranks = 1, subgrid = 0, ndim = 3;
+  int64_t     first = 0;
+  int32_t     N = 0, G = 0, F = 0, B = 0;
+  std::vector<int32_t> fn;       // 2F + B
+  std::vector<double>  normals;  // ndim * (F + B)
+  std::vector<double>  areas;    // F + B
+  std::vector<int32_t> level_diff, nb_offset;
+  std::vector<int64_t> ghost_global;
+  std::vector<int32_t> ghost_owner;
+  std::vector<int32_t> peers, recv_off, send_off, send_idx;  // offsets have n_peers + 1 entries
+};
+
+int owner_rank(int64_t g, int64_t n, int nranks) {
+  // inverse of first(r) = floor(n * r / nranks)
+  int r = static_cast<int>((static_cast<__int128>(g + 1) * nranks - 1) / n);
+  while (r > 0 && (n * r) / nranks > g) r--;
+  while (r + 1 < nranks && (n * (r + 1)) / nranks <= g) r++;
+  return r;
+}
+
+void build_part(Part& P) {
+  const Mesh&   M   = *P.m;
+  const int     dim = M.dim;
+  const int64_t n   = static_cast<int64_t>(M.leaves.size());
+  const int64_t lo = (n * P.rank) / P.nranks, hi = (n * (P.rank + 1)) / P.nranks;
+  P.first = lo;
+  P.N     = static_cast<int32_t>(hi - lo);
+
+  struct RawFace {
+    int64_t l, r;
+    int     f;
+  };
+  std::vector<RawFace> faces, walls;
+  for (int64_t e = 0; e < n; e++) {
+    const bool mine = e >= lo && e < hi;
+    for (int f = 0; f < 2 * dim; f++) {
+      const int32_t nb = M.across(static_cast<size_t>(e), f);
+      if (nb < 0) {
+        if (mine) walls.push_back({e, -1, f});
+        continue;
+      }
+      const bool nb_mine = nb >= lo && nb < hi;
+      if (!mine && !nb_mine) continue;
+      const int le = M.leaves[e].level, ln = M.leaves[nb].level;
+      if (ln > le) continue;  // several finer neighbours: they list the face
+      if (nb > e || (nb < e && ln < le)) faces.push_back({e, nb, f});
+    }
+  }
+  // ghosts: referenced elements outside [lo, hi), sorted by global index
+  std::vector<int64_t> gh;
+  for (const RawFace& rf : faces) {
+    if (rf.l < lo || rf.l >= hi) gh.push_back(rf.l);
+    if (rf.r < lo || rf.r >= hi) gh.push_back(rf.r);
+  }
+  std::sort(gh.begin(), gh.end());
+  gh.erase(std::unique(gh.begin(), gh.end()), gh.end());
+  P.ghost_global = gh;
+  P.G            = static_cast<int32_t>(gh.size());
+  P.ghost_owner.resize(gh.size());
+  for (size_t i = 0; i < gh.size(); i++) P.ghost_owner[i] = owner_rank(gh[i], n, P.nranks);
+  auto local = [&](int64_t g) -> int32_t {
+    if (g >= lo && g < hi) return static_cast<int32_t>(g - lo);
+    return P.N + static_cast<int32_t>(std::lower_bound(gh.begin(), gh.end(), g) - gh.begin());
+  };
+
+  P.F = static_cast<int32_t>(faces.size());
+  P.B = static_cast<int32_t>(walls.size());
+  P.fn.resize(2 * static_cast<size_t>(P.F) + P.B);
+  P.normals.assign(static_cast<size_t>(P.ndim) * (P.F + P.B), 0.0);
+  P.areas.resize(static_cast<size_t>(P.F) + P.B);
+  if (P.subgrid) {
+    P.level_diff.resize(P.F);
+    P.nb_offset.assign(static_cast<size_t>(dim) * P.F, 0);
+  }
+  auto geom = [&](size_t slot, int64_t e, int f) {
+    const double h = std::ldexp(1.0, -M.leaves[e].level);
+    P.normals[P.ndim * slot + f / 2] = (f & 1) ? 1.0 : -1.0;
+    P.areas[slot]                    = dim == 3 ? h * h : h;
+  };
+  for (int32_t i = 0; i < P.F; i++) {
+    const RawFace& rf = faces[i];
+    P.fn[2 * static_cast<size_t>(i)]     = local(rf.l);
+    P.fn[2 * static_cast<size_t>(i) + 1] = local(rf.r);
+    geom(i, rf.l, rf.f);
+    if (P.subgrid) {
+      // subgrid_mesh_manager.inl:587-647: anchor inside the right block.
+      const Leaf& L = M.leaves[rf.l];
+      const Leaf& R = M.leaves[rf.r];
+      P.level_diff[i] = R.level - L.level;
+      const int ax = rf.f / 2;
+      for (int d = 0; d < dim; d++) {
+        int o = 0;
+        if (d == ax)
+          o = (rf.f & 1) ? 0 : 3;
+        else if (R.level < L.level)
+          o = 2 * static_cast<int>(L.c[d] & 1u);
+        P.nb_offset[static_cast<size_t>(dim) * i + d] = o;
+      }
+    }
+  }
+  for (int32_t i = 0; i < P.B; i++) {
+    P.fn[2 * static_cast<size_t>(P.F) + i] = local(walls[i].l);
+    geom(static_cast<size_t>(P.F) + i, walls[i].l, walls[i].f);
+  }
+
+  // peers + recv ranges (ghost slots are grouped by owner because sorted by global id)
+  P.peers.clear();
+  P.recv_off.assign(1, 0);
+  for (int32_t g = 0; g < P.G; g++) {
+    if (P.peers.empty() || P.peers.back() != P.ghost_owner[g]) {
+      if (!P.peers.empty()) P.recv_off.push_back(g);
+      P.peers.push_back(P.ghost_owner[g]);
+    }
+  }
+  if (!P.peers.empty()) P.recv_off.push_back(P.G);
+  // send lists: my elements that share a listed face with an element of peer p
+  std::vector<std::vector<int32_t>> send(P.peers.size());
+  auto peer_slot = [&](int r) { return static_cast<size_t>(std::lower_bound(P.peers.begin(), P.peers.end(), r) - P.peers.begin()); };
+  for (int32_t i = 0; i < P.F; i++) {
+    const int32_t l = P.fn[2 * static_cast<size_t>(i)], r = P.fn[2 * static_cast<size_t>(i) + 1];
+    if (l >= P.N && r < P.N) send[peer_slot(P.ghost_owner[l - P.N])].push_back(r);
+    if (r >= P.N && l < P.N) send[peer_slot(P.ghost_owner[r - P.N])].push_back(l);
+  }
+  P.send_off.assign(1, 0);
+  P.send_idx.clear();
+  for (auto& s : send) {
+    std::sort(s.begin(), s.end());
+    s.erase(std::unique(s.begin(), s.end()), s.end());
+    P.send_idx.insert(P.send_idx.end(), s.begin(), s.end());
+    P.send_off.push_back(static_cast<int32_t>(P.send_idx.size()));
+  }
+}
+
+// Kelvin-Helmholtz initial state at a point, SURVEY 8d (restating the values of
+// examples/subgrid/solver.inl:84-103 (2D) and :35-56 (3D), quirk Q8 included:
+// rho_v1 = -/+0.5 is NOT multiplied by rho).
+void kh_state(int dim, const double x[3], double out[5]) {
+  const double kPi = 3.14159265358979323846;
+  const double sigma = 0.05 / std::sqrt(2.0);
+  const double gamma = 1.4;
+  const double s     = x[dim - 1];
+  const bool   in    = std::fabs(s - 0.5) < 0.25;
+  const double rho   = in ? 2.0 : 1.0;
+  const double a = (s - 0.75) / (2 * sigma), b = (s - 0.25) / (2 * sigma);
+  const double pert = rho * (0.1 * std::sin(4.0 * kPi * (x[0] - 0.5)) * (std::exp(-a * a) + std::exp(-b * b)));
+  out[0] = rho;
+  out[1] = in ? -0.5 : 0.5;
+  out[2] = dim == 2 ? pert : 0.0;
+  out[3] = dim == 3 ? pert : 0.0;
+  out[4] = 2.5 / (gamma - 1.0) + 0.5 * (out[1] * out[1] + out[2] * out[2] + out[3] * out[3]) / rho;
+}
+
+}  // namespace
+
+extern "C" {
+
+void* t8gpu_synth_mesh_create(int dim, int base_level, int max_level, double band, double shrink, int periodic) {
+  if (dim < 2 || dim > 3 || base_level < 1 || max_level < base_level || dim * max_level > 28) return nullptr;
+  Mesh* m     = new Mesh;
+  m->dim      = dim;
+  m->base     = base_level;
+  m->lmax     = max_level;
+  m->band     = band;
+  m->shrink   = shrink;
+  m->periodic = periodic;
+  m->build();
+  return m;
+}
+void    t8gpu_synth_mesh_destroy(void* h) { delete static_cast<Mesh*>(h); }
+int64_t t8gpu_synth_mesh_num_elements(const void* h) { return static_cast<int64_t>(static_cast<const Mesh*>(h)->leaves.size()); }
+int     t8gpu_synth_mesh_finest_level(const void* h) {
+  int l = 0;
+  for (const Leaf& k : static_cast<const Mesh*>(h)->leaves) l = std::max(l, k.level);
+  return l;
+}
+
+void* t8gpu_synth_part_create(const void* mesh, int rank, int nranks, int subgrid, int normal_dim) {
+  const Mesh* m = static_cast<const Mesh*>(mesh);
+  if (!m || rank < 0 || rank >= nranks || normal_dim < m->dim || normal_dim > 3) return nullptr;
+  Part* p    = new Part;
+  p->m       = m;
+  p->rank    = rank;
+  p->nranks  = nranks;
+  p->subgrid = subgrid;
+  p->ndim    = normal_dim;
+  build_part(*p);
+  return p;
+}
+void t8gpu_synth_part_destroy(void* h) { delete static_cast<Part*>(h); }
+
+// counts[8] = {N, G, F, B, n_peers, n_send, first_global_lo32, first_global_hi32}
+void t8gpu_synth_part_counts(const void* h, int64_t* counts) {
+  const Part* p = static_cast<const Part*>(h);
+  counts[0] = p->N;
+  counts[1] = p->G;
+  counts[2] = p->F;
+  counts[3] = p->B;
+  counts[4] = static_cast<int64_t>(p->peers.size());
+  counts[5] = static_cast<int64_t>(p->send_idx.size());
+  counts[6] = p->first;
+  counts[7] = static_cast<int64_t>(p->m->leaves.size());
+}
+
+// Any output pointer may be null. normals/areas/volumes/centers are double; the
+// caller converts to float_type (the reference casts t8code doubles the same way,
+// mesh_manager.inl:400-407).
+void t8gpu_synth_part_connectivity(const void* h, int32_t* face_neighbors, double* normals, double* areas,
+                                   int32_t* level_diff, int32_t* nb_offset) {
+  const Part* p = static_cast<const Part*>(h);
+  if (face_neighbors) std::memcpy(face_neighbors, p->fn.data(), p->fn.size() * sizeof(int32_t));
+  if (normals) std::memcpy(normals, p->normals.data(), p->normals.size() * sizeof(double));
+  if (areas) std::memcpy(areas, p->areas.data(), p->areas.size() * sizeof(double));
+  if (level_diff && !p->level_diff.empty()) std::memcpy(level_diff, p->level_diff.data(), p->level_diff.size() * sizeof(int32_t));
+  if (nb_offset && !p->nb_offset.empty()) std::memcpy(nb_offset, p->nb_offset.data(), p->nb_offset.size() * sizeof(int32_t));
+}
+
+// per owned+ghost element: level, volume, centre (N + G entries; centre is [N+G][3])
+void t8gpu_synth_part_elements(const void* h, int32_t* level, double* volume, double* centre) {
+  const Part* p   = static_cast<const Part*>(h);
+  const Mesh& M   = *p->m;
+  const int   tot = p->N + p->G;
+  for (int i = 0; i < tot; i++) {
+    const int64_t g = i < p->N ? p->first + i : p->ghost_global[i - p->N];
+    const Leaf&   l = M.leaves[g];
+    const double  hh = std::ldexp(1.0, -l.level);
+    if (level) level[i] = l.level;
+    if (volume) volume[i] = M.dim == 3 ? hh * hh * hh : hh * hh;
+    if (centre)
+      for (int d = 0; d < 3; d++) centre[3 * static_cast<size_t>(i) + d] = d < M.dim ? (l.c[d] + 0.5) * hh : 0.0;
+  }
+}
+
+// halo plan: ghost_global[G], ghost_owner[G], peers[n_peers], recv_off[n_peers+1] (ghost-slot
+// ranges relative to N), send_off[n_peers+1], send_idx[n_send] (local element indices).
+void t8gpu_synth_part_halo(const void* h, int64_t* ghost_global, int32_t* ghost_owner, int32_t* peers,
+                           int32_t* recv_off, int32_t* send_off, int32_t* send_idx) {
+  const Part* p = static_cast<const Part*>(h);
+  if (ghost_global) std::copy(p->ghost_global.begin(), p->ghost_global.end(), ghost_global);
+  if (ghost_owner) std::copy(p->ghost_owner.begin(), p->ghost_owner.end(), ghost_owner);
+  if (peers) std::copy(p->peers.begin(), p->peers.end(), peers);
+  if (recv_off) std::copy(p->recv_off.begin(), p->recv_off.end(), recv_off);
+  if (send_off) std::copy(p->send_off.begin(), p->send_off.end(), send_off);
+  if (send_idx) std::copy(p->send_idx.begin(), p->send_idx.end(), send_idx);
+}
+
+// Kelvin-Helmholtz initial condition for owned AND ghost elements.
+// cells_per_dim = 1: one value per element (plain path), out = 5 planes of `stride` doubles;
+// cells_per_dim = 4: Subgrid<4,..>, value per subcell at index e*S + i + 4j + 16k.
+void t8gpu_synth_part_kh_ic(const void* h, int cells_per_dim, double* out, size_t stride) {
+  const Part* p   = static_cast<const Part*>(h);
+  const Mesh& M   = *p->m;
+  const int   dim = M.dim;
+  const int   E   = cells_per_dim;
+  const int   S   = dim == 3 ? E * E * E : E * E;
+  const int   tot = p->N + p->G;
+  for (int i = 0; i < tot; i++) {
+    const int64_t g  = i < p->N ? p->first + i : p->ghost_global[i - p->N];
+    const Leaf&   l  = M.leaves[g];
+    const double  hh = std::ldexp(1.0, -l.level);
+    for (int c = 0; c < S; c++) {
+      const int ci[3] = {c % E, (c / E) % E, c / (E * E)};
+      double    x[3]  = {0, 0, 0};
+      for (int d = 0; d < dim; d++) x[d] = (l.c[d] + (ci[d] + 0.5) / E) * hh;
+      double u[5];
+      kh_state(dim, x, u);
+      for (int k = 0; k < 5; k++) out[k * stride + static_cast<size_t>(i) * S + c] = u[k];
+    }
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+"""ctypes mirror of csrc/host/synth_mesh.cpp (the t8code-free mesh provider)."""
+import ctypes as C
+import numpy as np
+
+from . import build as _build
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(_build.build_host())
+        _lib.t8gpu_synth_mesh_create.restype = C.c_void_p
+        _lib.t8gpu_synth_mesh_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
+        _lib.t8gpu_synth_mesh_destroy.argtypes = [C.c_void_p]
+        _lib.t8gpu_synth_mesh_num_elements.restype = C.c_int64
+        _lib.t8gpu_synth_mesh_num_elements.argtypes = [C.c_void_p]
+        _lib.t8gpu_synth_mesh_finest_level.restype = C.c_int
+        _lib.t8gpu_synth_mesh_finest_level.argtypes = [C.c_void_p]
+        _lib.t8gpu_synth_part_create.restype = C.c_void_p
+        _lib.t8gpu_synth_part_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _lib.t8gpu_synth_part_destroy.argtypes = [C.c_void_p]
+        _lib.t8gpu_synth_part_counts.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.t8gpu_synth_part_connectivity.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        _lib.t8gpu_synth_part_elements.argtypes = [C.c_void_p] + [C.c_void_p] * 3
+        _lib.t8gpu_synth_part_halo.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        _lib.t8gpu_synth_part_kh_ic.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class SynthMesh:
+    """Global 2:1-balanced periodic (or walled) quad/hex mesh in Morton order."""
+
+    def __init__(self, dim, base_level, max_level, band=0.0, shrink=1.0, periodic=True):
+        self.dim, self.base_level, self.max_level = dim, base_level, max_level
+        self._h = lib().t8gpu_synth_mesh_create(dim, base_level, max_level, float(band), float(shrink), int(periodic))
+        if not self._h:
+            raise ValueError("invalid synthetic mesh parameters")
+        self.num_elements = lib().t8gpu_synth_mesh_num_elements(self._h)
+        self.finest_level = lib().t8gpu_synth_mesh_finest_level(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().t8gpu_synth_mesh_destroy(self._h)
+            self._h = None
+
+    def partition(self, rank=0, nranks=1, subgrid=False, normal_dim=None):
+        return Partition(self, rank, nranks, subgrid, normal_dim)
+
+
+class Partition:
+    """One rank's share: the exact arrays the reference's connectivity accessors expose
+    (t8gpu/mesh/mesh_manager.h:159-166, subgrid_mesh_manager.h), ghosts in slots [N, N+G)."""
+
+    def __init__(self, mesh, rank, nranks, subgrid, normal_dim):
+        self.mesh, self.rank, self.nranks, self.subgrid = mesh, rank, nranks, bool(subgrid)
+        dim = mesh.dim
+        if normal_dim is None:
+            normal_dim = dim if subgrid else 3  # MeshManager<..., 3> stores 3 comps
+        self.normal_dim = normal_dim
+        h = lib().t8gpu_synth_part_create(mesh._h, rank, nranks, int(self.subgrid), normal_dim)
+        if not h:
+            raise ValueError("invalid partition parameters")
+        try:
+            cnt = np.zeros(8, np.int64)
+            lib().t8gpu_synth_part_counts(h, _p(cnt))
+            self.N, self.G, self.F, self.B, npeer, nsend = (int(x) for x in cnt[:6])
+            self.first_global, self.num_global = int(cnt[6]), int(cnt[7])
+            self.face_neighbors = np.zeros(2 * self.F + self.B, np.int32)
+            self.normals = np.zeros(normal_dim * (self.F + self.B), np.float64)
+            self.areas = np.zeros(self.F + self.B, np.float64)
+            self.level_diff = np.zeros(self.F, np.int32) if subgrid else None
+            self.nb_offset = np.zeros(dim * self.F, np.int32) if subgrid else None
+            lib().t8gpu_synth_part_connectivity(h, _p(self.face_neighbors), _p(self.normals), _p(self.areas),
+                                                _p(self.level_diff), _p(self.nb_offset))
+            tot = self.N + self.G
+            self.levels = np.zeros(tot, np.int32)
+            self.volumes = np.zeros(tot, np.float64)
+            self.centres = np.zeros((tot, 3), np.float64)
+            lib().t8gpu_synth_part_elements(h, _p(self.levels), _p(self.volumes), _p(self.centres))
+            self.ghost_global = np.zeros(self.G, np.int64)
+            self.ghost_owner = np.zeros(self.G, np.int32)
+            self.peers = np.zeros(npeer, np.int32)
+            self.recv_off = np.zeros(npeer + 1, np.int32)
+            self.send_off = np.zeros(npeer + 1, np.int32)
+            self.send_idx = np.zeros(nsend, np.int32)
+            lib().t8gpu_synth_part_halo(h, _p(self.ghost_global), _p(self.ghost_owner), _p(self.peers),
+                                        _p(self.recv_off), _p(self.send_off), _p(self.send_idx))
+            self._ic = {}
+            for cpd in ((4,) if subgrid else (1,)):
+                S = cpd ** dim
+                out = np.zeros((5, tot * S), np.float64)
+                lib().t8gpu_synth_part_kh_ic(h, cpd, _p(out), tot * S)
+                self._ic[cpd] = out
+        finally:
+            lib().t8gpu_synth_part_destroy(h)
+        # ranks[]/indices[] of the reference accessors (mesh_manager.h:141-157): ghosts resolve to local slots.
+        self.ranks = np.full(tot, rank, np.int32)
+        self.indices = np.arange(tot, dtype=np.int32)
+
+    @property
+    def cells_per_element(self):
+        return 4 ** self.mesh.dim if self.subgrid else 1
+
+    def kh_initial_state(self):
+        """(5, (N+G)*S) float64 Kelvin-Helmholtz state, ghosts included."""
+        return self._ic[4 if self.subgrid else 1]

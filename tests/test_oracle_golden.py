@@ -1,0 +1,93 @@
+"""Pins the CPU oracle: the SURVEY 8c known-answer vectors (the only ones that exist for this path)
+plus the algebraic invariants the scheme guarantees (last rows)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "survey_8c_kat.json")))
+
+
+def test_kat_kepes_f64_every_digit():
+    F = O.face_frame_flux(0, np.array([GOLD["uL"]], np.float64), np.array([GOLD["uR"]], np.float64))[0]
+    # the survey printed 17 significant digits: bit-exact round trip
+    assert [float(x) for x in F] == GOLD["kepes_f64"]
+
+
+def test_kat_kepes_f32_nine_digits():
+    F = O.face_frame_flux(0, np.array([GOLD["uL"]], np.float32), np.array([GOLD["uR"]], np.float32))[0]
+    assert [float("%.9g" % x) for x in F] == GOLD["kepes_f32"]
+
+
+def test_kat_hll_f32_nine_digits():
+    F = O.face_frame_flux(1, np.array([GOLD["uL"]], np.float32), np.array([GOLD["uR"]], np.float32))[0]
+    assert [float("%.9g" % x) for x in F] == GOLD["hll_f32"]
+
+
+def test_ln_mean_branches():
+    # series branch (u < 1e-4, kernels.cu:29-32) and log branch agree where they meet; a == b -> a
+    a = np.array([1.0, 1.0, 1.0, 2.0])
+    b = np.array([1.0, 1.0 + 1e-9, 1.0201, 5.0])
+    m = O.ln_mean(a, b)
+    assert m[0] == 1.0
+    exact = (b[1:] - a[1:]) / np.log(b[1:] / a[1:])
+    assert np.allclose(m[1:], exact, rtol=1e-9)
+    # either side of the branch switch (xi ~ 1.0202 gives u ~ 1e-4)
+    xi = np.array([1.02019, 1.02021])
+    assert abs(np.diff(O.ln_mean(np.ones(2), xi) - (xi - 1) / np.log(xi))[0]) < 1e-10
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-12), (np.float32, 2e-5)])
+def test_flux_consistency_and_antisymmetry(kind, dtype, tol):
+    n = 2000
+    sL, sR = O.random_states(n, 2024, dtype), O.random_states(n, 2025, dtype)
+    rng = np.random.default_rng(7)
+    nrm = rng.normal(size=(n, 3))
+    nrm[: n // 4] = np.eye(3)[rng.integers(0, 3, n // 4)] * rng.choice([-1.0, 1.0], (n // 4, 1))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm = nrm.astype(dtype)
+    # F(uL, uR; n) = -F(uR, uL; -n)
+    F = O.xyz_face_flux(kind, nrm, sL, sR)
+    G = O.xyz_face_flux(kind, -nrm, sR, sL)
+    scale = np.abs(F).max()
+    assert np.abs(F + G).max() <= 50 * tol * scale
+    # consistency F(u, u; n) = f(u).n
+    C = O.xyz_face_flux(kind, nrm, sL, sL).astype(np.float64)
+    s = sL.astype(np.float64)
+    v = s[:, 1:4] / s[:, :1]
+    pr = 0.4 * (s[:, 4] - 0.5 * (s[:, 1:4] * v).sum(1))
+    vn = (v * nrm).sum(1)
+    exact = np.stack([s[:, 0] * vn] + [s[:, 1 + d] * vn + pr * nrm[:, d] for d in range(3)] + [(s[:, 4] + pr) * vn], 1)
+    assert np.abs(C - exact).max() <= 50 * tol * np.abs(exact).max()
+
+
+def test_wall_flux_has_no_mass_or_energy():
+    s = O.random_states(500, 3, np.float64)
+    nrm = np.tile(np.array([[0.0, -1.0, 0.0]]), (500, 1))
+    W = O.xyz_face_flux(0, nrm, s, s, mirror=True)
+    assert np.abs(W[:, 0]).max() < 1e-13 and np.abs(W[:, 4]).max() < 1e-12
+    assert np.abs(W[:, 1]).max() < 1e-13 and np.abs(W[:, 3]).max() < 1e-13   # only normal momentum (pressure)
+    at_rest = s.copy()
+    at_rest[:, 1:4] = 0
+    at_rest[:, 4] = 2.5
+    Wr = O.xyz_face_flux(0, nrm, at_rest, at_rest, mirror=True)
+    assert np.allclose(Wr[:, 2], -1.0)                                      # fluid at rest: p * n_y, p = 0.4 * 2.5
+
+
+def test_rk3_truncated_coefficients_quirk_q1():
+    # ssp_runge_kutta.inl:12-14,23-25: 0.33333333333333 / 0.66666666666666, not 1/3, 2/3
+    import ctypes as C
+    n = 4
+    prev = np.full((5, n), 3.0)
+    mid = np.full((5, n), 6.0)
+    out = np.zeros((5, n))
+    flux = np.full((5, n), 9.0)
+    vol = np.full(n, 2.0)
+    O.lib().oracle_plain_rk_stage_f64(3, n, O.p(prev), O.p(mid), O.p(out), O.p(flux), C.c_size_t(n), O.p(vol), C.c_double(0.5))
+    assert out[0, 0] == 0.33333333333333 * 3.0 + 0.66666666666666 * 6.0 + 0.66666666666666 * 0.5 / 2.0 * 9.0
+    assert out[0, 0] != 3.0 / 3 + 6.0 * 2 / 3 + (2.0 / 3) * 0.5 / 2.0 * 9.0
+    assert (flux == 0).all()                      # every stage zeroes the flux planes

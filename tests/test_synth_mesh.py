@@ -1,0 +1,97 @@
+"""The t8code-free mesh provider must emit the reference's connectivity contract."""
+import numpy as np
+import pytest
+
+from t8gpu_amd.synth import SynthMesh
+
+
+def test_c1_uniform_counts():
+    m = SynthMesh(2, 8, 8)
+    p = m.partition()
+    assert (p.N, p.F, p.B, p.G) == (65536, 131072, 0, 0)
+    assert p.normal_dim == 3 and (p.normals.reshape(-1, 3)[:, 2] == 0).all()
+    assert np.allclose(p.areas, 2.0 ** -8) and np.allclose(p.volumes, 4.0 ** -8)
+    l, r = p.face_neighbors[0::2], p.face_neighbors[1::2]
+    assert (l < r).all()                                        # same level: listed by the lower index
+
+
+@pytest.mark.parametrize("dim,base,lmax,band", [(2, 3, 6, 0.06), (3, 2, 4, 0.1)])
+def test_amr_balance_orientation_and_closure(dim, base, lmax, band):
+    m = SynthMesh(dim, base, lmax, band=band)
+    p = m.partition()
+    lv = p.levels
+    l, r = p.face_neighbors[0::2], p.face_neighbors[1::2]
+    assert np.abs(lv[l] - lv[r]).max() == 1                      # 2:1 balanced, and AMR present
+    assert (lv[l] >= lv[r]).all()                               # hanging face listed by the finer element
+    same = lv[l] == lv[r]
+    assert (l[same] < r[same]).all()
+    h = 2.0 ** -lv[l].astype(float)
+    assert np.allclose(p.areas, h ** (dim - 1))                  # area of the listing (fine) element's face
+    # closed cells: sum of outward area vectors is zero for every element
+    nrm = p.normals.reshape(-1, p.normal_dim) * p.areas[:, None]
+    acc = np.zeros((p.N, p.normal_dim))
+    np.add.at(acc, l, nrm)
+    np.add.at(acc, r, -nrm)
+    assert np.abs(acc).max() < 1e-14
+    assert np.isclose(p.volumes.sum(), 1.0)
+
+
+def test_walls_become_boundary_faces():
+    m = SynthMesh(2, 3, 5, band=0.05, periodic=False)
+    p = m.partition()
+    assert p.B > 0 and p.face_neighbors.size == 2 * p.F + p.B
+    nb = p.normals.reshape(-1, 3)[p.F:]
+    ab = p.areas[p.F:]
+    assert np.isclose(ab[nb[:, 0] == -1].sum(), 1.0) and np.isclose(ab[nb[:, 1] == 1].sum(), 1.0)
+
+
+def test_subgrid_fields_match_add_face_rules():
+    # subgrid_mesh_manager.inl:587-647: level difference <= 0, offset = anchor inside the right block
+    m = SynthMesh(3, 3, 4, band=0.03)
+    p = m.partition(subgrid=True)
+    assert p.normal_dim == 3 and set(np.unique(p.level_diff)) == {-1, 0}
+    off = p.nb_offset.reshape(-1, 3)
+    nrm = p.normals.reshape(-1, 3)
+    ax = np.abs(nrm).argmax(1)
+    sign = nrm[np.arange(p.F), ax]
+    assert (off[np.arange(p.F), ax] == np.where(sign > 0, 0, 3)).all()
+    same = p.level_diff == 0
+    tang = off.copy()
+    tang[np.arange(p.F), ax] = 0
+    assert (tang[same] == 0).all() and set(np.unique(tang[~same])) == {0, 2}
+    m2 = SynthMesh(2, 3, 5, band=0.03)
+    p2 = m2.partition(subgrid=True)
+    assert p2.normal_dim == 2 and p2.nb_offset.size == 2 * p2.F
+
+
+@pytest.mark.parametrize("k", [2, 3, 8])
+def test_partition_halo_plan_is_symmetric(k):
+    m = SynthMesh(2, 3, 6, band=0.06)
+    parts = [m.partition(r, k) for r in range(k)]
+    assert sum(p.N for p in parts) == m.num_elements
+    whole = m.partition()
+    # every global face appears on the rank(s) owning its two sides
+    assert sum(p.F for p in parts) >= whole.F
+    for p in parts:
+        assert (p.ghost_owner != p.rank).all()
+        assert (np.diff(p.ghost_global) > 0).all()
+        for j, q in enumerate(p.peers):
+            other = parts[q]
+            jj = list(other.peers).index(p.rank)
+            mine = p.first_global + p.send_idx[p.send_off[j]:p.send_off[j + 1]]
+            theirs = other.ghost_global[other.recv_off[jj]:other.recv_off[jj + 1]]
+            assert (mine == theirs).all()                       # what I send is exactly what the peer mirrors
+
+
+def test_kh_initial_state_values():
+    m = SynthMesh(2, 4, 4)
+    p = m.partition()
+    u = p.kh_initial_state()
+    y = p.centres[:, 1]
+    inside = np.abs(y - 0.5) < 0.25
+    assert (u[0][inside] == 2).all() and (u[0][~inside] == 1).all()
+    assert (u[1][inside] == -0.5).all() and (u[1][~inside] == 0.5).all()     # quirk Q8: not multiplied by rho
+    assert (u[3] == 0).all()
+    assert np.allclose(u[4], 2.5 / 0.4 + 0.5 * (u[1] ** 2 + u[2] ** 2) / u[0])
+    ps = m.partition(subgrid=True)
+    assert ps.kh_initial_state().shape == (5, ps.N * 16)
