@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- M cell-updates/s of the flux + SSP-RK3 step on the synthetic Kelvin-Helmholtz AMR mesh.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one full iterate() (3 flux evaluations + 3 RK stages) over the whole mesh; one
+cell-update = one element advanced by one step. Inputs are resident in HBM before
+the timed region. Rank 0 prints ONE JSON line carrying `roofline` (dominant kernel, HIP-event timed
+inside the timed region) and `cpu_baseline` (the CPU oracle on a bounded sample, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+# Workloads. c4 is the north-star mesh (~10 M elements, strong-scaled over the ranks).
+WORKLOADS = {
+    "c1": dict(kind="plain", dim=2, base=8, lmax=8, band=0.0, dtype="f64", desc="2D KH uniform 256^2 quads"),
+    "c2": dict(kind="plain", dim=2, base=6, lmax=11, band=0.0596, dtype="f64", desc="2D KH AMR levels 6-11 (~1.03 M elements)"),
+    "c3": dict(kind="subgrid", dim=3, base=5, lmax=6, band=0.14, dtype="f32", desc="3D Subgrid<4,4,4> AMR levels 5-6"),
+    "c4": dict(kind="plain", dim=2, base=7, lmax=12, band=0.1472, dtype="f64", desc="2D KH AMR levels 7-12 (~9.93 M elements)"),
+}
+
+
+def algorithmic_bytes(kind, ft, phi, d=3, phi_c=3.0):
+    """SURVEY 8d / BASELINE.md: compulsory bytes per cell-update of the reference's dataflow.
+    Returns (per cell-update, [per-stage bytes of the flux part, RK part per stage x3])."""
+    if kind == "plain":
+        flux_stage = (10 * ft + 8) + phi * (8 + (d + 2) * ft)
+        rk = [21 * ft, 26 * ft, 26 * ft]
+        return 3 * flux_stage + sum(rk), flux_stage, rk
+    flux_stage = 10 * ft + (ft + 8 + phi_c * (24 + 4 * ft)) / 64.0
+    rk = [(20 + 1 / 64.0) * ft, (25 + 1 / 64.0) * ft, (25 + 1 / 64.0) * ft]
+    return 3 * flux_stage + sum(rk), flux_stage, rk
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default=os.environ.get("T8GPU_BENCH_MODE", "auto"), choices=["auto", "compat", "fused"])
+    ap.add_argument("--flux", default="kepes", choices=["kepes", "hll"])
+    ap.add_argument("--dtype", default=None, choices=[None, "f32", "f64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the hot path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+
+    from t8gpu_amd import hip
+    from t8gpu_amd.solver import PlainSolver, SubgridSolver
+    from t8gpu_amd.synth import SynthMesh
+
+    hip.lib()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    w = WORKLOADS[args.workload]
+    dts = args.dtype or w["dtype"]
+    tdtype = torch.float64 if dts == "f64" else torch.float32
+    ft = 8 if dts == "f64" else 4
+    kindf = hip.KEPES if args.flux == "kepes" else hip.HLL
+    mode = args.mode
+    if mode == "auto":
+        try:
+            from t8gpu_amd import fused  # noqa: F401
+            mode = "fused" if w["kind"] == "plain" or hasattr(fused, "SubgridPlan") else "compat"
+        except ImportError:
+            mode = "compat"
+
+    t0 = time.time()
+    mesh = SynthMesh(w["dim"], w["base"], w["lmax"], band=w["band"])
+    part = mesh.partition(rank, world, subgrid=(w["kind"] == "subgrid"))
+    n_global = mesh.num_elements
+    cells = part.cells_per_element
+    if w["kind"] == "plain":
+        solver = PlainSolver(part, tdtype, flux_kind=kindf, mode=mode)
+        delta_t = 0.1 * 2.0 ** -mesh.finest_level
+    else:
+        solver = SubgridSolver(part, tdtype, flux_kind=kindf, mode=mode)
+        delta_t = 0.1 * 2.0 ** -(mesh.finest_level + 2)
+    halo = None
+    if world > 1:
+        from t8gpu_amd import halo as halo_mod
+        halo = halo_mod.HaloExchange(part, solver, dist)
+    setup_s = time.time() - t0
+
+    # HIP-event timing of the dominant kernel (events recorded on the launch stream by the solver)
+    timers = []
+    solver.kernel_timer = None
+
+    def run(nsteps, timed):
+        for _ in range(nsteps):
+            solver.kernel_timer = timers if timed else None
+            solver.iterate(delta_t, halo=halo)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(args.warmup, False)
+    fence()
+    t1 = time.perf_counter()
+    run(args.steps, True)
+    fence()
+    elapsed = time.perf_counter() - t1
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # sanity: the solution must still be finite (a diverged run is not a measurement)
+    finite = bool(torch.isfinite(solver.state()).all().item())
+
+    total_cells = n_global * cells
+    value = total_cells * args.steps / elapsed / 1e6
+    phi = part.F / max(1, part.N)
+    per_update, flux_stage, rk = algorithmic_bytes(w["kind"], ft, phi if w["kind"] == "plain" else 0, 3, phi)
+    # dominant kernel: the fused stage kernel (flux + RK of one stage) or the face-flux kernel
+    if timers:
+        ms = [a.elapsed_time(b) for a, b in timers]
+        avg_ms = sum(ms) / len(ms)
+        local_cells = part.N * cells
+        if mode == "fused":
+            per_launch = local_cells * (flux_stage + sum(rk) / 3.0)
+            kname = "fused_stage (flux + RK of one stage)"
+        else:
+            per_launch = local_cells * flux_stage
+            kname = "flux_faces" if w["kind"] == "plain" else "subgrid_inner+outer"
+        achieved = per_launch / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                "algorithmic_bytes_per_launch": int(per_launch), "launches_timed": len(ms)}
+    else:
+        roof = None
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(part, w, dts, delta_t, kindf, args.cpu_seconds)
+
+    if rank == 0:
+        out = {
+            "metric": "M cell-updates/sec (flux+RK3 step) on Kelvin-Helmholtz AMR",
+            "value": round(value, 2), "unit": "M cell-updates/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": dts, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {w['desc']}", "elements": int(n_global),
+                       "cells": int(total_cells), "faces_per_element": round(phi, 4), "flux": args.flux,
+                       "kernels": mode, "partition": f"sfc-contiguous x{world}", "delta_t": delta_t,
+                       "algorithmic_bytes_per_cell_update": round(per_update, 1), "finite": finite,
+                       "setup_s": round(setup_s, 1)},
+            "hbm_frac_whole_step": round(value * 1e6 * per_update / world / (HBM_PEAK_GBS * 1e9), 4),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(part, w, dts, delta_t, kindf, budget_s):
+    """The CPU oracle (a port: the reference has no CPU path) timed on this box's host cores on a
+    bounded sample: whole steps of the same mesh until ~budget_s of wall time is spent."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    npdt = np.float64 if dts == "f64" else np.float32
+    case = O.PlainCase(part, npdt) if w["kind"] == "plain" else O.SubgridCase(part, npdt)
+    threads = O.lib(omp=True).oracle_num_threads()
+    cells = part.N * part.cells_per_element
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        case.iterate(delta_t, kind=kindf, omp=True)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or steps >= 50 or el / steps * (steps + 1) > 2 * budget_s:
+            break
+    return {"value": round(cells * steps / el / 1e6, 3), "unit": "M cell-updates/s", "cores": int(threads),
+            "kind": "port", "sample": f"{steps} full step(s) of the same mesh ({cells} cells), OpenMP oracle, "
+            f"{el:.1f} s wall", "cpu_model": _cpu_model()}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+if __name__ == "__main__":
+    main()

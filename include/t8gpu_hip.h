@@ -111,6 +111,38 @@ int t8gpu_hip_subgrid_rk3_stage_f64(int stage, int rank, int num_elements, T8gpu
                                     T8gpuVars_f64 out, T8gpuVars_f64 fluxes, const double* volumes, double delta_t,
                                     void* stream);
 
+/* ---- plain elements, fused tile kernels ("fast" tier) ------------------------------------------
+ * One launch per RK stage replaces kepes_compute_fluxes + reflective_boundary_condition +
+ * SSP_3RK_stepK of that stage (solver.cu:81-110 / 115-142 / 147-174): every tile (compact window of
+ * owned elements) stages per-element primitives in LDS, evaluates each of its faces once, sums the
+ * fluxes per element in a fixed order and applies the RK stage. The Fluxes planes are neither read
+ * nor written (the reference leaves them zero after every stage); speed_estimates is written as the
+ * reference does (may be NULL). The plan is built on the host by t8gpu_plan_plain_create()
+ * (t8gpu_amd/csrc/host/tile_plan.cpp) at every connectivity rebuild and uploaded by the caller. */
+typedef struct T8gpuPlainPlan {
+  const int32_t*  elem_off;   /* [ntiles+1] first owned element of each tile                      */
+  const int32_t*  halo_off;   /* [ntiles+1] into halo_ids                                         */
+  const int32_t*  face_off;   /* [ntiles+1] into face_*                                           */
+  const int32_t*  halo_ids;   /* slots of outside elements (other tiles / ghost mirrors)          */
+  const uint32_t* face_lr;    /* tile-local l | r << 16 (r = 0xFFFF: reflective wall)             */
+  const void*     face_geo;   /* float_type [n_faces][4] = nx, ny, nz, area                       */
+  const int32_t*  face_orig;  /* original face index if this tile reports the speed, else -1      */
+  const int32_t*  csr_off;    /* [N+1] into csr_ent                                               */
+  const uint16_t* csr_ent;    /* tile-local face | 0x8000 when the element is the face's right side */
+  const int32_t*  tile_order; /* [ntiles] interior tiles first, then tiles reading ghost slots    */
+  int32_t ntiles, n_interior_tiles, max_elems, max_halo, max_faces, reserved;
+} T8gpuPlainPlan;
+
+/* tile_begin/tile_count select a range of tile_order (0, ntiles = everything; [0, n_interior) can run
+ * while the halo exchange of `src` is still in flight, [n_interior, ntiles) after it). mid = state
+ * the fluxes are evaluated on (prev for stage 1, Step1, Step2); ghost slots of `mid` must be current. */
+int t8gpu_hip_plain_fused_stage_f32(int flux_kind, int stage, const T8gpuPlainPlan* plan, int tile_begin,
+                                    int tile_count, T8gpuVars_f32 prev, T8gpuVars_f32 mid, T8gpuVars_f32 out,
+                                    const float* volume, float delta_t, float* speed_estimates, void* stream);
+int t8gpu_hip_plain_fused_stage_f64(int flux_kind, int stage, const T8gpuPlainPlan* plan, int tile_begin,
+                                    int tile_count, T8gpuVars_f64 prev, T8gpuVars_f64 mid, T8gpuVars_f64 out,
+                                    const double* volume, double delta_t, double* speed_estimates, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

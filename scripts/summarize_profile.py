@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 CSVs written by scripts/profile_gpu.sh into one markdown summary
+(per-kernel average duration, HBM bytes per launch with the gfx950 FETCH_SIZE x2 correction of
+MI355X_MICROARCH.md section HBM, and SQ counter ratios)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.replace("void t8gpu_hip::", "").replace("t8gpu_hip::", "")
+    return name.split("(")[0][:60]
+
+
+def kernel_stats(d):
+    rows = []
+    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+        rows += list(csv.DictReader(open(f)))
+    return rows
+
+
+def counters(d):
+    """kernel -> counter -> (sum, n) over dispatches."""
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            a = acc[short(r["Kernel_Name"])][r["Counter_Name"]]
+            a[0] += float(r["Counter_Value"])
+            a[1] += 1
+    return acc
+
+
+def main(out):
+    print(f"# rocprofv3 summary: {os.path.basename(out)}\n")
+    for log in ("stats.log",):
+        p = os.path.join(out, log)
+        if os.path.exists(p):
+            for line in open(p):
+                if line.startswith("{"):
+                    j = json.loads(line)
+                    print(f"bench line (under kernel-trace): value={j['value']} {j['unit']}, ms_per_step={j['ms_per_step']}, "
+                          f"roofline={json.dumps(j['roofline'])}\n")
+    print("## kernel-trace --stats\n\n| kernel | calls | avg us | total % |\n|---|---|---|---|")
+    for r in sorted(kernel_stats(os.path.join(out, "stats")), key=lambda r: -float(r["TotalDurationNs"]))[:12]:
+        print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |")
+    fetch, write, sq = (counters(os.path.join(out, k)) for k in ("fetch", "write", "sq"))
+    print("\n## HBM traffic per launch (PMC, separate passes)\n\nFETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled "
+          "(gfx950 counts 128-B read requests as 64 B for wide coalesced streams, MI355X_MICROARCH.md section HBM), so the "
+          "read figure is an upper estimate where accesses are narrow.\n\n| kernel | FETCH_SIZE KiB | x2 read MB | WRITE_SIZE KiB | write MB | total MB |\n|---|---|---|---|---|---|")
+    for k in sorted(set(fetch) | set(write)):
+        fs = fetch[k]["FETCH_SIZE"]
+        ws = write[k]["WRITE_SIZE"]
+        f = fs[0] / fs[1] if fs[1] else 0.0
+        w = ws[0] / ws[1] if ws[1] else 0.0
+        print(f"| {k} | {f:.0f} | {2 * f * 1024 / 1e6:.1f} | {w:.0f} | {w * 1024 / 1e6:.1f} | {(2 * f + w) * 1024 / 1e6:.1f} |")
+    print("\n## SQ counters per launch (averages)\n")
+    names = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
+             "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]
+    print("| kernel | " + " | ".join(n.replace("SQ_", "") for n in names) + " |\n|---|" + "---|" * len(names))
+    for k in sorted(sq):
+        vals = [sq[k][n][0] / sq[k][n][1] if sq[k][n][1] else 0.0 for n in names]
+        print(f"| {k} | " + " | ".join(f"{v:.3g}" for v in vals) + " |")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1].rstrip("/"))

@@ -5,7 +5,7 @@
 //                220-279; examples/subgrid/kernels.inl:132-332), kept for the reference-dataflow
 //                ("compat") kernels. The eigenvector matrix is applied in its sparse form; dropping
 //                exact zeros and ones leaves every rounding step of the dense loops unchanged.
-//   * `Prim` + `kepes_prim` : per-ELEMENT quantities (1/rho, velocity, p, beta, logs, entropy
+//   * `Prim` + `kepes_prim` : per-ELEMENT quantities (velocity, p, beta, logs, entropy
 //                variable) are computed once per element and stage, so a face costs no log and a
 //                third of the divisions. Used by the fused tile kernels.
 #pragma once
@@ -214,6 +214,137 @@ T8_DEV void from_face_frame(const T n[3], const T t1[3], const T t2[3], const T 
   g[2] = Ff[1] * n[1] + Ff[2] * t1[1] + Ff[3] * t2[1];
   g[3] = Ff[1] * n[2] + Ff[2] * t1[2] + Ff[3] * t2[2];
   g[4] = Ff[4];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-element formulation (fused tile kernels).
+//
+// Everything in the KEPES flux that depends on ONE cell only is evaluated once per element and
+// stage: velocity, pressure, beta = rho/(2p), log(rho), log(2 beta) and the first entropy variable.
+// A face then needs no logarithm (log(aR/aL) = log aR - log aL; the series branch of ln_mean takes
+// over before that difference loses accuracy: |log| >= 0.02 outside it) and 7 divisions instead of
+// ~20. Frame-invariant pieces (|v|^2, the scalar entropy variable) are not rotated at all.
+// Same flux as kernels.cu:38-133,220-279 up to rounding (a few ulp; parity tolerance in tests/).
+// ------------------------------------------------------------------------------------------------
+template <class T>
+struct Prim {
+  T rho, vx, vy, vz, p, beta, lrho, lbeta, v0;
+};
+constexpr int kPrimWords = 9;
+
+template <class T>
+T8_DEV Prim<T> prim_from_state(const T s[5]) {
+  const T one = T(1), half = T(0.5), kappa = T(1.4);
+  const T km1 = kappa - one;
+  Prim<T> q;
+  const T ir = one / s[0];
+  q.rho      = s[0];
+  q.vx       = s[1] * ir;
+  q.vy       = s[2] * ir;
+  q.vz       = s[3] * ir;
+  const T ke = half * (q.vx * q.vx + q.vy * q.vy + q.vz * q.vz);
+  q.p        = km1 * (s[4] - s[0] * ke);
+  const T rp = s[0] / q.p;
+  q.beta     = half * rp;
+  q.lrho     = t8_log(s[0]);
+  const T lp = t8_log(q.p);
+  q.lbeta    = q.lrho - lp;
+  q.v0       = (kappa - (lp - kappa * q.lrho)) / km1 - rp * ke;
+  return q;
+}
+
+// logarithmic mean from the two values and log(aR) - log(aL)
+T8_DEV double ln_mean_dlog(double aL, double aR, double dlog) {
+  const double d = aR - aL, s = aR + aL;
+  const double f = d / s;
+  const double u = f * f;
+  const bool   small = u < 1.0e-4;
+  const double num = small ? s * 52.50 : d;
+  const double den = small ? (105.0 + u * (35.0 + u * (21.0 + u * 15.0))) : dlog;
+  return num / den;
+}
+// fp32: a difference of stored logs would cost accuracy near the branch switch; v_log_f32 is cheap.
+T8_DEV float ln_mean_dlog(float aL, float aR, float /*dlog*/) {
+  const float d = aR - aL, s = aR + aL;
+  const float f = d / s;
+  const float u = f * f;
+  const bool  small = u < 1.0e-4f;
+  const float num = small ? s * 52.50f : d;
+  const float den = small ? (105.0f + u * (35.0f + u * (21.0f + u * 15.0f))) : logf(aR / aL);
+  return num / den;
+}
+
+// KEPES flux through a face with unit normal n (basis n, t1, t2), scaled by `area`, in xyz.
+// mirror => the right state is the wall reflection of L (R is ignored).
+template <class T>
+T8_DEV void kepes_prim(const Prim<T>& L, const Prim<T>& R, bool mirror, const T n[3], const T t1[3], const T t2[3],
+                       T area, T g[5], T& speed) {
+  const T one = T(1), half = T(0.5), kappa = T(1.4);
+  const T km1 = kappa - one, skm1 = one / km1, ikappa = one / kappa;
+  const T uL = L.vx * n[0] + L.vy * n[1] + L.vz * n[2];
+  const T vL = L.vx * t1[0] + L.vy * t1[1] + L.vz * t1[2];
+  const T wL = L.vx * t2[0] + L.vy * t2[1] + L.vz * t2[2];
+  T       uR = R.vx * n[0] + R.vy * n[1] + R.vz * n[2];
+  T       vR = R.vx * t1[0] + R.vy * t1[1] + R.vz * t1[2];
+  T       wR = R.vx * t2[0] + R.vy * t2[1] + R.vz * t2[2];
+  if (mirror) {
+    uR = -uL;
+    vR = vL;
+    wR = wL;
+  }
+  const T qL = half * (uL * uL + vL * vL + wL * wL);
+  const T qR = half * (uR * uR + vR * vR + wR * wR);
+
+  const T rho  = ln_mean_dlog(L.rho, R.rho, R.lrho - L.lrho);
+  const T bhat = ln_mean_dlog(L.beta, R.beta, R.lbeta - L.lbeta);
+  const T ib   = one / bhat;
+  const T rho_mean = half * (L.rho + R.rho);
+  const T u = half * (uL + uR), v = half * (vL + vR), w = half * (wL + wR);
+  const T a  = t8_sqrt(kappa * half * (L.p + R.p) / rho);
+  const T h  = (kappa / (T(2) * km1)) * ib + half * (uL * uR + vL * vR + wL * wR);
+  const T p1 = rho_mean / (L.beta + R.beta);
+  const T q2 = qL + qR;
+
+  const T Fs0 = rho * u;
+  const T Fs1 = Fs0 * u + p1;
+  const T Fs2 = Fs0 * v;
+  const T Fs3 = Fs0 * w;
+  const T Fs4 = Fs0 * half * (skm1 * ib - q2) + u * Fs1 + v * Fs2 + w * Fs3;
+
+  speed = t8_abs(u) + a;
+
+  const T au = t8_abs(u);
+  const T D0 = half * t8_abs(u - a) * rho * ikappa;
+  const T D1 = au * (km1 * ikappa) * rho;
+  const T D2 = au * p1;
+  const T D4 = half * t8_abs(u + a) * rho * ikappa;
+
+  const T rpL = L.beta + L.beta, rpR = R.beta + R.beta;
+  const T J0 = R.v0 - L.v0;
+  const T J1 = rpR * uR - rpL * uL;
+  const T J2 = rpR * vR - rpL * vL;
+  const T J3 = rpR * wR - rpL * wL;
+  const T J4 = rpL - rpR;
+
+  const T ua = u * a;
+  const T hm = h - ua, hp = h + ua, k2 = half * (u * u + v * v + w * w);
+  const T c  = J0 + v * J2 + w * J3;  // common part of the three acoustic/entropy columns
+  const T d0 = D0 * (c + (u - a) * J1 + hm * J4);
+  const T d1 = D1 * (c + u * J1 + k2 * J4);
+  const T d2 = D2 * (J2 + v * J4);
+  const T d3 = D2 * (J3 + w * J4);
+  const T d4 = D4 * (c + (u + a) * J1 + hp * J4);
+  const T s014 = d0 + d1 + d4;
+  const T f0 = area * (Fs0 - half * s014);
+  const T f1 = area * (Fs1 - half * ((u - a) * d0 + u * d1 + (u + a) * d4));
+  const T f2 = area * (Fs2 - half * (v * s014 + d2));
+  const T f3 = area * (Fs3 - half * (w * s014 + d3));
+  const T f4 = area * (Fs4 - half * (hm * d0 + k2 * d1 + v * d2 + w * d3 + hp * d4));
+  g[0] = f0;
+  g[1] = f1 * n[0] + f2 * t1[0] + f3 * t2[0];
+  g[2] = f1 * n[1] + f2 * t1[1] + f3 * t2[1];
+  g[3] = f1 * n[2] + f2 * t1[2] + f3 * t2[2];
+  g[4] = f4;
 }
 
 }  // namespace t8gpu_hip

@@ -1,0 +1,209 @@
+// kernels_fused.hip -- fused tile kernels for plain elements (flux + RK stage in one launch).
+//
+// Workgroup = 256 lanes = one tile of the plan (tile_plan.cpp). Three phases, two barriers:
+//   1. lanes = tile elements + halo: gather the 5 conserved values (own range coalesced, halo through
+//      the sorted id list), turn them into per-element primitives, keep them in LDS;
+//   2. lanes = tile faces: packed (l, r), {n, area} streamed from the tile-ordered arrays (coalesced),
+//      primitives of both sides from LDS, one KEPES/HLL evaluation, area-scaled xyz flux to LDS;
+//   3. lanes = owned elements: sum the element's faces from LDS in CSR order (deterministic, no
+//      atomics), apply the SSP-RK3 stage, store the new state coalesced.
+// HBM sees: state in, state out, previous-step state, volume and the plan arrays -- the flux planes
+// never leave the chip. blockIdx -> tile is XCD-aware: blocks b, b+8, ... share an XCD (and its L2),
+// so each XCD gets one contiguous run of tiles and neighbouring tiles' halos hit the same L2.
+#include <hip/hip_runtime.h>
+
+#include "flux_math.hpp"
+#include "t8gpu_hip.h"
+
+namespace t8gpu_hip {
+
+template <class T>
+struct FVars {
+  T* p[5];
+};
+
+template <class T>
+struct vec4;
+template <>
+struct vec4<float> {
+  using type = float4;
+};
+template <>
+struct vec4<double> {
+  using type = double4;
+};
+
+// XCD-aware bijection block -> position in [0, nb): XCD x (= b % 8) owns a contiguous run.
+T8_DEV int xcd_position(int b, int nb) {
+  const int q = nb >> 3, rem = nb & 7, x = b & 7, k = b >> 3;
+  return x * q + (x < rem ? x : rem) + k;
+}
+
+template <class T, int KIND, int STAGE>
+__global__ __launch_bounds__(256) void k_plain_fused(T8gpuPlainPlan P, int tile_begin, FVars<T> prev, FVars<T> src,
+                                                     FVars<T> out, const T* __restrict__ vol, T dt,
+                                                     T* __restrict__ speed) {
+  extern __shared__ double lds_raw[];
+  T* const      lds = reinterpret_cast<T*>(lds_raw);
+  constexpr int NW  = KIND == 0 ? kPrimWords : 5;  // words per element kept in LDS
+  const int     LE  = P.max_elems + P.max_halo;    // element slots per LDS plane
+  const int     LF  = P.max_faces;
+  T* const      pe  = lds;                         // [NW][LE]
+  T* const      ff  = lds + (size_t)NW * LE;       // [5][LF]
+
+  const int tile = P.tile_order[tile_begin + xcd_position(blockIdx.x, gridDim.x)];
+  const int e0 = P.elem_off[tile], ne = P.elem_off[tile + 1] - e0;
+  const int h0 = P.halo_off[tile], nh = P.halo_off[tile + 1] - h0;
+  const int f0 = P.face_off[tile], nf = P.face_off[tile + 1] - f0;
+  const int tid = threadIdx.x;
+
+  // ---- phase 1: elements -> LDS --------------------------------------------------------------
+  for (int i = tid; i < ne + nh; i += 256) {
+    const int slot = i < ne ? e0 + i : P.halo_ids[h0 + (i - ne)];
+    T         s[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) s[k] = src.p[k][slot];
+    if (KIND == 0) {
+      const Prim<T> q = prim_from_state<T>(s);
+      pe[0 * LE + i]  = q.rho;
+      pe[1 * LE + i]  = q.vx;
+      pe[2 * LE + i]  = q.vy;
+      pe[3 * LE + i]  = q.vz;
+      pe[4 * LE + i]  = q.p;
+      pe[5 * LE + i]  = q.beta;
+      pe[6 * LE + i]  = q.lrho;
+      pe[7 * LE + i]  = q.lbeta;
+      pe[8 * LE + i]  = q.v0;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 5; k++) pe[k * LE + i] = s[k];
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: faces -----------------------------------------------------------------------
+  using V4 = typename vec4<T>::type;
+  const V4* __restrict__ geo = reinterpret_cast<const V4*>(P.face_geo) + f0;
+  for (int f = tid; f < nf; f += 256) {
+    const uint32_t lr = P.face_lr[f0 + f];
+    const V4       gm = geo[f];
+    const int      l = lr & 0xFFFFu, r16 = lr >> 16;
+    const bool     wall = r16 == 0xFFFFu;
+    const int      r = wall ? l : r16;
+    const T        n[3] = {gm.x, gm.y, gm.z};
+    T              t1[3], t2[3], g[5], spd = T(0);
+    face_basis<T>(n, t1, t2);
+    if (KIND == 0) {
+      Prim<T> L, R;
+      L.rho = pe[0 * LE + l]; L.vx = pe[1 * LE + l]; L.vy = pe[2 * LE + l]; L.vz = pe[3 * LE + l]; L.p = pe[4 * LE + l];
+      L.beta = pe[5 * LE + l]; L.lrho = pe[6 * LE + l]; L.lbeta = pe[7 * LE + l]; L.v0 = pe[8 * LE + l];
+      R.rho = pe[0 * LE + r]; R.vx = pe[1 * LE + r]; R.vy = pe[2 * LE + r]; R.vz = pe[3 * LE + r]; R.p = pe[4 * LE + r];
+      R.beta = pe[5 * LE + r]; R.lrho = pe[6 * LE + r]; R.lbeta = pe[7 * LE + r]; R.v0 = pe[8 * LE + r];
+      kepes_prim<T>(L, R, wall, n, t1, t2, gm.w, g, spd);
+      if (speed) {
+        const int orig = P.face_orig[f0 + f];
+        if (orig >= 0) speed[orig] = spd;
+      }
+    } else {
+      T sl[5], sr[5], Ff[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        sl[k] = pe[k * LE + l];
+        sr[k] = pe[k * LE + r];
+      }
+      face_frame_flux_ref<T, 1>(n, t1, t2, sl, sr, wall, Ff, spd);
+#pragma unroll
+      for (int k = 0; k < 5; k++) Ff[k] = gm.w * Ff[k];
+      from_face_frame<T>(n, t1, t2, Ff, g);
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) ff[k * LF + f] = g[k];
+  }
+  __syncthreads();
+
+  // ---- phase 3: per-element sum + RK stage (ssp_runge_kutta.inl:30-99) ---------------------------
+  for (int i = tid; i < ne; i += 256) {
+    const int e  = e0 + i;
+    const int c0 = P.csr_off[e], c1 = P.csr_off[e + 1];
+    T         acc[5] = {T(0), T(0), T(0), T(0), T(0)};
+    for (int c = c0; c < c1; c++) {
+      const unsigned ent = P.csr_ent[c];
+      const int      f   = ent & 0x7FFFu;
+      if (ent & 0x8000u) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) acc[k] += ff[k * LF + f];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 5; k++) acc[k] -= ff[k * LF + f];
+      }
+    }
+    const T scale = dt / vol[e];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      T o;
+      if (STAGE == 1) {
+        o = prev.p[k][e] + scale * acc[k];
+      } else if (STAGE == 2) {
+        o = rk3c<T>::c21 * prev.p[k][e] + rk3c<T>::c22 * src.p[k][e] + rk3c<T>::c23 * scale * acc[k];
+      } else {
+        o = rk3c<T>::c31 * prev.p[k][e] + rk3c<T>::c32 * src.p[k][e] + rk3c<T>::c33 * scale * acc[k];
+      }
+      out.p[k][e] = o;
+    }
+  }
+}
+
+template <class T, class V>
+FVars<T> fmk(const V& v) {
+  FVars<T> o;
+  for (int k = 0; k < 5; k++) o.p[k] = v.p[k];
+  return o;
+}
+
+template <class T, class V>
+int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count, V prev, V mid,
+                      V out, const T* volume, T dt, T* speed, void* stream) {
+  if (!plan || (kind != 0 && kind != 1) || stage < 1 || stage > 3) return static_cast<int>(hipErrorInvalidValue);
+  if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > plan->ntiles) return static_cast<int>(hipErrorInvalidValue);
+  if (plan->max_elems > 256 * 4) return static_cast<int>(hipErrorInvalidValue);
+  if (tile_count == 0) return 0;
+  const int    nw  = kind == 0 ? kPrimWords : 5;
+  const size_t lds = sizeof(T) * ((size_t)nw * (plan->max_elems + plan->max_halo) + (size_t)5 * plan->max_faces);
+  if (lds > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3  grid(tile_count), block(256);
+#define T8_FUSED(K, S)                                                                                       \
+  do {                                                                                                       \
+    if (lds > 64 * 1024) {                                                                                   \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_plain_fused<T, K, S>),             \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
+      if (e != hipSuccess) return static_cast<int>(e);                                                       \
+    }                                                                                                        \
+    hipLaunchKernelGGL((k_plain_fused<T, K, S>), grid, block, lds, s, *plan, tile_begin, fmk<T>(prev),       \
+                       fmk<T>(mid), fmk<T>(out), volume, dt, speed);                                         \
+  } while (0)
+  if (kind == 0) {
+    if (stage == 1) T8_FUSED(0, 1); else if (stage == 2) T8_FUSED(0, 2); else T8_FUSED(0, 3);
+  } else {
+    if (stage == 1) T8_FUSED(1, 1); else if (stage == 2) T8_FUSED(1, 2); else T8_FUSED(1, 3);
+  }
+#undef T8_FUSED
+  return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace t8gpu_hip
+
+extern "C" {
+int t8gpu_hip_plain_fused_stage_f32(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count,
+                                    T8gpuVars_f32 prev, T8gpuVars_f32 mid, T8gpuVars_f32 out, const float* volume,
+                                    float dt, float* speed, void* stream) {
+  return t8gpu_hip::plain_fused_stage<float>(kind, stage, plan, tile_begin, tile_count, prev, mid, out, volume, dt,
+                                             speed, stream);
+}
+int t8gpu_hip_plain_fused_stage_f64(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count,
+                                    T8gpuVars_f64 prev, T8gpuVars_f64 mid, T8gpuVars_f64 out, const double* volume,
+                                    double dt, double* speed, void* stream) {
+  return t8gpu_hip::plain_fused_stage<double>(kind, stage, plan, tile_begin, tile_count, prev, mid, out, volume, dt,
+                                              speed, stream);
+}
+}

@@ -1,0 +1,202 @@
+// tile_plan.cpp -- the face sort / permute + element-window tiling pre-pass of the fused kernels.
+//
+// Runs once per connectivity rebuild (where the reference runs compute_connectivity_information,
+// t8gpu/mesh/mesh_manager.inl:333-481), on the host, from the reference-format arrays
+// (face_neighbors, face_normals, face_surfaces). Output: for every tile (a contiguous SFC range of
+// owned elements, i.e. a compact window in space)
+//   * halo ids    : slots of the outside elements (other tiles' or ghost mirrors) its faces touch,
+//   * tile faces  : every face with a side in the tile, re-laid out contiguously (coalesced loads):
+//                   packed tile-local (l, r) indices, {nx, ny, nz, area}, original face id,
+//   * element CSR : per owned element the tile-local faces it sums, with the sign of its side.
+// A face cut by a tile boundary is listed in both tiles (flux evaluated twice, applied to the own
+// side only): no atomics, no flux planes in HBM, bitwise-reproducible sums (CSR order = face order).
+//
+// Host-only: covered by the CPU test-suite through a numpy interpreter of the plan.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct TilePlan {
+  int32_t N = 0, G = 0, F = 0, B = 0, ndim = 3, tmax = 256, fcap = 512;
+  int32_t max_halo = 0, max_faces = 0, max_elems = 0, n_interior = 0;
+  std::vector<int32_t>  elem_off, halo_off, face_off;  // [ntiles + 1]
+  std::vector<int32_t>  halo_ids;                      // slots
+  std::vector<uint32_t> face_lr;                       // l | r << 16 (tile-local; r = 0xFFFF: wall mirror)
+  std::vector<double>   face_geo;                      // [nfaces][4] = nx, ny, nz, area
+  std::vector<int32_t>  face_orig;                     // original face id if this tile reports its speed, else -1
+  std::vector<int32_t>  csr_off;                       // [N + 1]
+  std::vector<uint16_t> csr_ent;                       // tile-local face | 0x8000 if the element is the RIGHT side
+  std::vector<int32_t>  tile_order;                    // interior tiles first, then tiles that read ghost slots
+};
+
+void build(TilePlan& P, const int32_t* fn, const double* normals, const double* areas) {
+  const int32_t N = P.N, F = P.F, B = P.B;
+  // faces of each owned element, in original face order (interior faces first, then walls)
+  std::vector<int32_t> deg(static_cast<size_t>(N) + 1, 0);
+  for (int32_t f = 0; f < F; f++) {
+    const int32_t l = fn[2 * static_cast<size_t>(f)], r = fn[2 * static_cast<size_t>(f) + 1];
+    if (l < N) deg[l + 1]++;
+    if (r < N && r != l) deg[r + 1]++;
+  }
+  for (int32_t b = 0; b < B; b++) deg[fn[2 * static_cast<size_t>(F) + b] + 1]++;
+  for (int32_t e = 0; e < N; e++) deg[e + 1] += deg[e];
+  std::vector<int32_t> ef(deg[N]);
+  {
+    std::vector<int32_t> cur(deg.begin(), deg.end() - 1);
+    for (int32_t f = 0; f < F; f++) {
+      const int32_t l = fn[2 * static_cast<size_t>(f)], r = fn[2 * static_cast<size_t>(f) + 1];
+      if (l < N) ef[cur[l]++] = f;
+      if (r < N && r != l) ef[cur[r]++] = f;
+    }
+    for (int32_t b = 0; b < B; b++) ef[cur[fn[2 * static_cast<size_t>(F) + b]]++] = F + b;
+  }
+  auto side = [&](int32_t f, int which) -> int32_t {
+    if (f >= F) return which == 0 ? fn[2 * static_cast<size_t>(F) + (f - F)] : -1;
+    return fn[2 * static_cast<size_t>(f) + which];
+  };
+
+  // greedy tiling: grow the element range while elements <= tmax and distinct faces <= fcap
+  P.elem_off.assign(1, 0);
+  std::vector<int32_t> seen(static_cast<size_t>(F) + B, -1);
+  {
+    int32_t e = 0, tile = 0;
+    while (e < N) {
+      int32_t nf = 0, start = e;
+      while (e < N && e - start < P.tmax) {
+        int32_t add = 0;
+        for (int32_t j = deg[e]; j < deg[e + 1]; j++)
+          if (seen[ef[j]] != tile) add++;
+        if (e > start && nf + add > P.fcap) break;
+        for (int32_t j = deg[e]; j < deg[e + 1]; j++) seen[ef[j]] = tile;
+        nf += add;
+        e++;
+      }
+      P.elem_off.push_back(e);
+      tile++;
+    }
+  }
+  const int32_t ntiles = static_cast<int32_t>(P.elem_off.size()) - 1;
+  P.halo_off.assign(1, 0);
+  P.face_off.assign(1, 0);
+  P.csr_off.assign(static_cast<size_t>(N) + 1, 0);
+  std::fill(seen.begin(), seen.end(), -1);
+  std::vector<int32_t> tf, halo;
+  std::vector<uint8_t> reads_ghost(ntiles, 0);
+  for (int32_t t = 0; t < ntiles; t++) {
+    const int32_t e0 = P.elem_off[t], e1 = P.elem_off[t + 1], ne = e1 - e0;
+    tf.clear();
+    halo.clear();
+    for (int32_t e = e0; e < e1; e++)
+      for (int32_t j = deg[e]; j < deg[e + 1]; j++)
+        if (seen[ef[j]] != t) {
+          seen[ef[j]] = t;
+          tf.push_back(ef[j]);
+        }
+    std::sort(tf.begin(), tf.end());
+    for (int32_t f : tf)
+      for (int w = 0; w < 2; w++) {
+        const int32_t s = side(f, w);
+        if (s >= 0 && (s < e0 || s >= e1)) halo.push_back(s);
+      }
+    std::sort(halo.begin(), halo.end());
+    halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
+    if (!halo.empty() && halo.back() >= N) reads_ghost[t] = 1;
+    auto loc = [&](int32_t s) -> uint32_t {
+      if (s >= e0 && s < e1) return static_cast<uint32_t>(s - e0);
+      return static_cast<uint32_t>(ne + (std::lower_bound(halo.begin(), halo.end(), s) - halo.begin()));
+    };
+    const size_t fbase = P.face_lr.size();
+    for (int32_t f : tf) {
+      const int32_t l = side(f, 0), r = side(f, 1);
+      const uint32_t ll = loc(l), rr = r < 0 ? 0xFFFFu : loc(r);
+      P.face_lr.push_back(ll | (rr << 16));
+      for (int k = 0; k < 3; k++) P.face_geo.push_back(k < P.ndim ? normals[static_cast<size_t>(P.ndim) * f + k] : 0.0);
+      P.face_geo.push_back(areas[f]);
+      // the tile owning the left element reports the speed estimate (left is always owned or, for a
+      // face whose left side is a ghost, the tile of the right element does)
+      const int32_t reporter = (l < N) ? l : r;
+      P.face_orig.push_back((reporter >= e0 && reporter < e1) ? f : -1);
+    }
+    for (int32_t e = e0; e < e1; e++) {
+      for (int32_t j = deg[e]; j < deg[e + 1]; j++) {
+        const int32_t  f   = ef[j];
+        const uint16_t idx = static_cast<uint16_t>(std::lower_bound(tf.begin(), tf.end(), f) - tf.begin());
+        const bool     right = side(f, 0) != e;
+        P.csr_ent.push_back(static_cast<uint16_t>(idx | (right ? 0x8000u : 0u)));
+      }
+      P.csr_off[e + 1] = static_cast<int32_t>(P.csr_ent.size());
+    }
+    (void)fbase;
+    P.halo_ids.insert(P.halo_ids.end(), halo.begin(), halo.end());
+    P.halo_off.push_back(static_cast<int32_t>(P.halo_ids.size()));
+    P.face_off.push_back(static_cast<int32_t>(P.face_lr.size()));
+    P.max_halo  = std::max<int32_t>(P.max_halo, static_cast<int32_t>(halo.size()));
+    P.max_faces = std::max<int32_t>(P.max_faces, static_cast<int32_t>(tf.size()));
+    P.max_elems = std::max<int32_t>(P.max_elems, ne);
+  }
+  P.tile_order.clear();
+  for (int32_t t = 0; t < ntiles; t++)
+    if (!reads_ghost[t]) P.tile_order.push_back(t);
+  P.n_interior = static_cast<int32_t>(P.tile_order.size());
+  for (int32_t t = 0; t < ntiles; t++)
+    if (reads_ghost[t]) P.tile_order.push_back(t);
+}
+
+}  // namespace
+
+extern "C" {
+
+// fn = [2F + B] reference face_neighbors (local slots), normals = [ndim * (F + B)], areas = [F + B].
+// Returns null if a limit of the packed format is exceeded (tile-local index >= 0xFFFF, > 32767 faces).
+void* t8gpu_plan_plain_create(int32_t N, int32_t G, int32_t F, int32_t B, int32_t ndim, const int32_t* fn,
+                              const double* normals, const double* areas, int32_t tmax, int32_t fcap) {
+  if (N < 0 || F < 0 || B < 0 || ndim < 2 || ndim > 3 || tmax < 1 || tmax > 1024 || fcap < 1) return nullptr;
+  TilePlan* P = new TilePlan;
+  P->N = N; P->G = G; P->F = F; P->B = B; P->ndim = ndim; P->tmax = tmax; P->fcap = fcap;
+  build(*P, fn, normals, areas);
+  if (P->max_elems + P->max_halo >= 0xFFFF || P->max_faces > 0x7FFF) {
+    delete P;
+    return nullptr;
+  }
+  return P;
+}
+void t8gpu_plan_plain_destroy(void* h) { delete static_cast<TilePlan*>(h); }
+
+// sizes[10] = {ntiles, n_halo, n_faces, n_csr, max_elems, max_halo, max_faces, n_interior_tiles, N, F}
+void t8gpu_plan_plain_sizes(const void* h, int64_t* sizes) {
+  const TilePlan* P = static_cast<const TilePlan*>(h);
+  sizes[0] = static_cast<int64_t>(P->elem_off.size()) - 1;
+  sizes[1] = static_cast<int64_t>(P->halo_ids.size());
+  sizes[2] = static_cast<int64_t>(P->face_lr.size());
+  sizes[3] = static_cast<int64_t>(P->csr_ent.size());
+  sizes[4] = P->max_elems;
+  sizes[5] = P->max_halo;
+  sizes[6] = P->max_faces;
+  sizes[7] = P->n_interior;
+  sizes[8] = P->N;
+  sizes[9] = P->F;
+}
+
+void t8gpu_plan_plain_arrays(const void* h, int32_t* elem_off, int32_t* halo_off, int32_t* face_off,
+                             int32_t* halo_ids, uint32_t* face_lr, double* face_geo, int32_t* face_orig,
+                             int32_t* csr_off, uint16_t* csr_ent, int32_t* tile_order) {
+  const TilePlan* P = static_cast<const TilePlan*>(h);
+  auto cp = [](auto* dst, const auto& v) {
+    if (dst && !v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(v[0]));
+  };
+  cp(elem_off, P->elem_off);
+  cp(halo_off, P->halo_off);
+  cp(face_off, P->face_off);
+  cp(halo_ids, P->halo_ids);
+  cp(face_lr, P->face_lr);
+  cp(face_geo, P->face_geo);
+  cp(face_orig, P->face_orig);
+  cp(csr_off, P->csr_off);
+  cp(csr_ent, P->csr_ent);
+  cp(tile_order, P->tile_order);
+}
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+"""Device-side plan objects of the fused tile kernels (uploads the host plan, fills the C struct)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import hip
+from .plan import HostPlainPlan
+
+
+class T8gpuPlainPlan(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in HostPlainPlan.FIELDS] + [
+        ("ntiles", C.c_int32), ("n_interior_tiles", C.c_int32), ("max_elems", C.c_int32), ("max_halo", C.c_int32),
+        ("max_faces", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PlainPlan:
+    def __init__(self, part, dtype, tmax=256, fcap=512):
+        self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap)
+        self.dtype = dtype
+        self._keep = {}
+        c = T8gpuPlainPlan()
+        for name in HostPlainPlan.FIELDS:
+            a = getattr(self.host, name)
+            if name == "face_geo":
+                a = a.astype(np.float32 if dtype == torch.float32 else np.float64)
+            if a.dtype == np.uint32:
+                a = a.view(np.int32)
+            if a.dtype == np.uint16:
+                a = a.view(np.int16)
+            t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            self._keep[name] = t
+            setattr(c, name, t.data_ptr())
+        c.ntiles, c.n_interior_tiles = self.host.ntiles, self.host.n_interior
+        c.max_elems, c.max_halo, c.max_faces = self.host.max_elems, self.host.max_halo, self.host.max_faces
+        self.c = c
+
+    def stage(self, solver, stage, src, dst, dt, stream, tile_begin=0, tile_count=None):
+        from .solver import _timer_begin, _timer_end
+        n = self.host.ntiles - tile_begin if tile_count is None else tile_count
+        ev = _timer_begin(solver)
+        hip.call("t8gpu_hip_plain_fused_stage", self.dtype, solver.kind, stage, C.byref(self.c), tile_begin, n,
+                 solver.get_own_variables(solver.prev), solver.get_own_variables(src), solver.get_own_variables(dst),
+                 hip.ptr(solver.planes[25]), hip.fscalar(self.dtype, dt), hip.ptr(solver.speed), stream)
+        _timer_end(solver, ev)

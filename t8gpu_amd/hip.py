@@ -27,6 +27,9 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64 / librccl (same SONAMEs as /opt/rocm): load torch FIRST so that
+        # this library binds to the runtime that owns torch's streams and allocations.
+        import torch  # noqa: F401
         path = _build.HIP_LIB
         if not os.path.exists(path):
             raise T8gpuHipError(f"{path} is missing: run `python -m t8gpu_amd.build` (hipcc --offload-arch=gfx950). "

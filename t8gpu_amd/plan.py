@@ -1,0 +1,62 @@
+"""ctypes mirror of csrc/host/tile_plan.cpp: the host-side tiling pre-pass of the fused kernels."""
+import ctypes as C
+
+import numpy as np
+
+from . import synth as _synth
+
+_ready = False
+
+
+def _lib():
+    global _ready
+    lib = _synth.lib()
+    if not _ready:
+        lib.t8gpu_plan_plain_create.restype = C.c_void_p
+        lib.t8gpu_plan_plain_create.argtypes = [C.c_int32] * 5 + [C.c_void_p] * 3 + [C.c_int32] * 2
+        lib.t8gpu_plan_plain_destroy.argtypes = [C.c_void_p]
+        lib.t8gpu_plan_plain_sizes.argtypes = [C.c_void_p, C.c_void_p]
+        lib.t8gpu_plan_plain_arrays.argtypes = [C.c_void_p] * 11
+        _ready = True
+    return lib
+
+
+class HostPlainPlan:
+    """Host arrays of the plain-element tile plan (see include/t8gpu_hip.h, T8gpuPlainPlan)."""
+
+    FIELDS = ("elem_off", "halo_off", "face_off", "halo_ids", "face_lr", "face_geo", "face_orig", "csr_off",
+              "csr_ent", "tile_order")
+
+    def __init__(self, N, G, F, B, ndim, face_neighbors, normals, areas, tmax=256, fcap=512):
+        lib = _lib()
+        fn = np.ascontiguousarray(face_neighbors, np.int32)
+        nr = np.ascontiguousarray(normals, np.float64)
+        ar = np.ascontiguousarray(areas, np.float64)
+        assert fn.size == 2 * F + B and nr.size == ndim * (F + B) and ar.size == F + B
+        p = _synth._p
+        h = lib.t8gpu_plan_plain_create(N, G, F, B, ndim, p(fn), p(nr), p(ar), tmax, fcap)
+        if not h:
+            raise ValueError("tile plan exceeds the packed index format (use smaller tmax / fcap)")
+        try:
+            sz = np.zeros(10, np.int64)
+            lib.t8gpu_plan_plain_sizes(h, p(sz))
+            (self.ntiles, n_halo, n_faces, n_csr, self.max_elems, self.max_halo, self.max_faces,
+             self.n_interior) = (int(x) for x in sz[:8])
+            self.N, self.F, self.B, self.tmax, self.fcap = N, F, B, tmax, fcap
+            self.elem_off = np.zeros(self.ntiles + 1, np.int32)
+            self.halo_off = np.zeros(self.ntiles + 1, np.int32)
+            self.face_off = np.zeros(self.ntiles + 1, np.int32)
+            self.halo_ids = np.zeros(n_halo, np.int32)
+            self.face_lr = np.zeros(n_faces, np.uint32)
+            self.face_geo = np.zeros((n_faces, 4), np.float64)
+            self.face_orig = np.zeros(n_faces, np.int32)
+            self.csr_off = np.zeros(N + 1, np.int32)
+            self.csr_ent = np.zeros(n_csr, np.uint16)
+            self.tile_order = np.zeros(self.ntiles, np.int32)
+            lib.t8gpu_plan_plain_arrays(h, *(p(getattr(self, f)) for f in self.FIELDS))
+        finally:
+            lib.t8gpu_plan_plain_destroy(h)
+
+    @classmethod
+    def from_partition(cls, part, **kw):
+        return cls(part.N, part.G, part.F, part.B, part.normal_dim, part.face_neighbors, part.normals, part.areas, **kw)

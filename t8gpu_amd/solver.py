@@ -1,0 +1,178 @@
+"""Host-side mirrors of the reference solvers' hot loop, driving the C-ABI of include/t8gpu_hip.h.
+
+PlainSolver   <-> t8gpu::CompressibleEulerSolver::iterate   (examples/compressible_euler/solver.cu:75-175)
+SubgridSolver <-> SubgridCompressibleEulerSolver::iterate   (examples/subgrid/solver.inl:152-266)
+
+Same member names and step bookkeeping (`next`/`prev` swap, Step0..Step3 + Fluxes planes,
+plane = step*5 + var, stride = capacity). torch is used for device memory and streams only; every
+flux / RK computation is a HIP kernel behind the C-ABI. There is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import hip
+
+STEP0, STEP1, STEP2, STEP3, FLUXES = range(5)
+
+
+def _timer_begin(solver):
+    """bench.py sets solver.kernel_timer to a list to get (start, end) HIP events around the
+    dominant kernel, recorded on the stream the kernel is launched on (torch's current stream)."""
+    if getattr(solver, "kernel_timer", None) is None:
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
+def _timer_end(solver, ev):
+    if ev is not None:
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        solver.kernel_timer.append((ev, end))
+
+
+def _dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+class PlainSolver:
+    """Plain elements. mode = "compat": reference data flow (face kernel + atomics, RK kernel);
+    mode = "fused": tile kernels (flux + RK in one pass, no flux planes in HBM)."""
+
+    def __init__(self, part, dtype=torch.float64, flux_kind=hip.KEPES, mode="compat", capacity=None, state=None,
+                 device=None):
+        if not torch.cuda.is_available():
+            raise hip.T8gpuHipError("PlainSolver needs a GPU: the hot path has no CPU implementation")
+        hip.lib()
+        self.part, self.dtype, self.kind, self.mode = part, dtype, flux_kind, mode
+        tot = part.N + part.G
+        self.N, self.G, self.F, self.B, self.ndim = part.N, part.G, part.F, part.B, part.normal_dim
+        self.stride = capacity or tot
+        self.planes = torch.zeros((26, self.stride), dtype=dtype, device="cuda")
+        ic = part.kh_initial_state() if state is None else state
+        self.planes[0:5, :tot] = _dev(ic, dtype)
+        self.planes[25, :tot] = _dev(part.volumes, dtype)
+        self.fn = _dev(part.face_neighbors)
+        self.indices = None  # ghosts already resolve to local slots
+        self.normals = _dev(part.normals, dtype)
+        self.areas = _dev(part.areas, dtype)
+        self.speed = torch.zeros(max(1, part.F + part.B), dtype=dtype, device="cuda")
+        self.next, self.prev = STEP0, STEP3  # solver.h:100-101
+        self.plan = None
+        if mode == "fused":
+            from . import fused
+            self.plan = fused.PlainPlan(part, dtype)
+        elif mode != "compat":
+            raise ValueError(mode)
+
+    # -- accessors named after the reference API ------------------------------------------------
+    def get_own_variables(self, step):
+        return hip.vars_of(self.planes, step)
+
+    def get_own_volume(self):
+        return self.planes[25]
+
+    def state(self, step=None):
+        s = self.next if step is None else step
+        return self.planes[5 * s:5 * s + 5, :self.N]
+
+    # -- one flux evaluation + RK stage in the reference's data flow -----------------------------
+    def _stage_compat(self, stage, src, dst, dt, stream):
+        st, fl = self.get_own_variables(src), self.get_own_variables(FLUXES)
+        ev = _timer_begin(self)
+        hip.call("t8gpu_hip_flux_faces", self.dtype, self.kind, self.F, self.ndim, hip.ptr(self.fn), None,
+                 hip.ptr(self.normals), hip.ptr(self.areas), st, fl, hip.ptr(self.speed), stream)
+        _timer_end(self, ev)
+        if self.B > 0:
+            hip.call("t8gpu_hip_flux_boundary", self.dtype, self.kind, self.F, self.B, self.ndim, hip.ptr(self.fn),
+                     hip.ptr(self.normals), hip.ptr(self.areas), st, fl, hip.ptr(self.speed), stream)
+        hip.call("t8gpu_hip_rk3_stage", self.dtype, stage, self.N, self.get_own_variables(self.prev), st,
+                 self.get_own_variables(dst), fl, hip.ptr(self.planes[25]), hip.fscalar(self.dtype, dt), stream)
+
+    def iterate(self, delta_t, stream=None, halo=None):
+        """One SSP-RK3 step. `halo(step, stage)` (optional) refreshes the ghost slots of `step`."""
+        self.next, self.prev = self.prev, self.next  # solver.cu:76
+        s = hip.stream_ptr(stream)
+        srcs = (self.prev, STEP1, STEP2)
+        dsts = (STEP1, STEP2, self.next)
+        for k in range(3):
+            if halo is not None:
+                halo(srcs[k], k)
+            if self.mode == "compat":
+                self._stage_compat(k + 1, srcs[k], dsts[k], delta_t, s)
+            else:
+                self.plan.stage(self, k + 1, srcs[k], dsts[k], delta_t, s)
+
+
+class SubgridSolver:
+    """Subgrid<4,4> / Subgrid<4,4,4>: planes[25, (N+G)*S] in subcells + per-block volumes."""
+
+    def __init__(self, part, dtype=torch.float32, flux_kind=hip.KEPES, mode="compat", state=None):
+        if not torch.cuda.is_available():
+            raise hip.T8gpuHipError("SubgridSolver needs a GPU: the hot path has no CPU implementation")
+        hip.lib()
+        assert part.subgrid
+        self.part, self.dtype, self.kind, self.mode = part, dtype, flux_kind, mode
+        self.rank = part.mesh.dim
+        self.S = 4 ** self.rank
+        tot = part.N + part.G
+        self.N, self.G, self.F, self.B = part.N, part.G, part.F, part.B
+        self.stride = tot * self.S
+        self.planes = torch.zeros((25, self.stride), dtype=dtype, device="cuda")
+        ic = part.kh_initial_state() if state is None else state
+        self.planes[0:5] = _dev(ic, dtype)
+        self.volumes = _dev(part.volumes, dtype)
+        self.fn = _dev(part.face_neighbors)
+        self.level_diff = _dev(part.level_diff)
+        self.nb_offset = _dev(part.nb_offset)
+        self.normals = _dev(part.normals, dtype)
+        self.areas = _dev(part.areas, dtype)
+        self.next, self.prev = STEP0, STEP3
+        self.plan = None
+        if mode == "fused":
+            from . import fused
+            self.plan = fused.SubgridPlan(part, dtype)
+        elif mode != "compat":
+            raise ValueError(mode)
+
+    def get_own_variables(self, step):
+        return hip.vars_of(self.planes, step)
+
+    def state(self, step=None):
+        s = self.next if step is None else step
+        return self.planes[5 * s:5 * s + 5, :self.N * self.S]
+
+    def _stage_compat(self, stage, src, dst, dt, stream):
+        st, fl = self.get_own_variables(src), self.get_own_variables(FLUXES)
+        ev = _timer_begin(self)
+        hip.call("t8gpu_hip_subgrid_inner", self.dtype, self.kind, self.rank, self.N, st, fl, hip.ptr(self.volumes),
+                 stream)
+        _timer_end(self, ev)
+        if self.B > 0:
+            hip.call("t8gpu_hip_subgrid_boundary", self.dtype, self.kind, self.rank, self.F, self.B,
+                     hip.ptr(self.fn), hip.ptr(self.normals), hip.ptr(self.areas), st, fl, stream)
+        hip.call("t8gpu_hip_subgrid_outer", self.dtype, self.kind, self.rank, self.F, hip.ptr(self.fn), None,
+                 hip.ptr(self.level_diff), hip.ptr(self.nb_offset), hip.ptr(self.normals), hip.ptr(self.areas),
+                 st, fl, stream)
+        hip.call("t8gpu_hip_subgrid_rk3_stage", self.dtype, stage, self.rank, self.N,
+                 self.get_own_variables(self.prev), st, self.get_own_variables(dst), fl, hip.ptr(self.volumes),
+                 hip.fscalar(self.dtype, dt), stream)
+
+    def iterate(self, delta_t, stream=None, halo=None):
+        self.prev, self.next = self.next, self.prev  # solver.inl:154
+        s = hip.stream_ptr(stream)
+        srcs = (self.prev, STEP1, STEP2)
+        dsts = (STEP1, STEP2, self.next)
+        for k in range(3):
+            if halo is not None:
+                halo(srcs[k], k)
+            if self.mode == "compat":
+                self._stage_compat(k + 1, srcs[k], dsts[k], delta_t, s)
+            else:
+                self.plan.stage(self, k + 1, srcs[k], dsts[k], delta_t, s)

@@ -1,0 +1,84 @@
+"""-m gpu: fused tile kernels (flux + RK in one launch) against the CPU oracle and the compat tier."""
+import numpy as np
+import pytest
+import torch
+
+import _oracle as O
+from _gpu import NP, TOL1, TOL10, perturbed_state, rel_err
+from t8gpu_amd import hip
+from t8gpu_amd.solver import PlainSolver
+from t8gpu_amd.synth import SynthMesh
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float64, torch.float32]
+MESHES = [dict(dim=2, base_level=5, max_level=5), dict(dim=2, base_level=3, max_level=7, band=0.06),
+          dict(dim=2, base_level=3, max_level=5, band=0.06, periodic=False), dict(dim=3, base_level=2, max_level=4, band=0.1)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kind", [hip.KEPES, hip.HLL])
+@pytest.mark.parametrize("mesh_args", MESHES)
+def test_fused_iterate_vs_oracle(dtype, kind, mesh_args):
+    mesh = SynthMesh(**mesh_args)
+    part = mesh.partition()
+    st = perturbed_state(part, 21)
+    g = PlainSolver(part, dtype, flux_kind=kind, mode="fused", state=st)
+    o = O.PlainCase(part, NP[dtype], state=st)
+    dt = 0.1 * 2.0 ** -mesh.finest_level
+    g.iterate(dt)
+    o.iterate(dt, kind=kind)
+    torch.cuda.synchronize()
+    assert rel_err(g.state().cpu().numpy(), o.current()[:, :part.N]) < TOL1[dtype]
+    if kind == hip.KEPES:                                        # speed estimates of the last stage, every face
+        assert rel_err(g.speed.cpu().numpy()[None, :part.F + part.B], o.speed[None]) < TOL1[dtype] * 10
+    assert (g.planes[20:25] == 0).all()                          # Fluxes planes stay zero, as after the reference's RK
+    for _ in range(9):
+        g.iterate(dt)
+        o.iterate(dt, kind=kind)
+    assert rel_err(g.state().cpu().numpy(), o.current()[:, :part.N]) < TOL10[dtype]
+
+
+@pytest.mark.parametrize("tmax,fcap", [(256, 512), (64, 100), (17, 40), (256, 10 ** 6)])
+def test_fused_is_independent_of_the_tiling(tmax, fcap):
+    from t8gpu_amd import fused
+    mesh = SynthMesh(2, 3, 6, band=0.06, periodic=False)
+    part = mesh.partition()
+    st = perturbed_state(part, 4)
+    ref = PlainSolver(part, torch.float64, mode="fused", state=st)
+    alt = PlainSolver(part, torch.float64, mode="fused", state=st)
+    alt.plan = fused.PlainPlan(part, torch.float64, tmax=tmax, fcap=fcap)
+    dt = 0.1 * 2.0 ** -6
+    for _ in range(3):
+        ref.iterate(dt)
+        alt.iterate(dt)
+    # per-element sums run in face order whatever the tiling: bitwise identical
+    assert torch.equal(ref.state(), alt.state())
+
+
+def test_fused_is_bitwise_reproducible_and_conservative_at_c2_size():
+    """BASELINE C2 (2D KH AMR, ~1.03 M elements, fp64): size-independent properties at full size."""
+    mesh = SynthMesh(2, 6, 11, band=0.0596)
+    part = mesh.partition()
+    a = PlainSolver(part, torch.float64, mode="fused")
+    b = PlainSolver(part, torch.float64, mode="fused")
+    c = PlainSolver(part, torch.float64, mode="compat")
+    dt = 0.1 * 2.0 ** -11
+    vol = torch.from_numpy(part.volumes).cuda()
+    m0 = (a.state() * vol).sum(1)
+    for _ in range(3):
+        a.iterate(dt)
+        b.iterate(dt)
+        c.iterate(dt)
+    assert torch.equal(a.state(), b.state())                                   # no atomics: run-to-run identical
+    m1 = (a.state() * vol).sum(1)
+    assert float((m1 - m0).abs().max()) < 1e-12 * float(m0.abs().max())         # conservation (periodic mesh)
+    assert rel_err(a.state().cpu().numpy(), c.state().cpu().numpy()) < 1e-12    # fused == reference dataflow
+
+
+def test_uniform_state_is_a_fixed_point_fused():
+    mesh = SynthMesh(2, 3, 6, band=0.06)
+    part = mesh.partition()
+    uniform = np.tile(np.array([[1.3], [0.2], [-0.4], [0.1], [3.0]]), (1, part.N))
+    f = PlainSolver(part, torch.float64, mode="fused", state=uniform)
+    f.iterate(1e-3)
+    assert rel_err(f.state().cpu().numpy(), uniform) < 1e-13
