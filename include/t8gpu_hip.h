@@ -143,6 +143,21 @@ int t8gpu_hip_plain_fused_stage_f64(int flux_kind, int stage, const T8gpuPlainPl
                                     int tile_count, T8gpuVars_f64 prev, T8gpuVars_f64 mid, T8gpuVars_f64 out,
                                     const double* volume, double delta_t, double* speed_estimates, void* stream);
 
+/* ---- ghost-layer exchange (device side) ----------------------------------------------------------
+ * Replaces the reference's cross-rank pointer sharing (cudaIpc*, t8gpu/memory/shared_device_vector.inl:
+ * 15-30,159-199) and remote atomics (kernels.cu:295-308): ghosts are mirror slots [N, N+G) of the same
+ * planes, refreshed once per RK stage by  pack -> RCCL send/recv per neighbour rank -> unpack.
+ * Wire format: 5 values per element, element-major (sendbuf[5*t + var]); each peer's elements are a
+ * contiguous run of send_idx / of the ghost slots, so one message per peer and direction. The
+ * transport (ncclSend/ncclRecv in one group, on the stream of these kernels) is issued by the host
+ * side (t8gpu_amd/halo.py through torch.distributed's RCCL communicator). */
+int t8gpu_hip_halo_pack_f32(int n_send, const int32_t* send_idx, T8gpuVars_f32 state, float* sendbuf, void* stream);
+int t8gpu_hip_halo_pack_f64(int n_send, const int32_t* send_idx, T8gpuVars_f64 state, double* sendbuf, void* stream);
+int t8gpu_hip_halo_unpack_f32(int num_ghosts, int first_ghost_slot, const float* recvbuf, T8gpuVars_f32 state,
+                              void* stream);
+int t8gpu_hip_halo_unpack_f64(int num_ghosts, int first_ghost_slot, const double* recvbuf, T8gpuVars_f64 state,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

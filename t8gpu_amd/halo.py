@@ -1,0 +1,97 @@
+"""Ghost-layer exchange: one rank per GPU, RCCL send/recv over xGMI (torch.distributed's communicator).
+
+Replaces the reference's single-GPU CUDA-IPC pointer sharing + `cudaDeviceSynchronize(); MPI_Barrier`
+pairs (examples/compressible_euler/solver.cu:98-99,111-112,130-131,143-144,162-163): per RK stage
+
+    comm stream :  wait(state ready) -> pack kernel -> grouped isend/irecv per neighbour -> unpack kernel
+    main stream :  interior tiles ............................ wait(ghosts) -> tiles that read ghost slots
+
+No host barrier inside the step. The halo plan (peers, send lists, ghost ranges) comes from the mesh
+provider (csrc/host/synth_mesh.cpp; with real t8code: the forest's ghost layer).
+
+On CUDA tensors the pack/unpack are the HIP kernels of the C-ABI; the torch-indexing fallback exists
+only so that the same exchange logic can be exercised by the world_size-2 gloo tests on CPU.
+"""
+import torch
+
+from . import hip
+
+
+class HaloExchange:
+    def __init__(self, part, dtype, dist, device="cuda", overlap=True):
+        self.part, self.dist, self.dtype = part, dist, dtype
+        self.N, self.G = part.N, part.G
+        self.rank = part.rank
+        self.peers = [int(p) for p in part.peers]
+        self.send_off = [int(x) for x in part.send_off]
+        self.recv_off = [int(x) for x in part.recv_off]
+        self.n_send = int(part.send_idx.size)
+        self.on_gpu = str(device).startswith("cuda")
+        self.send_idx = torch.from_numpy(part.send_idx.copy()).to(device)
+        self.send_idx64 = self.send_idx.long()
+        self.sendbuf = torch.zeros(max(1, 5 * self.n_send), dtype=dtype, device=device)
+        self.recvbuf = torch.zeros(max(1, 5 * self.G), dtype=dtype, device=device)
+        self.comm_stream = torch.cuda.Stream() if (self.on_gpu and overlap) else None
+        self.ev_state = torch.cuda.Event() if self.on_gpu else None
+        self.ev_ghost = torch.cuda.Event() if self.on_gpu else None
+        self._reqs = []
+        if self.on_gpu:
+            hip.lib()
+
+    # -- device-side gather / scatter ------------------------------------------------------------
+    def _pack(self, planes5):
+        if self.n_send == 0:
+            return
+        if self.on_gpu:
+            hip.call("t8gpu_hip_halo_pack", self.dtype, self.n_send, hip.ptr(self.send_idx), hip.vars_of(planes5),
+                     hip.ptr(self.sendbuf), hip.stream_ptr())
+        else:
+            self.sendbuf[:5 * self.n_send].view(self.n_send, 5).copy_(planes5[:, self.send_idx64].t())
+
+    def _unpack(self, planes5):
+        if self.G == 0:
+            return
+        if self.on_gpu:
+            hip.call("t8gpu_hip_halo_unpack", self.dtype, self.G, self.N, hip.ptr(self.recvbuf), hip.vars_of(planes5),
+                     hip.stream_ptr())
+        else:
+            planes5[:, self.N:self.N + self.G] = self.recvbuf[:5 * self.G].view(self.G, 5).t()
+
+    def _transport(self):
+        ops = []
+        for j, p in enumerate(self.peers):
+            r0, r1 = 5 * self.recv_off[j], 5 * self.recv_off[j + 1]
+            s0, s1 = 5 * self.send_off[j], 5 * self.send_off[j + 1]
+            if r1 > r0:
+                ops.append(self.dist.P2POp(self.dist.irecv, self.recvbuf[r0:r1], p))
+            if s1 > s0:
+                ops.append(self.dist.P2POp(self.dist.isend, self.sendbuf[s0:s1], p))
+        if ops:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()   # on CUDA: enqueues a stream wait, does not block the host
+
+    # -- one exchange, split so that compute can run between start() and finish() ----------------
+    def start(self, planes5):
+        """planes5: the [5, stride] view of the step whose ghost slots must be refreshed."""
+        if not self.peers:
+            return
+        if self.comm_stream is not None:
+            self.ev_state.record()                       # everything that produced planes5 is on the main stream
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(self.ev_state)
+                self._pack(planes5)
+                self._transport()
+                self._unpack(planes5)
+                self.ev_ghost.record()
+        else:
+            self._pack(planes5)
+            self._transport()
+            self._unpack(planes5)
+
+    def finish(self):
+        if self.peers and self.comm_stream is not None:
+            torch.cuda.current_stream().wait_event(self.ev_ghost)
+
+    def exchange(self, planes5):
+        self.start(planes5)
+        self.finish()

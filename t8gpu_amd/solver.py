@@ -95,19 +95,45 @@ class PlainSolver:
         hip.call("t8gpu_hip_rk3_stage", self.dtype, stage, self.N, self.get_own_variables(self.prev), st,
                  self.get_own_variables(dst), fl, hip.ptr(self.planes[25]), hip.fscalar(self.dtype, dt), stream)
 
-    def iterate(self, delta_t, stream=None, halo=None):
-        """One SSP-RK3 step. `halo(step, stage)` (optional) refreshes the ghost slots of `step`."""
+    def begin_step(self):
         self.next, self.prev = self.prev, self.next  # solver.cu:76
+
+    def stage_steps(self, k):
+        """(source step, destination step) of RK stage k = 0, 1, 2 (solver.cu:81-174)."""
+        return (self.prev, STEP1, STEP2)[k], (STEP1, STEP2, self.next)[k]
+
+    def step_planes(self, step):
+        return self.planes[5 * step:5 * step + 5]
+
+    def run_stage(self, k, delta_t, stream=None, halo=None, split=False):
+        """Flux evaluation on the stage's source state + RK update. With a halo exchange (or split=True)
+        the fused kernels run the interior tiles first and the ghost-reading tiles after finish()."""
         s = hip.stream_ptr(stream)
-        srcs = (self.prev, STEP1, STEP2)
-        dsts = (STEP1, STEP2, self.next)
-        for k in range(3):
+        src, dst = self.stage_steps(k)
+        if halo is not None:
+            halo.start(self.step_planes(src))
+        if self.mode == "compat":
             if halo is not None:
-                halo(srcs[k], k)
-            if self.mode == "compat":
-                self._stage_compat(k + 1, srcs[k], dsts[k], delta_t, s)
-            else:
-                self.plan.stage(self, k + 1, srcs[k], dsts[k], delta_t, s)
+                halo.finish()
+            self._stage_compat(k + 1, src, dst, delta_t, s)
+            return
+        ni, nt = self.plan.host.n_interior, self.plan.host.ntiles
+        if (halo is None and not split) or ni == nt or ni == 0:
+            if halo is not None:
+                halo.finish()
+            self.plan.stage(self, k + 1, src, dst, delta_t, s)
+        else:
+            self.plan.stage(self, k + 1, src, dst, delta_t, s, 0, ni)
+            if halo is not None:
+                halo.finish()
+            self.plan.stage(self, k + 1, src, dst, delta_t, s, ni, nt - ni)
+
+    def iterate(self, delta_t, stream=None, halo=None):
+        """One SSP-RK3 step (CompressibleEulerSolver::iterate). `halo` (a halo.HaloExchange) refreshes
+        the ghost slots of each stage's source state while the interior tiles are already running."""
+        self.begin_step()
+        for k in range(3):
+            self.run_stage(k, delta_t, stream, halo)
 
 
 class SubgridSolver:
@@ -171,7 +197,7 @@ class SubgridSolver:
         dsts = (STEP1, STEP2, self.next)
         for k in range(3):
             if halo is not None:
-                halo(srcs[k], k)
+                raise NotImplementedError("multi-rank Subgrid runs need block-sized halo messages (next round)")
             if self.mode == "compat":
                 self._stage_compat(k + 1, srcs[k], dsts[k], delta_t, s)
             else:
