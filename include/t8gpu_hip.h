@@ -130,7 +130,13 @@ typedef struct T8gpuPlainPlan {
   const int32_t*  csr_off;    /* [N+1] into csr_ent                                               */
   const uint16_t* csr_ent;    /* tile-local face | 0x8000 when the element is the face's right side */
   const int32_t*  tile_order; /* [ntiles] interior tiles first, then tiles reading ghost slots    */
-  int32_t ntiles, n_interior_tiles, max_elems, max_halo, max_faces, reserved;
+  int32_t ntiles, n_interior_tiles, max_elems, max_halo, max_faces, ell_width;
+  /* optional compressed forms (NULL = absent); with them and tiles of <= 256 elements, <= 512 own+halo
+   * elements and <= 512 faces the software-pipelined kernel variant is used */
+  const uint16_t* ell;        /* [N][ell_width] copy of the CSR lists, 0xFFFF-padded, 16-byte rows      */
+  const uint16_t* geo_idx;    /* per tile face: row of geo_table                                      */
+  const void*     geo_table;  /* float_type [n_geo][4]: the distinct {nx, ny, nz, area} tuples         */
+  int32_t n_geo, reserved;
 } T8gpuPlainPlan;
 
 /* tile_begin/tile_count select a range of tile_order (0, ntiles = everything; [0, n_interior) can run

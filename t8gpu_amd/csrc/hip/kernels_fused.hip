@@ -153,6 +153,186 @@ __global__ __launch_bounds__(256) void k_plain_fused(T8gpuPlainPlan P, int tile_
   }
 }
 
+// ---- software-pipelined variant --------------------------------------------------------------------
+// Same three phases, but EVERY global load of the tile is issued in the prologue, before the first
+// barrier: states of own + halo elements (2 per lane), the lane's two faces (packed indices, geometry
+// index, original id) and the lane's element row (previous state, volume, first 8 face-list entries).
+// The generic kernel above exposes three dependent memory latencies per tile (one per phase); here
+// they overlap, and the own state stays in registers for the RK stage. Needs tiles of <= 256 elements,
+// <= 512 own+halo elements and <= 512 faces (tile_plan.cpp guarantees it with the default caps).
+template <class T>
+T8_DEV void ell_accumulate(uint4 w, const T* __restrict__ ff, int LF, T acc[5], bool& done) {
+  const unsigned ent[8] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    if (ent[j] == 0xFFFFu) done = true;
+    if (!done) {
+      const int f   = ent[j] & 0x7FFFu;
+      const T   sgn = (ent[j] & 0x8000u) ? T(1) : T(-1);
+#pragma unroll
+      for (int k = 0; k < 5; k++) acc[k] += sgn * ff[k * LF + f];
+    }
+  }
+}
+
+template <class T>
+T8_DEV void store_prim(T* pe, int LE, int i, const T s[5]) {
+  const Prim<T> q = prim_from_state<T>(s);
+  pe[0 * LE + i] = q.rho;
+  pe[1 * LE + i] = q.vx;
+  pe[2 * LE + i] = q.vy;
+  pe[3 * LE + i] = q.vz;
+  pe[4 * LE + i] = q.p;
+  pe[5 * LE + i] = q.beta;
+  pe[6 * LE + i] = q.lrho;
+  pe[7 * LE + i] = q.lbeta;
+  pe[8 * LE + i] = q.v0;
+}
+
+template <class T>
+T8_DEV void load_prim(const T* pe, int LE, int i, Prim<T>& q) {
+  q.rho = pe[0 * LE + i]; q.vx = pe[1 * LE + i]; q.vy = pe[2 * LE + i]; q.vz = pe[3 * LE + i]; q.p = pe[4 * LE + i];
+  q.beta = pe[5 * LE + i]; q.lrho = pe[6 * LE + i]; q.lbeta = pe[7 * LE + i]; q.v0 = pe[8 * LE + i];
+}
+
+template <class T, int KIND, int STAGE, bool DICT>
+__global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int tile_begin, FVars<T> prev, FVars<T> src,
+                                                       FVars<T> out, const T* __restrict__ vol, T dt,
+                                                       T* __restrict__ speed) {
+  extern __shared__ double lds_raw[];
+  using V4 = typename vec4<T>::type;
+  T* const      lds = reinterpret_cast<T*>(lds_raw);
+  constexpr int NW  = KIND == 0 ? kPrimWords : 5;
+  const int     LE  = P.max_elems + P.max_halo;
+  const int     LF  = P.max_faces;
+  T* const      pe  = lds;
+  T* const      ff  = lds + (size_t)NW * LE;
+
+  const int tile = P.tile_order[tile_begin + xcd_position(blockIdx.x, gridDim.x)];
+  const int e0 = P.elem_off[tile], ne = P.elem_off[tile + 1] - e0;
+  const int h0 = P.halo_off[tile], nh = P.halo_off[tile + 1] - h0;
+  const int f0 = P.face_off[tile], nf = P.face_off[tile + 1] - f0;
+  const int tid = threadIdx.x;
+
+  // ---- prologue: all global loads of the tile ----------------------------------------------------
+  const int  i1 = tid + 256;
+  const bool own = tid < ne, a0 = tid < ne + nh, a1 = i1 < ne + nh;
+  const int  slot0 = own ? e0 + tid : (a0 ? P.halo_ids[h0 + (tid - ne)] : e0);
+  const int  slot1 = a1 ? P.halo_ids[h0 + (i1 - ne)] : e0;
+  T          s0[5], s1[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) s0[k] = src.p[k][slot0];
+#pragma unroll
+  for (int k = 0; k < 5; k++) s1[k] = src.p[k][slot1];
+  const int      fb = tid + 256;
+  const bool     va = tid < nf, vb = fb < nf;
+  const uint32_t lra = P.face_lr[f0 + (va ? tid : 0)];
+  const uint32_t lrb = P.face_lr[f0 + (vb ? fb : 0)];
+  V4             gma, gmb;
+  if (DICT) {
+    const V4* __restrict__ tab = reinterpret_cast<const V4*>(P.geo_table);
+    gma = tab[P.geo_idx[f0 + (va ? tid : 0)]];
+    gmb = tab[P.geo_idx[f0 + (vb ? fb : 0)]];
+  } else {
+    const V4* __restrict__ geo = reinterpret_cast<const V4*>(P.face_geo) + f0;
+    gma = geo[va ? tid : 0];
+    gmb = geo[vb ? fb : 0];
+  }
+  int oa = -1, ob = -1;
+  if (speed && KIND == 0) {
+    oa = P.face_orig[f0 + (va ? tid : 0)];
+    ob = P.face_orig[f0 + (vb ? fb : 0)];
+  }
+  const int e = e0 + (own ? tid : 0);
+  T         pv[5];
+  if (STAGE > 1) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) pv[k] = prev.p[k][e];
+  }
+  const T     volume = vol[e];
+  const uint4* __restrict__ ellrow = reinterpret_cast<const uint4*>(P.ell + (size_t)e * P.ell_width);
+  const uint4 ell0 = ellrow[0];
+
+  // ---- phase 1 -----------------------------------------------------------------------------------
+  if (a0) {
+    if (KIND == 0) {
+      store_prim<T>(pe, LE, tid, s0);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 5; k++) pe[k * LE + tid] = s0[k];
+    }
+  }
+  if (a1) {
+    if (KIND == 0) {
+      store_prim<T>(pe, LE, i1, s1);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 5; k++) pe[k * LE + i1] = s1[k];
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2 -----------------------------------------------------------------------------------
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const bool     valid = it == 0 ? va : vb;
+    const uint32_t lr    = it == 0 ? lra : lrb;
+    const V4       gm    = it == 0 ? gma : gmb;
+    const int      orig  = it == 0 ? oa : ob;
+    const int      f     = it == 0 ? tid : fb;
+    if (valid) {
+      const int  l = lr & 0xFFFFu, r16 = lr >> 16;
+      const bool wall = r16 == 0xFFFFu;
+      const int  r = wall ? l : r16;
+      const T    n[3] = {gm.x, gm.y, gm.z};
+      T          t1[3], t2[3], g[5], spd = T(0);
+      face_basis<T>(n, t1, t2);
+      if (KIND == 0) {
+        Prim<T> L, R;
+        load_prim<T>(pe, LE, l, L);
+        load_prim<T>(pe, LE, r, R);
+        kepes_prim<T>(L, R, wall, n, t1, t2, gm.w, g, spd);
+        if (orig >= 0) speed[orig] = spd;
+      } else {
+        T sl[5], sr[5], Ff[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+          sl[k] = pe[k * LE + l];
+          sr[k] = pe[k * LE + r];
+        }
+        face_frame_flux_ref<T, 1>(n, t1, t2, sl, sr, wall, Ff, spd);
+#pragma unroll
+        for (int k = 0; k < 5; k++) Ff[k] = gm.w * Ff[k];
+        from_face_frame<T>(n, t1, t2, Ff, g);
+      }
+#pragma unroll
+      for (int k = 0; k < 5; k++) ff[k * LF + f] = g[k];
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3 -----------------------------------------------------------------------------------
+  if (own) {
+    T    acc[5] = {T(0), T(0), T(0), T(0), T(0)};
+    bool done = false;
+    ell_accumulate<T>(ell0, ff, LF, acc, done);
+    for (int c = 1; c < P.ell_width / 8 && !done; c++) ell_accumulate<T>(ellrow[c], ff, LF, acc, done);
+    const T scale = dt / volume;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      T o;
+      if (STAGE == 1) {
+        o = s0[k] + scale * acc[k];
+      } else if (STAGE == 2) {
+        o = rk3c<T>::c21 * pv[k] + rk3c<T>::c22 * s0[k] + rk3c<T>::c23 * scale * acc[k];
+      } else {
+        o = rk3c<T>::c31 * pv[k] + rk3c<T>::c32 * s0[k] + rk3c<T>::c33 * scale * acc[k];
+      }
+      out.p[k][e] = o;
+    }
+  }
+}
+
 template <class T, class V>
 FVars<T> fmk(const V& v) {
   FVars<T> o;
@@ -172,15 +352,27 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
   if (lds > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3  grid(tile_count), block(256);
-#define T8_FUSED(K, S)                                                                                       \
+  const bool  pipelined = plan->ell && plan->ell_width >= 8 && plan->ell_width % 8 == 0 && plan->max_elems <= 256 &&
+                         plan->max_elems + plan->max_halo <= 512 && plan->max_faces <= 512;
+  const bool  dict = pipelined && plan->geo_idx && plan->geo_table && plan->n_geo > 0;
+#define T8_LAUNCH(KERNEL)                                                                                    \
   do {                                                                                                       \
     if (lds > 64 * 1024) {                                                                                   \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_plain_fused<T, K, S>),             \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL),                             \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
       if (e != hipSuccess) return static_cast<int>(e);                                                       \
     }                                                                                                        \
-    hipLaunchKernelGGL((k_plain_fused<T, K, S>), grid, block, lds, s, *plan, tile_begin, fmk<T>(prev),       \
-                       fmk<T>(mid), fmk<T>(out), volume, dt, speed);                                         \
+    hipLaunchKernelGGL(KERNEL, grid, block, lds, s, *plan, tile_begin, fmk<T>(prev), fmk<T>(mid),            \
+                       fmk<T>(out), volume, dt, speed);                                                      \
+  } while (0)
+#define T8_FUSED(K, S)                                              \
+  do {                                                              \
+    if (dict)                                                       \
+      T8_LAUNCH((k_plain_fused_p<T, K, S, true>));                  \
+    else if (pipelined)                                             \
+      T8_LAUNCH((k_plain_fused_p<T, K, S, false>));                 \
+    else                                                            \
+      T8_LAUNCH((k_plain_fused<T, K, S>));                          \
   } while (0)
   if (kind == 0) {
     if (stage == 1) T8_FUSED(0, 1); else if (stage == 2) T8_FUSED(0, 2); else T8_FUSED(0, 3);
@@ -188,6 +380,7 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
     if (stage == 1) T8_FUSED(1, 1); else if (stage == 2) T8_FUSED(1, 2); else T8_FUSED(1, 3);
   }
 #undef T8_FUSED
+#undef T8_LAUNCH
   return static_cast<int>(hipGetLastError());
 }
 

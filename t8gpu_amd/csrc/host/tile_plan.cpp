@@ -30,6 +30,12 @@ struct TilePlan {
   std::vector<int32_t>  csr_off;                       // [N + 1]
   std::vector<uint16_t> csr_ent;                       // tile-local face | 0x8000 if the element is the RIGHT side
   std::vector<int32_t>  tile_order;                    // interior tiles first, then tiles that read ghost slots
+  // compressed forms used by the pipelined kernel
+  int32_t lecap = 512;                                 // max own + halo elements per tile
+  int32_t ell_width = 0;                               // padded per-element face-list width (multiple of 8)
+  std::vector<uint16_t> ell;                           // [N][ell_width], 0xFFFF = padding
+  std::vector<uint16_t> geo_idx;                       // per tile face: index into geo_table (empty if > 65535 distinct)
+  std::vector<double>   geo_table;                     // [n_geo][4]
 };
 
 void build(TilePlan& P, const int32_t* fn, const double* normals, const double* areas) {
@@ -77,6 +83,38 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
       P.elem_off.push_back(e);
       tile++;
     }
+  }
+  // a tile must fit the kernel's LDS window: own + halo elements <= lecap; halve offenders
+  {
+    std::vector<int32_t> stamp(static_cast<size_t>(N) + P.G, -1);
+    std::vector<int32_t> off;
+    int32_t              id = 0;
+    std::vector<std::pair<int32_t, int32_t>> work;
+    for (size_t t = P.elem_off.size() - 1; t-- > 0;) work.push_back({P.elem_off[t], P.elem_off[t + 1]});
+    off.push_back(0);
+    while (!work.empty()) {
+      const auto [a, b] = work.back();
+      work.pop_back();
+      int32_t nh = 0;
+      for (int32_t e = a; e < b; e++)
+        for (int32_t j = deg[e]; j < deg[e + 1]; j++)
+          for (int w = 0; w < 2; w++) {
+            const int32_t o = side(ef[j], w);
+            if (o >= 0 && (o < a || o >= b) && stamp[o] != id) {
+              stamp[o] = id;
+              nh++;
+            }
+          }
+      id++;
+      if ((b - a) + nh > P.lecap && b - a > 1) {
+        const int32_t m = a + (b - a) / 2;
+        work.push_back({m, b});
+        work.push_back({a, m});
+      } else {
+        off.push_back(b);
+      }
+    }
+    P.elem_off.swap(off);
   }
   const int32_t ntiles = static_cast<int32_t>(P.elem_off.size()) - 1;
   P.halo_off.assign(1, 0);
@@ -143,6 +181,38 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
   P.n_interior = static_cast<int32_t>(P.tile_order.size());
   for (int32_t t = 0; t < ntiles; t++)
     if (reads_ghost[t]) P.tile_order.push_back(t);
+
+  // fixed-width (ELL) copy of the element face lists: one aligned 16-byte load per 8 entries
+  int32_t maxdeg = 0;
+  for (int32_t e = 0; e < N; e++) maxdeg = std::max(maxdeg, P.csr_off[e + 1] - P.csr_off[e]);
+  P.ell_width = std::max(8, (maxdeg + 7) / 8 * 8);
+  P.ell.assign(static_cast<size_t>(N) * P.ell_width, 0xFFFFu);
+  for (int32_t e = 0; e < N; e++)
+    for (int32_t c = P.csr_off[e]; c < P.csr_off[e + 1]; c++)
+      P.ell[static_cast<size_t>(e) * P.ell_width + (c - P.csr_off[e])] = P.csr_ent[c];
+
+  // dictionary of distinct {nx, ny, nz, area} tuples (exact bit patterns): Cartesian AMR meshes have a
+  // few dozen, so a face needs a 2-byte index instead of 4 float_type values
+  {
+    struct Key {
+      uint64_t w[4];
+      bool     operator<(const Key& o) const { return std::lexicographical_compare(w, w + 4, o.w, o.w + 4); }
+      bool     operator==(const Key& o) const { return std::equal(w, w + 4, o.w); }
+    };
+    const size_t     nfaces = P.face_lr.size();
+    std::vector<Key> keys(nfaces);
+    for (size_t f = 0; f < nfaces; f++) std::memcpy(keys[f].w, &P.face_geo[4 * f], 32);
+    std::vector<Key> uniq(keys);
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    if (uniq.size() <= 65535) {
+      P.geo_table.resize(uniq.size() * 4);
+      for (size_t i = 0; i < uniq.size(); i++) std::memcpy(&P.geo_table[4 * i], uniq[i].w, 32);
+      P.geo_idx.resize(nfaces);
+      for (size_t f = 0; f < nfaces; f++)
+        P.geo_idx[f] = static_cast<uint16_t>(std::lower_bound(uniq.begin(), uniq.end(), keys[f]) - uniq.begin());
+    }
+  }
 }
 
 }  // namespace
@@ -157,7 +227,7 @@ void* t8gpu_plan_plain_create(int32_t N, int32_t G, int32_t F, int32_t B, int32_
   TilePlan* P = new TilePlan;
   P->N = N; P->G = G; P->F = F; P->B = B; P->ndim = ndim; P->tmax = tmax; P->fcap = fcap;
   build(*P, fn, normals, areas);
-  if (P->max_elems + P->max_halo >= 0xFFFF || P->max_faces > 0x7FFF) {
+  if (P->max_elems + P->max_halo >= 0xFFFF || P->max_faces > 0x7FFE) {
     delete P;
     return nullptr;
   }
@@ -165,7 +235,8 @@ void* t8gpu_plan_plain_create(int32_t N, int32_t G, int32_t F, int32_t B, int32_
 }
 void t8gpu_plan_plain_destroy(void* h) { delete static_cast<TilePlan*>(h); }
 
-// sizes[10] = {ntiles, n_halo, n_faces, n_csr, max_elems, max_halo, max_faces, n_interior_tiles, N, F}
+// sizes[12] = {ntiles, n_halo, n_faces, n_csr, max_elems, max_halo, max_faces, n_interior_tiles, N, F,
+//              ell_width, n_geo (0: no dictionary)}
 void t8gpu_plan_plain_sizes(const void* h, int64_t* sizes) {
   const TilePlan* P = static_cast<const TilePlan*>(h);
   sizes[0] = static_cast<int64_t>(P->elem_off.size()) - 1;
@@ -178,6 +249,15 @@ void t8gpu_plan_plain_sizes(const void* h, int64_t* sizes) {
   sizes[7] = P->n_interior;
   sizes[8] = P->N;
   sizes[9] = P->F;
+  sizes[10] = P->ell_width;
+  sizes[11] = static_cast<int64_t>(P->geo_table.size() / 4);
+}
+
+void t8gpu_plan_plain_compressed(const void* h, uint16_t* ell, uint16_t* geo_idx, double* geo_table) {
+  const TilePlan* P = static_cast<const TilePlan*>(h);
+  if (ell && !P->ell.empty()) std::memcpy(ell, P->ell.data(), P->ell.size() * sizeof(uint16_t));
+  if (geo_idx && !P->geo_idx.empty()) std::memcpy(geo_idx, P->geo_idx.data(), P->geo_idx.size() * sizeof(uint16_t));
+  if (geo_table && !P->geo_table.empty()) std::memcpy(geo_table, P->geo_table.data(), P->geo_table.size() * sizeof(double));
 }
 
 void t8gpu_plan_plain_arrays(const void* h, int32_t* elem_off, int32_t* halo_off, int32_t* face_off,

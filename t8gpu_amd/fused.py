@@ -11,11 +11,12 @@ from .plan import HostPlainPlan
 class T8gpuPlainPlan(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in HostPlainPlan.FIELDS] + [
         ("ntiles", C.c_int32), ("n_interior_tiles", C.c_int32), ("max_elems", C.c_int32), ("max_halo", C.c_int32),
-        ("max_faces", C.c_int32), ("reserved", C.c_int32)]
+        ("max_faces", C.c_int32), ("ell_width", C.c_int32), ("ell", C.c_void_p), ("geo_idx", C.c_void_p),
+        ("geo_table", C.c_void_p), ("n_geo", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PlainPlan:
-    def __init__(self, part, dtype, tmax=256, fcap=512):
+    def __init__(self, part, dtype, tmax=256, fcap=512, compressed=True):
         self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap)
         self.dtype = dtype
         self._keep = {}
@@ -31,6 +32,18 @@ class PlainPlan:
             t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
             self._keep[name] = t
             setattr(c, name, t.data_ptr())
+        npf = np.float32 if dtype == torch.float32 else np.float64
+        if compressed:
+            extra = {"ell": self.host.ell.view(np.int16)}
+            c.ell_width = self.host.ell_width
+            if self.host.geo_table.shape[0] > 0:
+                extra["geo_idx"] = self.host.geo_idx.view(np.int16)
+                extra["geo_table"] = self.host.geo_table.astype(npf)
+                c.n_geo = self.host.geo_table.shape[0]
+            for name, a in extra.items():
+                t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+                self._keep[name] = t
+                setattr(c, name, t.data_ptr())
         c.ntiles, c.n_interior_tiles = self.host.ntiles, self.host.n_interior
         c.max_elems, c.max_halo, c.max_faces = self.host.max_elems, self.host.max_halo, self.host.max_faces
         self.c = c

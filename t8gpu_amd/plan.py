@@ -17,6 +17,7 @@ def _lib():
         lib.t8gpu_plan_plain_destroy.argtypes = [C.c_void_p]
         lib.t8gpu_plan_plain_sizes.argtypes = [C.c_void_p, C.c_void_p]
         lib.t8gpu_plan_plain_arrays.argtypes = [C.c_void_p] * 11
+        lib.t8gpu_plan_plain_compressed.argtypes = [C.c_void_p] * 4
         _ready = True
     return lib
 
@@ -38,7 +39,7 @@ class HostPlainPlan:
         if not h:
             raise ValueError("tile plan exceeds the packed index format (use smaller tmax / fcap)")
         try:
-            sz = np.zeros(10, np.int64)
+            sz = np.zeros(12, np.int64)
             lib.t8gpu_plan_plain_sizes(h, p(sz))
             (self.ntiles, n_halo, n_faces, n_csr, self.max_elems, self.max_halo, self.max_faces,
              self.n_interior) = (int(x) for x in sz[:8])
@@ -54,6 +55,12 @@ class HostPlainPlan:
             self.csr_ent = np.zeros(n_csr, np.uint16)
             self.tile_order = np.zeros(self.ntiles, np.int32)
             lib.t8gpu_plan_plain_arrays(h, *(p(getattr(self, f)) for f in self.FIELDS))
+            self.ell_width, n_geo = int(sz[10]), int(sz[11])
+            self.ell = np.zeros((N, self.ell_width), np.uint16)
+            self.geo_idx = np.zeros(n_faces if n_geo else 0, np.uint16)
+            self.geo_table = np.zeros((n_geo, 4), np.float64)
+            lib.t8gpu_plan_plain_compressed(h, p(self.ell), p(self.geo_idx) if n_geo else None,
+                                            p(self.geo_table) if n_geo else None)
         finally:
             lib.t8gpu_plan_plain_destroy(h)
 

@@ -38,15 +38,17 @@ def test_fused_iterate_vs_oracle(dtype, kind, mesh_args):
     assert rel_err(g.state().cpu().numpy(), o.current()[:, :part.N]) < TOL10[dtype]
 
 
-@pytest.mark.parametrize("tmax,fcap", [(256, 512), (64, 100), (17, 40), (256, 10 ** 6)])
-def test_fused_is_independent_of_the_tiling(tmax, fcap):
+@pytest.mark.parametrize("tmax,fcap,compressed", [(256, 512, False), (64, 100, True), (17, 40, True), (256, 10 ** 6, True),
+                                                  (200, 300, False)])
+def test_fused_is_independent_of_the_tiling(tmax, fcap, compressed):
+    """Pipelined (ELL + geometry dictionary) and generic kernel variants, any tiling: bitwise equal."""
     from t8gpu_amd import fused
     mesh = SynthMesh(2, 3, 6, band=0.06, periodic=False)
     part = mesh.partition()
     st = perturbed_state(part, 4)
     ref = PlainSolver(part, torch.float64, mode="fused", state=st)
     alt = PlainSolver(part, torch.float64, mode="fused", state=st)
-    alt.plan = fused.PlainPlan(part, torch.float64, tmax=tmax, fcap=fcap)
+    alt.plan = fused.PlainPlan(part, torch.float64, tmax=tmax, fcap=fcap, compressed=compressed)
     dt = 0.1 * 2.0 ** -6
     for _ in range(3):
         ref.iterate(dt)
