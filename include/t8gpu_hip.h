@@ -164,6 +164,45 @@ int t8gpu_hip_halo_unpack_f32(int num_ghosts, int first_ghost_slot, const float*
 int t8gpu_hip_halo_unpack_f64(int num_ghosts, int first_ghost_slot, const double* recvbuf, T8gpuVars_f64 state,
                               void* stream);
 
+/* ---- native RCCL transport + whole-step driver ----------------------------------------------------
+ * One communicator per process (one rank per GPU); the 128-byte id is created on one rank and
+ * distributed by the caller (MPI_Bcast, torch.distributed, ...). Replaces the MPI_Allgather of CUDA-IPC
+ * handles at construction and at EVERY resize (shared_device_vector.inl:21-22,95-96,179-185,270-276). */
+int t8gpu_hip_comm_unique_id(char* id128);
+int t8gpu_hip_comm_create(const char* id128, int rank, int nranks, void** comm);
+int t8gpu_hip_comm_destroy(void* comm);
+int t8gpu_hip_comm_abort(void* comm);
+int t8gpu_hip_stream_wait(void* stream, double timeout_s); /* 0 idle, 1 timed out, else hipError_t */
+
+typedef struct T8gpuHalo {
+  int32_t num_elements, num_ghosts, n_peers, n_send;
+  const int32_t* peers;     /* HOST [n_peers] neighbour ranks, ascending                               */
+  const int32_t* send_off;  /* HOST [n_peers+1] ranges of send_idx per peer                            */
+  const int32_t* recv_off;  /* HOST [n_peers+1] ranges of the ghost slots (relative to N) per peer     */
+  const int32_t* send_idx;  /* DEVICE [n_send] owned elements mirrored on a peer                       */
+  void* sendbuf;            /* DEVICE 5*n_send float_type                                              */
+  void* recvbuf;            /* DEVICE 5*num_ghosts float_type                                          */
+  void* comm;               /* from t8gpu_hip_comm_create                                              */
+} T8gpuHalo;
+
+/* pack -> ncclGroupStart, ncclRecv/ncclSend per peer, ncclGroupEnd -> unpack, all on `stream`. */
+int t8gpu_hip_halo_exchange_f32(const T8gpuHalo* halo, T8gpuVars_f32 state, void* stream);
+int t8gpu_hip_halo_exchange_f64(const T8gpuHalo* halo, T8gpuVars_f64 state, void* stream);
+
+/* CompressibleEulerSolver::iterate (solver.cu:75-175) as one call: `planes` is the MemoryManager
+ * allocation (26 planes of `stride`, plane = step*5+var, volume = plane 25; memory_manager.h:460), prev /
+ * next the step ids AFTER the caller's std::swap (solver.cu:76). Enqueues 3 x [exchange on an internal
+ * second stream || interior tiles, then ghost-reading tiles] on `stream` and returns; no host sync. */
+int t8gpu_hip_plain_stepper_create(const T8gpuPlainPlan* plan, const T8gpuHalo* halo_or_null, void** stepper);
+int t8gpu_hip_plain_stepper_destroy(void* stepper);
+int t8gpu_hip_plain_stepper_iterate_f32(void* stepper, int flux_kind, float* planes, size_t stride, int prev, int next,
+                                        float delta_t, float* speed_estimates, void* stream);
+int t8gpu_hip_plain_stepper_iterate_f64(void* stepper, int flux_kind, double* planes, size_t stride, int prev, int next,
+                                        double delta_t, double* speed_estimates, void* stream);
+/* optional HIP-event timing of the stage kernels (for roofline accounting) */
+int t8gpu_hip_plain_stepper_timing(void* stepper, int enable);
+int t8gpu_hip_plain_stepper_elapsed(void* stepper, double* total_ms, int* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,252 @@
+// stepper.hip -- native driver of one SSP-RK3 step: iterate() without any host language in the loop.
+//
+// Mirrors CompressibleEulerSolver::iterate (examples/compressible_euler/solver.cu:75-175) for the fused
+// tier: 3 x [ghost exchange || interior tiles -> ghost-reading tiles]. Where the reference brackets
+// every kernel with cudaDeviceSynchronize + MPI_Barrier (5 pairs per step) this driver only enqueues:
+// ordering is carried by two HIP streams and two events, the ghost exchange is one RCCL group of
+// ncclSend/ncclRecv per neighbour rank over xGMI, and the host returns immediately.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "t8gpu_hip.h"
+
+namespace {
+
+inline int nccl_code(ncclResult_t r) { return r == ncclSuccess ? 0 : 10000 + static_cast<int>(r); }
+
+#define T8_HIP_TRY(expr)                                  \
+  do {                                                    \
+    hipError_t e__ = (expr);                              \
+    if (e__ != hipSuccess) return static_cast<int>(e__);  \
+  } while (0)
+#define T8_TRY(expr)            \
+  do {                          \
+    int c__ = (expr);           \
+    if (c__ != 0) return c__;   \
+  } while (0)
+
+struct Stepper {
+  T8gpuPlainPlan plan{};
+  bool           has_halo = false;
+  T8gpuHalo      halo{};
+  std::vector<int32_t> peers, send_off, recv_off;
+  hipStream_t    comm_stream = nullptr;
+  hipEvent_t     ev_state = nullptr, ev_ghost = nullptr;
+  bool           timing = false;
+  std::vector<hipEvent_t> pool;   // start/stop pairs of the stage-kernel launches
+  size_t         used = 0;
+};
+
+template <class T>
+ncclDataType_t nccl_type();
+template <>
+ncclDataType_t nccl_type<float>() { return ncclFloat; }
+template <>
+ncclDataType_t nccl_type<double>() { return ncclDouble; }
+
+template <class T, class V>
+int exchange(const T8gpuHalo& h, const int32_t* peers, const int32_t* send_off, const int32_t* recv_off, V state,
+             hipStream_t s) {
+  if (h.n_peers <= 0) return 0;
+  T*       sb = static_cast<T*>(h.sendbuf);
+  T*       rb = static_cast<T*>(h.recvbuf);
+  if constexpr (sizeof(T) == 4) {
+    T8_TRY(t8gpu_hip_halo_pack_f32(h.n_send, h.send_idx, state, sb, s));
+  } else {
+    T8_TRY(t8gpu_hip_halo_pack_f64(h.n_send, h.send_idx, state, sb, s));
+  }
+  ncclComm_t comm = static_cast<ncclComm_t>(h.comm);
+  T8_TRY(nccl_code(ncclGroupStart()));
+  for (int j = 0; j < h.n_peers; j++) {
+    const size_t rc = 5 * static_cast<size_t>(recv_off[j + 1] - recv_off[j]);
+    const size_t sc = 5 * static_cast<size_t>(send_off[j + 1] - send_off[j]);
+    if (rc) T8_TRY(nccl_code(ncclRecv(rb + 5 * static_cast<size_t>(recv_off[j]), rc, nccl_type<T>(), peers[j], comm, s)));
+    if (sc) T8_TRY(nccl_code(ncclSend(sb + 5 * static_cast<size_t>(send_off[j]), sc, nccl_type<T>(), peers[j], comm, s)));
+  }
+  T8_TRY(nccl_code(ncclGroupEnd()));
+  if constexpr (sizeof(T) == 4) {
+    T8_TRY(t8gpu_hip_halo_unpack_f32(h.num_ghosts, h.num_elements, rb, state, s));
+  } else {
+    T8_TRY(t8gpu_hip_halo_unpack_f64(h.num_ghosts, h.num_elements, rb, state, s));
+  }
+  return 0;
+}
+
+template <class V, class T>
+V step_vars(T* planes, size_t stride, int step) {
+  V v;
+  for (int k = 0; k < 5; k++) v.p[k] = planes + (static_cast<size_t>(step) * 5 + k) * stride;
+  return v;
+}
+
+int tick(Stepper* S, hipStream_t s) {
+  if (!S->timing) return 0;
+  if (S->used == S->pool.size()) {
+    hipEvent_t e;
+    T8_HIP_TRY(hipEventCreate(&e));
+    S->pool.push_back(e);
+  }
+  T8_HIP_TRY(hipEventRecord(S->pool[S->used++], s));
+  return 0;
+}
+
+template <class T, class V>
+int iterate(Stepper* S, int kind, T* planes, size_t stride, int prev, int next, T dt, T* speed, hipStream_t s) {
+  const int   src[3] = {prev, 1, 2}, dst[3] = {1, 2, next};  // Step1 = 1, Step2 = 2 (solver.h:24-31)
+  const T*    vol = planes + 25 * stride;
+  const int   ni = S->plan.n_interior_tiles, nt = S->plan.ntiles;
+  const V     pv = step_vars<V>(planes, stride, prev);
+  for (int k = 0; k < 3; k++) {
+    const V sv = step_vars<V>(planes, stride, src[k]);
+    const V ov = step_vars<V>(planes, stride, dst[k]);
+    const bool comm = S->has_halo && S->halo.n_peers > 0;
+    if (comm) {
+      T8_HIP_TRY(hipEventRecord(S->ev_state, s));
+      T8_HIP_TRY(hipStreamWaitEvent(S->comm_stream, S->ev_state, 0));
+      T8_TRY((exchange<T, V>(S->halo, S->peers.data(), S->send_off.data(), S->recv_off.data(), sv, S->comm_stream)));
+      T8_HIP_TRY(hipEventRecord(S->ev_ghost, S->comm_stream));
+    }
+    auto launch = [&](int b, int n) -> int {
+      T8_TRY(tick(S, s));
+      if constexpr (sizeof(T) == 4) {
+        T8_TRY(t8gpu_hip_plain_fused_stage_f32(kind, k + 1, &S->plan, b, n, pv, sv, ov, vol, dt, speed, s));
+      } else {
+        T8_TRY(t8gpu_hip_plain_fused_stage_f64(kind, k + 1, &S->plan, b, n, pv, sv, ov, vol, dt, speed, s));
+      }
+      return tick(S, s);
+    };
+    if (!comm || ni == 0 || ni == nt) {
+      if (comm) T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_ghost, 0));
+      T8_TRY(launch(0, nt));
+    } else {
+      T8_TRY(launch(0, ni));
+      T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_ghost, 0));
+      T8_TRY(launch(ni, nt - ni));
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int t8gpu_hip_comm_unique_id(char* id128) {
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) return nccl_code(r);
+  static_assert(sizeof(id) == 128, "ncclUniqueId layout");
+  std::memcpy(id128, &id, 128);
+  return 0;
+}
+
+int t8gpu_hip_comm_create(const char* id128, int rank, int nranks, void** comm) {
+  ncclUniqueId id;
+  std::memcpy(&id, id128, 128);
+  ncclComm_t c = nullptr;
+  ncclResult_t r = ncclCommInitRank(&c, nranks, id, rank);
+  if (r != ncclSuccess) return nccl_code(r);
+  *comm = c;
+  return 0;
+}
+
+int t8gpu_hip_comm_destroy(void* comm) { return comm ? nccl_code(ncclCommDestroy(static_cast<ncclComm_t>(comm))) : 0; }
+int t8gpu_hip_comm_abort(void* comm) { return comm ? nccl_code(ncclCommAbort(static_cast<ncclComm_t>(comm))) : 0; }
+
+int t8gpu_hip_halo_exchange_f32(const T8gpuHalo* h, T8gpuVars_f32 state, void* stream) {
+  if (!h) return static_cast<int>(hipErrorInvalidValue);
+  return exchange<float, T8gpuVars_f32>(*h, h->peers, h->send_off, h->recv_off, state, static_cast<hipStream_t>(stream));
+}
+int t8gpu_hip_halo_exchange_f64(const T8gpuHalo* h, T8gpuVars_f64 state, void* stream) {
+  if (!h) return static_cast<int>(hipErrorInvalidValue);
+  return exchange<double, T8gpuVars_f64>(*h, h->peers, h->send_off, h->recv_off, state, static_cast<hipStream_t>(stream));
+}
+
+// Polls a stream until it is idle or `timeout_s` elapsed (1 = timed out). Lets a caller bound the
+// first exchange on a new communicator and fall back (t8gpu_hip_comm_abort) instead of hanging.
+int t8gpu_hip_stream_wait(void* stream, double timeout_s) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    hipError_t e = hipStreamQuery(static_cast<hipStream_t>(stream));
+    if (e == hipSuccess) return 0;
+    if (e != hipErrorNotReady) return static_cast<int>(e);
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return 1;
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  }
+}
+
+int t8gpu_hip_plain_stepper_create(const T8gpuPlainPlan* plan, const T8gpuHalo* halo, void** out) {
+  if (!plan || !out) return static_cast<int>(hipErrorInvalidValue);
+  Stepper* S = new Stepper;
+  S->plan = *plan;
+  if (halo && halo->n_peers > 0) {
+    S->has_halo = true;
+    S->halo     = *halo;
+    S->peers.assign(halo->peers, halo->peers + halo->n_peers);
+    S->send_off.assign(halo->send_off, halo->send_off + halo->n_peers + 1);
+    S->recv_off.assign(halo->recv_off, halo->recv_off + halo->n_peers + 1);
+    hipError_t e = hipStreamCreateWithFlags(&S->comm_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_state, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_ghost, hipEventDisableTiming);
+    if (e != hipSuccess) {
+      delete S;
+      return static_cast<int>(e);
+    }
+  }
+  *out = S;
+  return 0;
+}
+
+int t8gpu_hip_plain_stepper_destroy(void* h) {
+  Stepper* S = static_cast<Stepper*>(h);
+  if (!S) return 0;
+  for (hipEvent_t e : S->pool) (void)hipEventDestroy(e);
+  if (S->ev_state) (void)hipEventDestroy(S->ev_state);
+  if (S->ev_ghost) (void)hipEventDestroy(S->ev_ghost);
+  if (S->comm_stream) (void)hipStreamDestroy(S->comm_stream);
+  delete S;
+  return 0;
+}
+
+int t8gpu_hip_plain_stepper_iterate_f32(void* h, int flux_kind, float* planes, size_t stride, int prev, int next,
+                                        float delta_t, float* speed, void* stream) {
+  if (!h || prev < 0 || prev > 3 || next < 0 || next > 3) return static_cast<int>(hipErrorInvalidValue);
+  return iterate<float, T8gpuVars_f32>(static_cast<Stepper*>(h), flux_kind, planes, stride, prev, next, delta_t, speed,
+                                       static_cast<hipStream_t>(stream));
+}
+int t8gpu_hip_plain_stepper_iterate_f64(void* h, int flux_kind, double* planes, size_t stride, int prev, int next,
+                                        double delta_t, double* speed, void* stream) {
+  if (!h || prev < 0 || prev > 3 || next < 0 || next > 3) return static_cast<int>(hipErrorInvalidValue);
+  return iterate<double, T8gpuVars_f64>(static_cast<Stepper*>(h), flux_kind, planes, stride, prev, next, delta_t, speed,
+                                        static_cast<hipStream_t>(stream));
+}
+
+int t8gpu_hip_plain_stepper_timing(void* h, int enable) {
+  Stepper* S = static_cast<Stepper*>(h);
+  if (!S) return static_cast<int>(hipErrorInvalidValue);
+  S->timing = enable != 0;
+  S->used   = 0;
+  return 0;
+}
+
+// Sum of the stage-kernel durations recorded since timing was enabled (call after a device sync).
+int t8gpu_hip_plain_stepper_elapsed(void* h, double* total_ms, int* launches) {
+  Stepper* S = static_cast<Stepper*>(h);
+  if (!S || !total_ms || !launches) return static_cast<int>(hipErrorInvalidValue);
+  double sum = 0;
+  for (size_t i = 0; i + 1 < S->used; i += 2) {
+    float ms = 0;
+    T8_HIP_TRY(hipEventElapsedTime(&ms, S->pool[i], S->pool[i + 1]));
+    sum += ms;
+  }
+  *total_ms = sum;
+  *launches = static_cast<int>(S->used / 2);
+  return 0;
+}
+
+}  // extern "C"

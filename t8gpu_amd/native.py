@@ -1,0 +1,98 @@
+"""ctypes mirrors of the native (C++) step driver and RCCL transport of include/t8gpu_hip.h."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import hip
+
+
+class T8gpuHalo(C.Structure):
+    _fields_ = [("num_elements", C.c_int32), ("num_ghosts", C.c_int32), ("n_peers", C.c_int32), ("n_send", C.c_int32),
+                ("peers", C.c_void_p), ("send_off", C.c_void_p), ("recv_off", C.c_void_p), ("send_idx", C.c_void_p),
+                ("sendbuf", C.c_void_p), ("recvbuf", C.c_void_p), ("comm", C.c_void_p)]
+
+
+class NativeComm:
+    """One RCCL communicator per process. `broadcast_bytes(b, src)` distributes rank 0's unique id
+    (torch.distributed, MPI, ...)."""
+
+    def __init__(self, rank, nranks, broadcast_bytes):
+        lib = hip.lib()
+        idbuf = C.create_string_buffer(128)
+        if rank == 0:
+            hip.check(lib.t8gpu_hip_comm_unique_id(idbuf))
+        uid = broadcast_bytes(bytes(idbuf.raw), 0)
+        assert len(uid) == 128
+        self.handle = C.c_void_p()
+        hip.check(lib.t8gpu_hip_comm_create(C.create_string_buffer(uid, 128), rank, nranks, C.byref(self.handle)))
+        self.rank, self.nranks = rank, nranks
+
+    def abort(self):
+        if self.handle:
+            hip.lib().t8gpu_hip_comm_abort(self.handle)
+            self.handle = C.c_void_p()
+
+    def destroy(self):
+        if self.handle:
+            hip.lib().t8gpu_hip_comm_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+class NativeHalo:
+    """T8gpuHalo descriptor of one partition (host index arrays + device buffers)."""
+
+    def __init__(self, part, dtype, comm):
+        self.dtype = dtype
+        self.peers = np.ascontiguousarray(part.peers, np.int32)
+        self.send_off = np.ascontiguousarray(part.send_off, np.int32)
+        self.recv_off = np.ascontiguousarray(part.recv_off, np.int32)
+        self.send_idx = torch.from_numpy(np.ascontiguousarray(part.send_idx, np.int32)).cuda()
+        n_send = int(part.send_idx.size)
+        self.sendbuf = torch.zeros(max(1, 5 * n_send), dtype=dtype, device="cuda")
+        self.recvbuf = torch.zeros(max(1, 5 * part.G), dtype=dtype, device="cuda")
+        c = T8gpuHalo()
+        c.num_elements, c.num_ghosts, c.n_peers, c.n_send = part.N, part.G, len(self.peers), n_send
+        c.peers = self.peers.ctypes.data
+        c.send_off = self.send_off.ctypes.data
+        c.recv_off = self.recv_off.ctypes.data
+        c.send_idx = self.send_idx.data_ptr()
+        c.sendbuf, c.recvbuf = self.sendbuf.data_ptr(), self.recvbuf.data_ptr()
+        c.comm = comm.handle
+        self.c, self.comm = c, comm
+
+    def exchange(self, planes5, stream=None):
+        hip.call("t8gpu_hip_halo_exchange", self.dtype, C.byref(self.c), hip.vars_of(planes5), hip.stream_ptr(stream))
+
+
+class NativeStepper:
+    """t8gpu_hip_plain_stepper_*: the whole iterate() enqueued by one C call."""
+
+    def __init__(self, plan, halo=None):
+        self.plan, self.halo = plan, halo
+        self.handle = C.c_void_p()
+        hip.check(hip.lib().t8gpu_hip_plain_stepper_create(C.byref(plan.c), C.byref(halo.c) if halo is not None else None,
+                                                           C.byref(self.handle)))
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            hip.lib().t8gpu_hip_plain_stepper_destroy(self.handle)
+            self.handle = None
+
+    def iterate(self, solver, delta_t, stream=None):
+        hip.call("t8gpu_hip_plain_stepper_iterate", solver.dtype, self.handle, solver.kind, hip.ptr(solver.planes),
+                 C.c_size_t(solver.stride), solver.prev, solver.next, hip.fscalar(solver.dtype, delta_t),
+                 hip.ptr(solver.speed), hip.stream_ptr(stream))
+
+    def timing(self, enable):
+        hip.check(hip.lib().t8gpu_hip_plain_stepper_timing(self.handle, int(enable)))
+
+    def elapsed(self):
+        ms, n = C.c_double(), C.c_int()
+        hip.check(hip.lib().t8gpu_hip_plain_stepper_elapsed(self.handle, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def stream_wait(stream, timeout_s):
+    """0 = idle, 1 = still busy after timeout_s."""
+    return hip.lib().t8gpu_hip_stream_wait(C.c_void_p(stream.cuda_stream), C.c_double(timeout_s))

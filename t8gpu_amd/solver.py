@@ -128,10 +128,20 @@ class PlainSolver:
                 halo.finish()
             self.plan.stage(self, k + 1, src, dst, delta_t, s, ni, nt - ni)
 
+    def use_native_stepper(self, native_halo=None):
+        """Drive iterate() through the C++ stepper (one C call per step, RCCL called natively)."""
+        from . import native
+        assert self.mode == "fused"
+        self.stepper = native.NativeStepper(self.plan, native_halo)
+        return self.stepper
+
     def iterate(self, delta_t, stream=None, halo=None):
         """One SSP-RK3 step (CompressibleEulerSolver::iterate). `halo` (a halo.HaloExchange) refreshes
         the ghost slots of each stage's source state while the interior tiles are already running."""
         self.begin_step()
+        if getattr(self, "stepper", None) is not None:
+            self.stepper.iterate(self, delta_t, stream)
+            return
         for k in range(3):
             self.run_stage(k, delta_t, stream, halo)
 

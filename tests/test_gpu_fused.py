@@ -84,3 +84,34 @@ def test_uniform_state_is_a_fixed_point_fused():
     f = PlainSolver(part, torch.float64, mode="fused", state=uniform)
     f.iterate(1e-3)
     assert rel_err(f.state().cpu().numpy(), uniform) < 1e-13
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_native_stepper_equals_python_driven_iterate(dtype):
+    mesh = SynthMesh(2, 3, 7, band=0.06, periodic=False)
+    part = mesh.partition()
+    st = perturbed_state(part, 8)
+    a = PlainSolver(part, dtype, mode="fused", state=st)
+    b = PlainSolver(part, dtype, mode="fused", state=st)
+    stepper = b.use_native_stepper()
+    stepper.timing(True)
+    dt = 0.1 * 2.0 ** -7
+    for _ in range(4):
+        a.iterate(dt)
+        b.iterate(dt)
+    torch.cuda.synchronize()
+    assert (a.next, a.prev) == (b.next, b.prev)
+    assert torch.equal(a.planes, b.planes) and torch.equal(a.speed, b.speed)
+    ms, n = stepper.elapsed()
+    assert n == 12 and ms > 0
+
+
+def test_native_comm_single_rank_and_stream_wait():
+    from t8gpu_amd import native
+    comm = native.NativeComm(0, 1, lambda b, src: b)           # nranks = 1: bootstrap + init only
+    part = SynthMesh(2, 3, 5, band=0.06).partition()
+    halo = native.NativeHalo(part, torch.float64, comm)
+    planes = torch.zeros(5, part.N, dtype=torch.float64, device="cuda")
+    halo.exchange(planes)                                      # no peers: must be a no-op
+    assert native.stream_wait(torch.cuda.current_stream(), 5.0) == 0
+    comm.destroy()
