@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 WORKLOADS = {
     "c1": dict(kind="plain", dim=2, base=8, lmax=8, band=0.0, dtype="f64", desc="2D KH uniform 256^2 quads"),
     "c2": dict(kind="plain", dim=2, base=6, lmax=11, band=0.0596, dtype="f64", desc="2D KH AMR levels 6-11 (~1.03 M elements)"),
-    "c3": dict(kind="subgrid", dim=3, base=5, lmax=6, band=0.14, dtype="f32", desc="3D Subgrid<4,4,4> AMR levels 5-6"),
+    "c3": dict(kind="subgrid", dim=3, base=5, lmax=6, band=0.17, dtype="f32", desc="3D Subgrid<4,4,4> AMR levels 5-6"),
     "c4": dict(kind="plain", dim=2, base=7, lmax=12, band=0.1472, dtype="f64", desc="2D KH AMR levels 7-12 (~9.93 M elements)"),
 }
 

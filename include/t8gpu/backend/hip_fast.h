@@ -1,0 +1,156 @@
+// t8gpu/backend/hip_fast.h -- C++ binding of the C-ABI (include/t8gpu_hip.h) for code written against
+// the t8gpu accessor API. This is what a t8gpu maintainer adds to re-point
+// CompressibleEulerSolver::iterate (examples/compressible_euler/solver.cu:75-175) at the tuned kernels:
+//
+//     t8gpu::hip::PlainFusedPlan plan(host_mesh);                    // at every connectivity rebuild
+//     ...
+//     std::swap(next, prev);                                          // solver.cu:76
+//     t8gpu::hip::iterate_fused(mesh_manager, plan, prev, next, delta_t, speed_estimates);
+//
+// or, keeping the reference's kernel-by-kernel structure, t8gpu::hip::flux_faces / flux_boundary /
+// rk3_stage in place of the three <<<>>> launches of a stage. Errors abort like T8GPU_CUDA_CHECK_ERROR.
+#ifndef T8GPU_HIP_BACKEND_HIP_FAST_H
+#define T8GPU_HIP_BACKEND_HIP_FAST_H
+
+#include <t8gpu/mesh/mesh_manager.h>
+#include <t8gpu_hip.h>
+#include <t8gpu_host.h>
+
+#include <type_traits>
+#include <vector>
+
+namespace t8gpu::hip {
+
+  template<typename ft>
+  using vars_t = std::conditional_t<std::is_same_v<ft, float>, T8gpuVars_f32, T8gpuVars_f64>;
+
+  template<typename VariableType>
+  auto to_vars(MemoryAccessorOwn<VariableType> acc) {
+    using ft = typename variable_traits<VariableType>::float_type;
+    static_assert(variable_traits<VariableType>::nb_variables == 5, "the Euler kernels expect Rho, Rho_v1..3, Rho_e");
+    vars_t<ft> v;
+    for (int k = 0; k < 5; k++) v.p[k] = acc.get(k);
+    return v;
+  }
+
+#define T8GPU_DISPATCH(ft, name, ...)                                \
+  do {                                                               \
+    if constexpr (std::is_same_v<ft, float>) {                       \
+      T8GPU_HIP_CHECK_ABI(name##_f32(__VA_ARGS__));                  \
+    } else {                                                         \
+      T8GPU_HIP_CHECK_ABI(name##_f64(__VA_ARGS__));                  \
+    }                                                                \
+  } while (0)
+
+  /// replaces kepes_compute_fluxes<<<>>> (kernels.cu:135-309)
+  template<typename VariableType, size_t dim>
+  void flux_faces(MeshConnectivityAccessor<typename variable_traits<VariableType>::float_type, dim> const& c,
+                  MemoryAccessorOwn<VariableType> state, MemoryAccessorOwn<VariableType> fluxes,
+                  typename variable_traits<VariableType>::float_type* speed, int flux_kind = T8GPU_FLUX_KEPES,
+                  hipStream_t stream = nullptr) {
+    using ft = typename variable_traits<VariableType>::float_type;
+    T8GPU_DISPATCH(ft, t8gpu_hip_flux_faces, flux_kind, c.get_num_local_faces(), static_cast<int>(dim), c.face_neighbors(),
+                   c.indices(), c.face_normals(), c.face_surfaces(), to_vars(state), to_vars(fluxes), speed, stream);
+  }
+  /// replaces reflective_boundary_condition<<<>>> (kernels.cu:311-469)
+  template<typename VariableType, size_t dim>
+  void flux_boundary(MeshConnectivityAccessor<typename variable_traits<VariableType>::float_type, dim> const& c,
+                     MemoryAccessorOwn<VariableType> state, MemoryAccessorOwn<VariableType> fluxes,
+                     typename variable_traits<VariableType>::float_type* speed, int flux_kind = T8GPU_FLUX_KEPES,
+                     hipStream_t stream = nullptr) {
+    using ft = typename variable_traits<VariableType>::float_type;
+    T8GPU_DISPATCH(ft, t8gpu_hip_flux_boundary, flux_kind, c.get_num_local_faces(), c.get_num_local_boundary_faces(),
+                   static_cast<int>(dim), c.face_neighbors(), c.face_normals(), c.face_surfaces(), to_vars(state),
+                   to_vars(fluxes), speed, stream);
+  }
+  /// replaces timestepping::SSP_3RK_step{1,2,3}<<<>>> (ssp_runge_kutta.inl:30-99)
+  template<typename VariableType>
+  void rk3_stage(int stage, int num_elements, MemoryAccessorOwn<VariableType> prev, MemoryAccessorOwn<VariableType> mid,
+                 MemoryAccessorOwn<VariableType> out, MemoryAccessorOwn<VariableType> fluxes,
+                 typename variable_traits<VariableType>::float_type const* volume,
+                 typename variable_traits<VariableType>::float_type delta_t, hipStream_t stream = nullptr) {
+    using ft = typename variable_traits<VariableType>::float_type;
+    T8GPU_DISPATCH(ft, t8gpu_hip_rk3_stage, stage, num_elements, to_vars(prev), to_vars(mid), to_vars(out), to_vars(fluxes),
+                   volume, delta_t, stream);
+  }
+
+  /// Device copy of the tile plan (t8gpu_plan_plain_create) + the native step driver.
+  template<typename ft>
+  class PlainFusedPlan {
+   public:
+    explicit PlainFusedPlan(HostMeshArrays const& m, int ndim = 3, int tmax = 256, int fcap = 512) {
+      void* h = t8gpu_plan_plain_create(m.num_local_elements, m.num_ghost_elements, m.num_local_faces,
+                                        m.num_local_boundary_faces, ndim, m.face_neighbors.data(), m.face_normals.data(),
+                                        m.face_surfaces.data(), tmax, fcap);
+      if (!h) T8GPU_ABORT("t8gpu_plan_plain_create failed");
+      int64_t sz[12];
+      t8gpu_plan_plain_sizes(h, sz);
+      const size_t nt = sz[0], nhalo = sz[1], nfaces = sz[2], ncsr = sz[3], N = sz[8], w = sz[10], ngeo = sz[11];
+      std::vector<int32_t>  elem_off(nt + 1), halo_off(nt + 1), face_off(nt + 1), halo_ids(nhalo), face_orig(nfaces),
+          csr_off(N + 1), tile_order(nt);
+      std::vector<uint32_t> face_lr(nfaces);
+      std::vector<double>   geo(4 * nfaces), table(4 * ngeo);
+      std::vector<uint16_t> csr_ent(ncsr), ell(N * w), geo_idx(ngeo ? nfaces : 0);
+      t8gpu_plan_plain_arrays(h, elem_off.data(), halo_off.data(), face_off.data(), halo_ids.data(), face_lr.data(),
+                              geo.data(), face_orig.data(), csr_off.data(), csr_ent.data(), tile_order.data());
+      t8gpu_plan_plain_compressed(h, ell.data(), ngeo ? geo_idx.data() : nullptr, ngeo ? table.data() : nullptr);
+      t8gpu_plan_plain_destroy(h);
+      m_plan.elem_off   = up(elem_off);
+      m_plan.halo_off   = up(halo_off);
+      m_plan.face_off   = up(face_off);
+      m_plan.halo_ids   = up(halo_ids);
+      m_plan.face_lr    = up(face_lr);
+      m_plan.face_geo   = up(std::vector<ft>(geo.begin(), geo.end()));
+      m_plan.face_orig  = up(face_orig);
+      m_plan.csr_off    = up(csr_off);
+      m_plan.csr_ent    = up(csr_ent);
+      m_plan.tile_order = up(tile_order);
+      m_plan.ell        = up(ell);
+      m_plan.geo_idx    = ngeo ? up(geo_idx) : nullptr;
+      m_plan.geo_table  = ngeo ? up(std::vector<ft>(table.begin(), table.end())) : nullptr;
+      m_plan.ntiles = static_cast<int32_t>(nt); m_plan.n_interior_tiles = static_cast<int32_t>(sz[7]);
+      m_plan.max_elems = static_cast<int32_t>(sz[4]); m_plan.max_halo = static_cast<int32_t>(sz[5]);
+      m_plan.max_faces = static_cast<int32_t>(sz[6]); m_plan.ell_width = static_cast<int32_t>(w);
+      m_plan.n_geo = static_cast<int32_t>(ngeo); m_plan.reserved = 0;
+      T8GPU_HIP_CHECK_ABI(t8gpu_hip_plain_stepper_create(&m_plan, nullptr, &m_stepper));
+    }
+    ~PlainFusedPlan() {
+      t8gpu_hip_plain_stepper_destroy(m_stepper);
+      for (void* p : m_allocs) (void)hipFree(p);
+    }
+    PlainFusedPlan(PlainFusedPlan const&)            = delete;
+    PlainFusedPlan& operator=(PlainFusedPlan const&) = delete;
+    [[nodiscard]] T8gpuPlainPlan const& view() const { return m_plan; }
+    [[nodiscard]] void*                 stepper() const { return m_stepper; }
+
+   private:
+    T8gpuPlainPlan     m_plan{};
+    void*              m_stepper = nullptr;
+    std::vector<void*> m_allocs;
+    template<typename T>
+    T* up(std::vector<T> const& v) {
+      T* d = nullptr;
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&d, sizeof(T) * (v.empty() ? 1 : v.size())));
+      if (!v.empty()) T8GPU_CUDA_CHECK_ERROR(hipMemcpy(d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+      m_allocs.push_back(d);
+      return d;
+    }
+  };
+
+  /// the three stages of iterate() (solver.cu:78-174) in one call; prev/next are the step ids after the swap
+  template<typename VariableType, typename StepType, size_t dim>
+  void iterate_fused(SyntheticMeshManager<VariableType, StepType, dim>&                                  mesh,
+                     PlainFusedPlan<typename variable_traits<VariableType>::float_type> const&           plan,
+                     typename step_traits<StepType>::index_type prev, typename step_traits<StepType>::index_type next,
+                     typename variable_traits<VariableType>::float_type delta_t,
+                     typename variable_traits<VariableType>::float_type* speed, int flux_kind = T8GPU_FLUX_KEPES,
+                     hipStream_t stream = nullptr) {
+    using ft = typename variable_traits<VariableType>::float_type;
+    T8GPU_DISPATCH(ft, t8gpu_hip_plain_stepper_iterate, plan.stepper(), flux_kind, mesh.planes_base(), mesh.plane_stride(),
+                   static_cast<int>(prev), static_cast<int>(next), delta_t, speed, stream);
+  }
+#undef T8GPU_DISPATCH
+
+}  // namespace t8gpu::hip
+
+#endif  // T8GPU_HIP_BACKEND_HIP_FAST_H

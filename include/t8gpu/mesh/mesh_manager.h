@@ -1,0 +1,155 @@
+// t8gpu/mesh/mesh_manager.h (MI355X backend)
+//
+// MeshConnectivityAccessor<float_type, dim>: the device-side view of the face lists, with the getters
+// of the reference (t8gpu/mesh/mesh_manager.h:30-182) over the same arrays:
+//   ranks[N+G], indices[N+G], face_neighbors[2F + B], face_normals[dim * (F + B)], face_surfaces[F + B].
+// SyntheticMeshManager<V, S, dim>: MemoryManager + those arrays filled from host vectors (e.g. the
+// t8code-free provider of include/t8gpu_host.h). It exposes the part of MeshManager's interface the hot
+// path uses (mesh_manager.h:253-421): get_connectivity_information(), get_num_local_{elements,faces,
+// boundary_faces}(), get_num_ghost_elements(), get_{own,all}_variable(s), get_own_volume().
+// The t8code-bound MeshManager (constructor from a forest, adapt, partition, VTK) is NOT part of this
+// round; it needs t8code, which this build does not have.
+#ifndef T8GPU_HIP_MESH_MESH_MANAGER_H
+#define T8GPU_HIP_MESH_MESH_MANAGER_H
+
+#include <t8gpu/memory/memory_manager.h>
+
+#include <array>
+#include <cstdint>
+#include <vector>
+
+#if !__has_include(<t8.h>)
+using t8_locidx_t = int32_t;
+#else
+#include <t8.h>
+#endif
+
+namespace t8gpu {
+
+  template<typename float_type, size_t dim>
+  class MeshConnectivityAccessor {
+    template<typename VT, typename ST, size_t dim_>
+    friend class MeshManager;
+    template<typename VT, typename ST, size_t dim_>
+    friend class SyntheticMeshManager;
+
+   public:
+    MeshConnectivityAccessor(MeshConnectivityAccessor const&)            = default;
+    MeshConnectivityAccessor& operator=(MeshConnectivityAccessor const&) = default;
+
+    [[nodiscard]] __host__ __device__ inline t8_locidx_t get_num_local_faces() const { return m_num_local_faces; }
+    [[nodiscard]] __host__ __device__ inline t8_locidx_t get_num_local_boundary_faces() const { return m_num_local_boundary_faces; }
+
+    [[nodiscard]] __device__ inline float_type get_face_surface(int f) const { return m_face_surfaces[f]; }
+    [[nodiscard]] __device__ inline float_type get_boundary_face_surface(int f) const { return m_face_surfaces[m_num_local_faces + f]; }
+
+    [[nodiscard]] __device__ inline std::array<float_type, dim> get_face_normal(int f) const { return normal_at(f); }
+    [[nodiscard]] __device__ inline std::array<float_type, dim> get_boundary_face_normal(int f) const { return normal_at(m_num_local_faces + f); }
+
+    /// (left, right) LOCAL element indices; >= num_local_elements means a ghost (mirror slot)
+    [[nodiscard]] __device__ inline std::array<t8_locidx_t, 2> get_face_neighbor_indices(int f) const {
+      return {m_face_neighbors[2 * f], m_face_neighbors[2 * f + 1]};
+    }
+    [[nodiscard]] __device__ inline t8_locidx_t get_boundary_face_neighbor_index(int f) const {
+      return m_face_neighbors[2 * m_num_local_faces + f];
+    }
+    /// owner rank / slot of a local element index. In this backend every element (ghosts included)
+    /// resolves to a slot of THIS rank's planes, so `var[rank][index]` never leaves the device.
+    [[nodiscard]] __device__ inline t8_locidx_t get_element_owner_rank(int e) const { return m_ranks[e]; }
+    [[nodiscard]] __device__ inline t8_locidx_t get_element_owner_remote_index(int e) const { return m_indices[e]; }
+
+    // raw arrays, for the C-ABI (t8gpu_hip_flux_faces_* takes exactly these)
+    [[nodiscard]] __host__ __device__ t8_locidx_t const* face_neighbors() const { return m_face_neighbors; }
+    [[nodiscard]] __host__ __device__ t8_locidx_t const* indices() const { return m_indices; }
+    [[nodiscard]] __host__ __device__ float_type const*  face_normals() const { return m_face_normals; }
+    [[nodiscard]] __host__ __device__ float_type const*  face_surfaces() const { return m_face_surfaces; }
+
+   private:
+    int const*         m_ranks;
+    t8_locidx_t const* m_indices;
+    t8_locidx_t const* m_face_neighbors;
+    float_type const*  m_face_normals;
+    float_type const*  m_face_surfaces;
+    t8_locidx_t        m_num_local_faces;
+    t8_locidx_t        m_num_local_boundary_faces;
+
+    __device__ inline std::array<float_type, dim> normal_at(int slot) const {
+      std::array<float_type, dim> n{};
+      for (size_t k = 0; k < dim; k++) n[k] = m_face_normals[dim * slot + k];
+      return n;
+    }
+    MeshConnectivityAccessor(int const* ranks, t8_locidx_t const* indices, t8_locidx_t const* fn, float_type const* normals,
+                             float_type const* surfaces, t8_locidx_t F, t8_locidx_t B)
+        : m_ranks{ranks}, m_indices{indices}, m_face_neighbors{fn}, m_face_normals{normals}, m_face_surfaces{surfaces},
+          m_num_local_faces{F}, m_num_local_boundary_faces{B} {}
+  };
+
+  /// Host description of one rank's mesh in the reference's array formats (doubles are converted to
+  /// float_type the way the reference casts t8code's doubles, mesh_manager.inl:400-407).
+  struct HostMeshArrays {
+    int32_t num_local_elements = 0, num_ghost_elements = 0, num_local_faces = 0, num_local_boundary_faces = 0;
+    int     rank = 0;
+    std::vector<int32_t> face_neighbors;  // [2F + B]
+    std::vector<double>  face_normals;    // [dim * (F + B)]
+    std::vector<double>  face_surfaces;   // [F + B]
+    std::vector<double>  volumes;         // [N + G]
+  };
+
+  template<typename VariableType, typename StepType, size_t dim>
+  class SyntheticMeshManager : public MemoryManager<VariableType, StepType> {
+   public:
+    using float_type          = typename variable_traits<VariableType>::float_type;
+    using variable_index_type = typename variable_traits<VariableType>::index_type;
+    using step_index_type     = typename step_traits<StepType>::index_type;
+
+    explicit SyntheticMeshManager(HostMeshArrays const& m, sc_MPI_Comm comm = sc_MPI_COMM_WORLD)
+        : MemoryManager<VariableType, StepType>(static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements, comm),
+          m_num_local_elements{m.num_local_elements}, m_num_ghost_elements{m.num_ghost_elements},
+          m_num_local_faces{m.num_local_faces}, m_num_local_boundary_faces{m.num_local_boundary_faces} {
+      const size_t tot = static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements;
+      std::vector<int>         ranks(tot, m.rank);
+      std::vector<t8_locidx_t> indices(tot);
+      for (size_t i = 0; i < tot; i++) indices[i] = static_cast<t8_locidx_t>(i);
+      upload(m_ranks, ranks);
+      upload(m_indices, indices);
+      upload(m_face_neighbors, m.face_neighbors);
+      upload(m_face_normals, std::vector<float_type>(m.face_normals.begin(), m.face_normals.end()));
+      upload(m_face_surfaces, std::vector<float_type>(m.face_surfaces.begin(), m.face_surfaces.end()));
+      this->set_volume(std::vector<float_type>(m.volumes.begin(), m.volumes.end()));
+    }
+    ~SyntheticMeshManager() {
+      (void)hipFree(m_ranks);
+      (void)hipFree(m_indices);
+      (void)hipFree(m_face_neighbors);
+      (void)hipFree(m_face_normals);
+      (void)hipFree(m_face_surfaces);
+    }
+    SyntheticMeshManager(SyntheticMeshManager const&)            = delete;
+    SyntheticMeshManager& operator=(SyntheticMeshManager const&) = delete;
+
+    [[nodiscard]] MeshConnectivityAccessor<float_type, dim> get_connectivity_information() const {
+      return {m_ranks, m_indices, m_face_neighbors, m_face_normals, m_face_surfaces, m_num_local_faces, m_num_local_boundary_faces};
+    }
+    [[nodiscard]] t8_locidx_t get_num_local_elements() const { return m_num_local_elements; }
+    [[nodiscard]] t8_locidx_t get_num_ghost_elements() const { return m_num_ghost_elements; }
+    [[nodiscard]] t8_locidx_t get_num_local_faces() const { return m_num_local_faces; }
+    [[nodiscard]] t8_locidx_t get_num_local_boundary_faces() const { return m_num_local_boundary_faces; }
+
+   private:
+    t8_locidx_t  m_num_local_elements, m_num_ghost_elements, m_num_local_faces, m_num_local_boundary_faces;
+    int*         m_ranks          = nullptr;
+    t8_locidx_t* m_indices        = nullptr;
+    t8_locidx_t* m_face_neighbors = nullptr;
+    float_type*  m_face_normals   = nullptr;
+    float_type*  m_face_surfaces  = nullptr;
+
+    template<typename T>
+    static void upload(T*& dst, std::vector<T> const& src) {
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&dst, sizeof(T) * (src.empty() ? 1 : src.size())));
+      if (!src.empty()) T8GPU_CUDA_CHECK_ERROR(hipMemcpy(dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
+    }
+  };
+
+}  // namespace t8gpu
+
+#endif  // T8GPU_HIP_MESH_MESH_MANAGER_H

@@ -1,0 +1,57 @@
+/* t8gpu_host.h -- C ABI of the host-only library (t8gpu_amd/lib/libt8gpu_host.so, no HIP dependency).
+ *
+ *  - t8gpu_synth_*: t8code-free provider of the hot path's input contract (the arrays
+ *    MeshManager::compute_connectivity_information builds, t8gpu/mesh/mesh_manager.inl:333-481 and
+ *    subgrid_mesh_manager.inl:560-961) for periodic / walled unit squares and cubes with 2:1 AMR,
+ *    SFC partitions with ghost mirror slots and per-peer halo lists.
+ *  - t8gpu_plan_plain_*: the tiling pre-pass of the fused kernels (see T8gpuPlainPlan in t8gpu_hip.h),
+ *    run at every connectivity rebuild.
+ * All pointers are HOST pointers; output arrays are caller-allocated (sizes from the *_counts/_sizes calls).
+ */
+#ifndef T8GPU_HOST_H
+#define T8GPU_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- synthetic mesh -------------------------------------------------------------------------- */
+void*   t8gpu_synth_mesh_create(int dim, int base_level, int max_level, double band, double shrink, int periodic);
+void    t8gpu_synth_mesh_destroy(void* mesh);
+int64_t t8gpu_synth_mesh_num_elements(const void* mesh);
+int     t8gpu_synth_mesh_finest_level(const void* mesh);
+
+void* t8gpu_synth_part_create(const void* mesh, int rank, int nranks, int subgrid, int normal_dim);
+void  t8gpu_synth_part_destroy(void* part);
+/* counts[8] = {N, G, F, B, n_peers, n_send, first_global, n_global} */
+void t8gpu_synth_part_counts(const void* part, int64_t* counts);
+/* face_neighbors[2F+B], normals[normal_dim*(F+B)], areas[F+B], level_diff[F], nb_offset[dim*F] (subgrid) */
+void t8gpu_synth_part_connectivity(const void* part, int32_t* face_neighbors, double* normals, double* areas,
+                                   int32_t* level_diff, int32_t* nb_offset);
+/* per owned + ghost element: level[N+G], volume[N+G], centre[(N+G)*3] */
+void t8gpu_synth_part_elements(const void* part, int32_t* level, double* volume, double* centre);
+void t8gpu_synth_part_halo(const void* part, int64_t* ghost_global, int32_t* ghost_owner, int32_t* peers,
+                           int32_t* recv_off, int32_t* send_off, int32_t* send_idx);
+/* Kelvin-Helmholtz initial state (values of examples/subgrid/solver.inl:35-56,84-103): out = 5 planes of
+ * `stride` doubles; cells_per_dim = 1 (plain) or 4 (Subgrid<4,..>, index e*S + i + 4j + 16k). */
+void t8gpu_synth_part_kh_ic(const void* part, int cells_per_dim, double* out, size_t stride);
+
+/* ---- tile plan of the fused plain-element kernels --------------------------------------------- */
+void* t8gpu_plan_plain_create(int32_t N, int32_t G, int32_t F, int32_t B, int32_t ndim, const int32_t* face_neighbors,
+                              const double* normals, const double* areas, int32_t tmax, int32_t fcap);
+void  t8gpu_plan_plain_destroy(void* plan);
+/* sizes[12] = {ntiles, n_halo, n_faces, n_csr, max_elems, max_halo, max_faces, n_interior_tiles, N, F,
+ *              ell_width, n_geo} */
+void t8gpu_plan_plain_sizes(const void* plan, int64_t* sizes);
+void t8gpu_plan_plain_arrays(const void* plan, int32_t* elem_off, int32_t* halo_off, int32_t* face_off,
+                             int32_t* halo_ids, uint32_t* face_lr, double* face_geo, int32_t* face_orig,
+                             int32_t* csr_off, uint16_t* csr_ent, int32_t* tile_order);
+void t8gpu_plan_plain_compressed(const void* plan, uint16_t* ell, uint16_t* geo_idx, double* geo_table);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T8GPU_HOST_H */
