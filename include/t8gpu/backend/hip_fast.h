@@ -89,7 +89,7 @@ namespace t8gpu::hip {
       std::vector<int32_t>  elem_off(nt + 1), halo_off(nt + 1), face_off(nt + 1), halo_ids(nhalo), face_orig(nfaces),
           csr_off(N + 1), tile_order(nt);
       std::vector<uint32_t> face_lr(nfaces);
-      std::vector<double>   geo(4 * nfaces), table(4 * ngeo);
+      std::vector<double>   geo(4 * nfaces), table(12 * ngeo);
       std::vector<uint16_t> csr_ent(ncsr), ell(N * w), geo_idx(ngeo ? nfaces : 0);
       t8gpu_plan_plain_arrays(h, elem_off.data(), halo_off.data(), face_off.data(), halo_ids.data(), face_lr.data(),
                               geo.data(), face_orig.data(), csr_off.data(), csr_ent.data(), tile_order.data());

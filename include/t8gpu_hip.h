@@ -135,7 +135,7 @@ typedef struct T8gpuPlainPlan {
    * elements and <= 512 faces the software-pipelined kernel variant is used */
   const uint16_t* ell;        /* [N][ell_width] copy of the CSR lists, 0xFFFF-padded, 16-byte rows      */
   const uint16_t* geo_idx;    /* per tile face: row of geo_table                                      */
-  const void*     geo_table;  /* float_type [n_geo][4]: the distinct {nx, ny, nz, area} tuples         */
+  const void*     geo_table;  /* float_type [n_geo][12]: distinct {nx,ny,nz,area, t1x,t1y,t1z,0, t2x,t2y,t2z,0} */
   int32_t n_geo, reserved;
 } T8gpuPlainPlan;
 
@@ -202,6 +202,27 @@ int t8gpu_hip_plain_stepper_iterate_f64(void* stepper, int flux_kind, double* pl
 /* optional HIP-event timing of the stage kernels (for roofline accounting) */
 int t8gpu_hip_plain_stepper_timing(void* stepper, int enable);
 int t8gpu_hip_plain_stepper_elapsed(void* stepper, double* total_ms, int* launches);
+
+/* ---- Subgrid<4,4,4>, fused block kernel ("fast" tier) ----------------------------------------------
+ * One launch per RK stage replaces compute_inner_fluxes + compute_boundary_fluxes + compute_outer_fluxes
+ * + subgrid::SSP_3RK_stepK of that stage (examples/subgrid/solver.inl:166-195): one 64-lane wavefront per
+ * 4x4x4 block evaluates every flux its subcells need (an outer sub-face is evaluated by both blocks that
+ * share it) and applies the RK stage; the Fluxes planes are neither read nor written. The plan is the
+ * per-block face list built by t8gpu_plan_subgrid_create() (csrc/host/subgrid_plan.cpp). */
+typedef struct T8gpuSubgridPlan {
+  const int32_t* bf_off;        /* [num_elements+1] into bf_ent                                         */
+  const int32_t* bf_ent;        /* face index (bit 31: the block is the face's RIGHT side); walls first */
+  const int32_t* face_rec;      /* [F+B][4] = left slot, right slot (-1 wall), code, 0 (16-byte aligned) */
+  const void*    face_surfaces; /* float_type [F+B], the reference's face_surfaces array                 */
+  int32_t num_elements, rank, max_faces_per_block, reserved;
+} T8gpuSubgridPlan;
+
+int t8gpu_hip_subgrid_fused_stage_f32(int flux_kind, int stage, const T8gpuSubgridPlan* plan, T8gpuVars_f32 prev,
+                                      T8gpuVars_f32 mid, T8gpuVars_f32 out, const float* volumes, float delta_t,
+                                      void* stream);
+int t8gpu_hip_subgrid_fused_stage_f64(int flux_kind, int stage, const T8gpuSubgridPlan* plan, T8gpuVars_f64 prev,
+                                      T8gpuVars_f64 mid, T8gpuVars_f64 out, const double* volumes, double delta_t,
+                                      void* stream);
 
 #ifdef __cplusplus
 }

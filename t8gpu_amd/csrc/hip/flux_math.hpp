@@ -159,6 +159,24 @@ T8_DEV void hll_ref(const T uL[5], const T uR[5], T F[5]) {
   for (int k = 0; k < 5; k++) F[k] = ((sr * Fl[k] - sl * Fr[k]) + sr * sl * (uR[k] - uL[k])) / (sr - sl);
 }
 
+// frame of an axis-aligned face: exactly what face_basis() returns for n = +-e_axis
+template <class T>
+T8_DEV void axis_basis(int axis, bool positive, T n[3], T t1[3], T t2[3]) {
+  const T s = positive ? T(1) : T(-1);
+  n[0] = n[1] = n[2] = t1[0] = t1[1] = t1[2] = t2[0] = t2[1] = t2[2] = T(0);
+  n[axis] = s;
+  if (axis == 0) {
+    t1[2] = -s;
+    t2[1] = T(1);
+  } else if (axis == 1) {
+    t1[0] = s;
+    t2[2] = T(-1);
+  } else {
+    t1[1] = s;
+    t2[0] = T(-1);
+  }
+}
+
 // face frame (n, t1, t2): kernels.cu:174-193 == kernels.inl:133-156
 template <class T>
 T8_DEV void face_basis(const T n[3], T t1[3], T t2[3]) {
@@ -226,6 +244,24 @@ T8_DEV void from_face_frame(const T n[3], const T t1[3], const T t2[3], const T 
 // ~20. Frame-invariant pieces (|v|^2, the scalar entropy variable) are not rotated at all.
 // Same flux as kernels.cu:38-133,220-279 up to rounding (a few ulp; parity tolerance in tests/).
 // ------------------------------------------------------------------------------------------------
+// Division in the fast tier. The reference-dataflow kernels keep IEEE division (v_div_scale / v_div_fmas /
+// v_div_fixup: 10 instructions in fp32, 13 in fp64); here operands are O(1) physical quantities, never
+// denormal or huge, so a reciprocal plus Newton steps is enough: fp32 v_rcp_f32 (1 ulp) and one
+// multiply, fp64 v_rcp_f64 + two Newton steps + one residual correction (< 1 ulp, checked in tests).
+T8_DEV float t8_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+T8_DEV double t8_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r        = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r        = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+T8_DEV float  t8_div(float a, float b) { return a * t8_rcp(b); }
+T8_DEV double t8_div(double a, double b) {
+  const double r = t8_rcp(b);
+  const double q = a * r;
+  return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+}
+
 template <class T>
 struct Prim {
   T rho, vx, vy, vz, p, beta, lrho, lbeta, v0;
@@ -237,41 +273,41 @@ T8_DEV Prim<T> prim_from_state(const T s[5]) {
   const T one = T(1), half = T(0.5), kappa = T(1.4);
   const T km1 = kappa - one;
   Prim<T> q;
-  const T ir = one / s[0];
+  const T ir = t8_rcp(s[0]);
   q.rho      = s[0];
   q.vx       = s[1] * ir;
   q.vy       = s[2] * ir;
   q.vz       = s[3] * ir;
   const T ke = half * (q.vx * q.vx + q.vy * q.vy + q.vz * q.vz);
   q.p        = km1 * (s[4] - s[0] * ke);
-  const T rp = s[0] / q.p;
+  const T rp = t8_div(s[0], q.p);
   q.beta     = half * rp;
   q.lrho     = t8_log(s[0]);
   const T lp = t8_log(q.p);
   q.lbeta    = q.lrho - lp;
-  q.v0       = (kappa - (lp - kappa * q.lrho)) / km1 - rp * ke;
+  q.v0       = (kappa - (lp - kappa * q.lrho)) * (one / km1) - rp * ke;
   return q;
 }
 
 // logarithmic mean from the two values and log(aR) - log(aL)
 T8_DEV double ln_mean_dlog(double aL, double aR, double dlog) {
   const double d = aR - aL, s = aR + aL;
-  const double f = d / s;
+  const double f = t8_div(d, s);
   const double u = f * f;
   const bool   small = u < 1.0e-4;
   const double num = small ? s * 52.50 : d;
   const double den = small ? (105.0 + u * (35.0 + u * (21.0 + u * 15.0))) : dlog;
-  return num / den;
+  return t8_div(num, den);
 }
 // fp32: a difference of stored logs would cost accuracy near the branch switch; v_log_f32 is cheap.
 T8_DEV float ln_mean_dlog(float aL, float aR, float /*dlog*/) {
   const float d = aR - aL, s = aR + aL;
-  const float f = d / s;
+  const float f = t8_div(d, s);
   const float u = f * f;
   const bool  small = u < 1.0e-4f;
   const float num = small ? s * 52.50f : d;
-  const float den = small ? (105.0f + u * (35.0f + u * (21.0f + u * 15.0f))) : logf(aR / aL);
-  return num / den;
+  const float den = small ? (105.0f + u * (35.0f + u * (21.0f + u * 15.0f))) : logf(t8_div(aR, aL));
+  return t8_div(num, den);
 }
 
 // KEPES flux through a face with unit normal n (basis n, t1, t2), scaled by `area`, in xyz.
@@ -297,12 +333,12 @@ T8_DEV void kepes_prim(const Prim<T>& L, const Prim<T>& R, bool mirror, const T 
 
   const T rho  = ln_mean_dlog(L.rho, R.rho, R.lrho - L.lrho);
   const T bhat = ln_mean_dlog(L.beta, R.beta, R.lbeta - L.lbeta);
-  const T ib   = one / bhat;
+  const T ib   = t8_rcp(bhat);
   const T rho_mean = half * (L.rho + R.rho);
   const T u = half * (uL + uR), v = half * (vL + vR), w = half * (wL + wR);
-  const T a  = t8_sqrt(kappa * half * (L.p + R.p) / rho);
+  const T a  = t8_sqrt(t8_div(kappa * half * (L.p + R.p), rho));
   const T h  = (kappa / (T(2) * km1)) * ib + half * (uL * uR + vL * vR + wL * wR);
-  const T p1 = rho_mean / (L.beta + R.beta);
+  const T p1 = t8_div(rho_mean, L.beta + R.beta);
   const T q2 = qL + qR;
 
   const T Fs0 = rho * u;

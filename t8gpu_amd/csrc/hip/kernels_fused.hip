@@ -229,10 +229,13 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
   const uint32_t lra = P.face_lr[f0 + (va ? tid : 0)];
   const uint32_t lrb = P.face_lr[f0 + (vb ? fb : 0)];
   V4             gma, gmb;
+  int            gia = 0, gib = 0;
   if (DICT) {
     const V4* __restrict__ tab = reinterpret_cast<const V4*>(P.geo_table);
-    gma = tab[P.geo_idx[f0 + (va ? tid : 0)]];
-    gmb = tab[P.geo_idx[f0 + (vb ? fb : 0)]];
+    gia = 3 * P.geo_idx[f0 + (va ? tid : 0)];
+    gib = 3 * P.geo_idx[f0 + (vb ? fb : 0)];
+    gma = tab[gia];
+    gmb = tab[gib];
   } else {
     const V4* __restrict__ geo = reinterpret_cast<const V4*>(P.face_geo) + f0;
     gma = geo[va ? tid : 0];
@@ -286,7 +289,14 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
       const int  r = wall ? l : r16;
       const T    n[3] = {gm.x, gm.y, gm.z};
       T          t1[3], t2[3], g[5], spd = T(0);
-      face_basis<T>(n, t1, t2);
+      if (DICT) {  // frame precomputed per distinct normal (table rows are L1/L2 resident)
+        const V4* __restrict__ tab = reinterpret_cast<const V4*>(P.geo_table);
+        const V4 b1 = tab[(it == 0 ? gia : gib) + 1], b2 = tab[(it == 0 ? gia : gib) + 2];
+        t1[0] = b1.x; t1[1] = b1.y; t1[2] = b1.z;
+        t2[0] = b2.x; t2[1] = b2.y; t2[2] = b2.z;
+      } else {
+        face_basis<T>(n, t1, t2);
+      }
       if (KIND == 0) {
         Prim<T> L, R;
         load_prim<T>(pe, LE, l, L);

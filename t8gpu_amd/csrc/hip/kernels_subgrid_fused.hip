@@ -1,0 +1,303 @@
+// kernels_subgrid_fused.hip -- Subgrid<4,4,4>: one 64-lane wavefront = one block, one launch per RK stage.
+//
+// Replaces, per stage, compute_inner_fluxes + compute_boundary_fluxes + compute_outer_fluxes +
+// subgrid::SSP_3RK_stepK (examples/subgrid/solver.inl:166-195) and their flux-plane round trips
+// (up to 6 read-modify-writes per cell and variable in the inner kernel, 10 atomics per sub-face in the
+// outer one). Lane c owns subcell (i, j, k) = (c & 3, (c >> 2) & 3, c >> 4) of block blockIdx:
+//   1. own state -> per-cell primitives, registers + LDS (neighbours: lane +1 / +4 / +16);
+//   2. inner faces, x then y then z: lanes with coordinate < 3 evaluate the flux to their + neighbour,
+//      the wave exchanges it through LDS (-own, +lower, the reference's order);
+//   3. the block's coarse faces (walls first), four at a time: lane = (face slot, sub-face), the far
+//      side's subcell is gathered from the neighbour block (2:1 hanging map of kernels.inl:752-758), the
+//      sub-face fluxes go to LDS and every cell picks up the ones that end on it, in list order;
+//   4. RK stage on the accumulated flux, coalesced store.
+// An outer sub-face is evaluated by both blocks that share it (same arguments, same result), so there
+// are no atomics, no flux planes and the result is bitwise reproducible. The wave runs in lock-step,
+// so the reference's unsynchronised LDS reuse has no counterpart here.
+#include <hip/hip_runtime.h>
+
+#include "flux_math.hpp"
+#include "t8gpu_hip.h"
+
+namespace t8gpu_hip {
+
+template <class T>
+struct SVars {
+  T* p[5];
+};
+
+T8_DEV int sg_xcd_position(int b, int nb) {
+  const int q = nb >> 3, rem = nb & 7, x = b & 7, k = b >> 3;
+  return x * q + (x < rem ? x : rem) + k;
+}
+
+struct FaceCode {
+  int axis, positive, hanging, off[3];
+};
+T8_DEV FaceCode decode(int code) {
+  FaceCode f;
+  f.axis     = code & 3;
+  f.positive = (code >> 2) & 1;
+  f.hanging  = (code >> 3) & 1;
+  f.off[0]   = (code >> 4) & 3;
+  f.off[1]   = (code >> 6) & 3;
+  f.off[2]   = (code >> 8) & 3;
+  return f;
+}
+
+template <class T, int KIND>
+struct CellData {  // what a flux evaluation needs from one cell: primitives (KEPES) or the raw state (HLL)
+  static constexpr int words = KIND == 0 ? kPrimWords : 5;
+  T v[words];
+};
+
+template <class T, int KIND>
+T8_DEV CellData<T, KIND> cell_from_state(const T s[5]) {
+  CellData<T, KIND> c;
+  if (KIND == 0) {
+    const Prim<T> q = prim_from_state<T>(s);
+    c.v[0] = q.rho; c.v[1] = q.vx; c.v[2] = q.vy; c.v[3] = q.vz; c.v[4] = q.p;
+    c.v[5] = q.beta; c.v[6] = q.lrho; c.v[7] = q.lbeta; c.v[8] = q.v0;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 5; k++) c.v[k] = s[k];
+  }
+  return c;
+}
+
+// area-scaled xyz flux from L to R through a face with unit normal n
+template <class T, int KIND>
+T8_DEV void cell_flux(const CellData<T, KIND>& L, const CellData<T, KIND>& R, bool wall, int axis, bool positive, T area, T g[5]) {
+  T n[3], t1[3], t2[3], spd;
+  axis_basis<T>(axis, positive, n, t1, t2);   // subgrid faces are axis-aligned (kernels.inl:717-750 requires it)
+  if (KIND == 0) {
+    Prim<T> a, b;
+    a.rho = L.v[0]; a.vx = L.v[1]; a.vy = L.v[2]; a.vz = L.v[3]; a.p = L.v[4]; a.beta = L.v[5]; a.lrho = L.v[6]; a.lbeta = L.v[7]; a.v0 = L.v[8];
+    b.rho = R.v[0]; b.vx = R.v[1]; b.vy = R.v[2]; b.vz = R.v[3]; b.p = R.v[4]; b.beta = R.v[5]; b.lrho = R.v[6]; b.lbeta = R.v[7]; b.v0 = R.v[8];
+    kepes_prim<T>(a, b, wall, n, t1, t2, area, g, spd);
+  } else {
+    T Ff[5], q[5];
+    face_frame_flux_ref<T, 1>(n, t1, t2, L.v, R.v, wall, Ff, spd);
+    from_face_frame<T>(n, t1, t2, Ff, q);
+#pragma unroll
+    for (int k = 0; k < 5; k++) g[k] = q[k] * area;
+  }
+}
+
+// What one lane needs for its (face slot, sub-face) of an outer pass; `sf` is the far cell's state.
+template <class T>
+struct FaceLane {
+  bool active, right, wall;
+  int  axis, positive, myflat;
+  T    area, sf[5];
+};
+
+template <class T>
+T8_DEV FaceLane<T> load_face_lane(const T8gpuSubgridPlan& P, const SVars<T>& src, int b0, int nbf, int idx, int si, int sj) {
+  FaceLane<T> L;
+  L.active = idx < nbf;
+  L.right = L.wall = false;
+  L.axis = L.positive = L.myflat = 0;
+  L.area = T(0);
+#pragma unroll
+  for (int k = 0; k < 5; k++) L.sf[k] = T(1);
+  if (L.active) {
+    const int  ent = P.bf_ent[b0 + idx];
+    const int  fid = ent & 0x7FFFFFFF;
+    const int4 rec = reinterpret_cast<const int4*>(P.face_rec)[fid];
+    L.right        = ent < 0;
+    L.wall         = rec.y < 0;
+    L.area         = reinterpret_cast<const T*>(P.face_surfaces)[fid];
+    const FaceCode fc = decode(rec.z);
+    const int  ta = fc.axis == 0 ? 1 : 0, tb = fc.axis == 2 ? 1 : 2;
+    int        lc[3], rc[3];
+    lc[fc.axis] = fc.positive ? 3 : 0;
+    lc[ta]      = si;
+    lc[tb]      = sj;
+    rc[fc.axis] = fc.off[fc.axis];
+    rc[ta]      = fc.off[ta] + (fc.hanging ? si / 2 : si);
+    rc[tb]      = fc.off[tb] + (fc.hanging ? sj / 2 : sj);
+    const int lflat = lc[0] + 4 * lc[1] + 16 * lc[2], rflat = rc[0] + 4 * rc[1] + 16 * rc[2];
+    L.myflat   = L.right ? rflat : lflat;
+    L.axis     = fc.axis;
+    L.positive = fc.positive;
+    if (!L.wall) {
+      const size_t far = (size_t)(L.right ? rec.x : rec.y) * 64 + (L.right ? lflat : rflat);
+#pragma unroll
+      for (int k = 0; k < 5; k++) L.sf[k] = src.p[k][far];
+    }
+  }
+  return L;
+}
+
+template <class T, int KIND, int STAGE>
+__global__ __launch_bounds__(64) void k_subgrid444_fused(T8gpuSubgridPlan P, SVars<T> prev, SVars<T> src, SVars<T> out,
+                                                         const T* __restrict__ volumes, T dt) {
+  constexpr int NW = CellData<T, KIND>::words;
+  __shared__ T  pe[NW][64];  // this block's cells
+  __shared__ T  xb[5][64];   // flux exchange buffer (inner: per cell; outer: [slot * 16 + sub-face])
+  const int    e = sg_xcd_position(blockIdx.x, gridDim.x);
+  const int    c = threadIdx.x;
+  const int    cc[3] = {c & 3, (c >> 2) & 3, c >> 4};
+  const size_t o = (size_t)e * 64 + c;
+
+  T s0[5], pv[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) s0[k] = src.p[k][o];
+  if (STAGE > 1) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) pv[k] = prev.p[k][o];
+  }
+  const T   vol     = volumes[e];
+  const int b0      = P.bf_off[e];
+  const int nbf     = P.bf_off[e + 1] - b0;
+  const T   edge    = t8_cbrt(vol) / T(4);
+  const T   surface = edge * edge;
+
+  // the first two outer passes (8 coarse faces: every block of a uniform region) are fetched NOW, so
+  // that their dependent loads (face list -> face record -> far cell) overlap the inner-face arithmetic
+  const int slot = c >> 4, sub = c & 15, si = sub & 3, sj = sub >> 2;
+  const FaceLane<T> pre0 = load_face_lane<T>(P, src, b0, nbf, slot, si, sj);
+  const FaceLane<T> pre1 = load_face_lane<T>(P, src, b0, nbf, 4 + slot, si, sj);
+
+  const CellData<T, KIND> mine = cell_from_state<T, KIND>(s0);
+#pragma unroll
+  for (int w = 0; w < NW; w++) pe[w][c] = mine.v[w];
+  __syncthreads();
+
+  T acc[5] = {T(0), T(0), T(0), T(0), T(0)};
+
+  // ---- inner faces (kernels.inl:364-533) ---------------------------------------------------------
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const int str = d == 0 ? 1 : (d == 1 ? 4 : 16);
+    T         g[5] = {T(0), T(0), T(0), T(0), T(0)};
+    if (cc[d] < 3) {
+      CellData<T, KIND> nbr;
+#pragma unroll
+      for (int w = 0; w < NW; w++) nbr.v[w] = pe[w][c + str];
+      cell_flux<T, KIND>(mine, nbr, false, d, true, surface, g);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; k++) xb[k][c] = g[k];
+    __syncthreads();
+    if (cc[d] < 3) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) acc[k] -= g[k];
+    }
+    if (cc[d] > 0) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) acc[k] += xb[k][c - str];
+    }
+  }
+
+  // ---- coarse faces of this block: walls (kernels.inl:913-1107), then outer faces (:664-802) -------
+  for (int p0 = 0; p0 < nbf; p0 += 4) {
+    T                 g[5] = {T(0), T(0), T(0), T(0), T(0)};
+    const FaceLane<T> fl = p0 == 0 ? pre0 : (p0 == 4 ? pre1 : load_face_lane<T>(P, src, b0, nbf, p0 + slot, si, sj));
+    if (fl.active) {
+      CellData<T, KIND> here;
+#pragma unroll
+      for (int w = 0; w < NW; w++) here.v[w] = pe[w][fl.myflat];
+      const T sfc = fl.area / T(16);
+      if (fl.wall) {
+        cell_flux<T, KIND>(here, here, true, fl.axis, fl.positive, sfc, g);
+      } else {
+        const CellData<T, KIND> there = cell_from_state<T, KIND>(fl.sf);
+        if (fl.right)
+          cell_flux<T, KIND>(there, here, false, fl.axis, fl.positive, sfc, g);
+        else
+          cell_flux<T, KIND>(here, there, false, fl.axis, fl.positive, sfc, g);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; k++) xb[k][c] = g[k];
+    __syncthreads();
+    // every cell collects the sub-face fluxes that end on it, slot by slot (list order)
+    for (int s = 0; s < 4 && p0 + s < nbf; s++) {
+      const int  ent   = P.bf_ent[b0 + p0 + s];
+      const int  fid   = ent & 0x7FFFFFFF;
+      const bool right = ent < 0;
+      const FaceCode fc = decode(reinterpret_cast<const int4*>(P.face_rec)[fid].z);
+      const int  ta = fc.axis == 0 ? 1 : 0, tb = fc.axis == 2 ? 1 : 2;
+      if (!right) {
+        if (cc[fc.axis] == (fc.positive ? 3 : 0)) {
+          const int q = 16 * s + cc[ta] + 4 * cc[tb];
+#pragma unroll
+          for (int k = 0; k < 5; k++) acc[k] -= xb[k][q];
+        }
+      } else if (cc[fc.axis] == fc.off[fc.axis]) {
+        const int di = cc[ta] - fc.off[ta], dj = cc[tb] - fc.off[tb];
+        if (!fc.hanging) {
+          const int q = 16 * s + di + 4 * dj;
+#pragma unroll
+          for (int k = 0; k < 5; k++) acc[k] += xb[k][q];
+        } else if (di >= 0 && di < 2 && dj >= 0 && dj < 2) {
+#pragma unroll
+          for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+            for (int ii = 0; ii < 2; ii++) {
+              const int q = 16 * s + (2 * di + ii) + 4 * (2 * dj + jj);
+#pragma unroll
+              for (int k = 0; k < 5; k++) acc[k] += xb[k][q];
+            }
+        }
+      }
+    }
+  }
+
+  // ---- RK stage (ssp_runge_kutta.inl:101-221): per-subcell volume = volumes[e] / 64 ------------------
+  const T scale = dt / (vol / T(64));
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    T r;
+    if (STAGE == 1) {
+      r = s0[k] + scale * acc[k];
+    } else if (STAGE == 2) {
+      r = rk3c<T>::c21 * pv[k] + rk3c<T>::c22 * s0[k] + rk3c<T>::c23 * scale * acc[k];
+    } else {
+      r = rk3c<T>::c31 * pv[k] + rk3c<T>::c32 * s0[k] + rk3c<T>::c33 * scale * acc[k];
+    }
+    out.p[k][o] = r;
+  }
+}
+
+template <class T, class V>
+SVars<T> smk(const V& v) {
+  SVars<T> o;
+  for (int k = 0; k < 5; k++) o.p[k] = v.p[k];
+  return o;
+}
+
+template <class T, class V>
+int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, V prev, V mid, V out, const T* volumes, T dt,
+                        void* stream) {
+  if (!plan || (kind != 0 && kind != 1) || stage < 1 || stage > 3 || plan->rank != 3) return static_cast<int>(hipErrorInvalidValue);
+  if (plan->num_elements <= 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3  grid(plan->num_elements), block(64);
+#define T8_SG(K, S) \
+  hipLaunchKernelGGL((k_subgrid444_fused<T, K, S>), grid, block, 0, s, *plan, smk<T>(prev), smk<T>(mid), smk<T>(out), volumes, dt)
+  if (kind == 0) {
+    if (stage == 1) T8_SG(0, 1); else if (stage == 2) T8_SG(0, 2); else T8_SG(0, 3);
+  } else {
+    if (stage == 1) T8_SG(1, 1); else if (stage == 2) T8_SG(1, 2); else T8_SG(1, 3);
+  }
+#undef T8_SG
+  return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace t8gpu_hip
+
+extern "C" {
+int t8gpu_hip_subgrid_fused_stage_f32(int kind, int stage, const T8gpuSubgridPlan* plan, T8gpuVars_f32 prev,
+                                      T8gpuVars_f32 mid, T8gpuVars_f32 out, const float* volumes, float dt, void* stream) {
+  return t8gpu_hip::subgrid_fused_stage<float>(kind, stage, plan, prev, mid, out, volumes, dt, stream);
+}
+int t8gpu_hip_subgrid_fused_stage_f64(int kind, int stage, const T8gpuSubgridPlan* plan, T8gpuVars_f64 prev,
+                                      T8gpuVars_f64 mid, T8gpuVars_f64 out, const double* volumes, double dt, void* stream) {
+  return t8gpu_hip::subgrid_fused_stage<double>(kind, stage, plan, prev, mid, out, volumes, dt, stream);
+}
+}

@@ -1,0 +1,100 @@
+// subgrid_plan.cpp -- per-block face lists for the fused Subgrid kernels.
+//
+// The reference walks the coarse-face list from the FACE side (one CUDA block per coarse face,
+// atomicAdd into both neighbours, examples/subgrid/kernels.inl:664-911). The fused kernel works from
+// the BLOCK side: one wavefront owns one 4x4x4 block, evaluates every flux its subcells need and
+// applies the RK stage, so it needs, per block, the coarse faces that touch it and on which side.
+// Input = the reference-format arrays (face_neighbors, face_level_difference, face_neighbor_offset,
+// face_normals, face_surfaces); output:
+//   bf_off[N+1], bf_ent[]  : per owned block its faces (wall faces first, then interior faces in
+//                            original order); bit 31 set when the block is the face's RIGHT side
+//   face_rec[F+B][4]       : {left slot, right slot (-1: wall), code, 0} with
+//                            code = axis | positive<<2 | hanging<<3 | off0<<4 | off1<<6 | off2<<8
+// Normals must be exact +-unit axis vectors -- the reference's kernels require the same
+// (kernels.inl:717-750 select the face plane by comparing the normal with +-1.0).
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace {
+struct SubgridPlan {
+  int32_t N = 0, F = 0, B = 0, rank = 3, max_bf = 0;
+  std::vector<int32_t> bf_off, bf_ent, face_rec;
+};
+}  // namespace
+
+extern "C" {
+
+void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, const int32_t* fn,
+                                const int32_t* level_diff, const int32_t* nb_offset, const double* normals) {
+  if (N < 0 || F < 0 || B < 0 || (rank != 2 && rank != 3)) return nullptr;
+  SubgridPlan* P = new SubgridPlan;
+  P->N = N; P->F = F; P->B = B; P->rank = rank;
+  P->face_rec.assign(4 * (static_cast<size_t>(F) + B), 0);
+  std::vector<int32_t> cnt(static_cast<size_t>(N) + 1, 0);
+  for (int32_t f = 0; f < F + B; f++) {
+    int axis = -1, positive = 0;
+    for (int d = 0; d < rank; d++) {
+      const double c = normals[static_cast<size_t>(rank) * f + d];
+      if (c == 1.0 || c == -1.0) {
+        if (axis >= 0) { delete P; return nullptr; }
+        axis     = d;
+        positive = c > 0;
+      } else if (c != 0.0) {
+        delete P;
+        return nullptr;
+      }
+    }
+    if (axis < 0) { delete P; return nullptr; }
+    int32_t code = axis | (positive << 2);
+    int32_t l, r = -1;
+    if (f < F) {
+      l = fn[2 * static_cast<size_t>(f)];
+      r = fn[2 * static_cast<size_t>(f) + 1];
+      if (level_diff[f] != 0) code |= 1 << 3;
+      for (int d = 0; d < rank; d++) code |= (nb_offset[static_cast<size_t>(rank) * f + d] & 3) << (4 + 2 * d);
+    } else {
+      l = fn[2 * static_cast<size_t>(F) + (f - F)];
+    }
+    int32_t* rec = &P->face_rec[4 * static_cast<size_t>(f)];
+    rec[0] = l; rec[1] = r; rec[2] = code; rec[3] = 0;
+    if (l < N) cnt[l + 1]++;
+    if (r >= 0 && r < N && r != l) cnt[r + 1]++;
+  }
+  for (int32_t e = 0; e < N; e++) {
+    if (cnt[e + 1] > P->max_bf) P->max_bf = cnt[e + 1];
+    cnt[e + 1] += cnt[e];
+  }
+  P->bf_off = cnt;
+  P->bf_ent.assign(cnt[N], 0);
+  std::vector<int32_t> cur(cnt.begin(), cnt.end() - 1);
+  for (int32_t b = 0; b < B; b++) {                      // walls first (reference order: inner, boundary, outer)
+    const int32_t l = fn[2 * static_cast<size_t>(F) + b];
+    if (l < N) P->bf_ent[cur[l]++] = F + b;
+  }
+  for (int32_t f = 0; f < F; f++) {
+    const int32_t l = fn[2 * static_cast<size_t>(f)], r = fn[2 * static_cast<size_t>(f) + 1];
+    if (l < N) P->bf_ent[cur[l]++] = f;
+    if (r < N && r != l) P->bf_ent[cur[r]++] = f | static_cast<int32_t>(0x80000000u);
+  }
+  return P;
+}
+
+void t8gpu_plan_subgrid_destroy(void* h) { delete static_cast<SubgridPlan*>(h); }
+
+/* sizes[3] = {n_entries, max faces per block, F + B} */
+void t8gpu_plan_subgrid_sizes(const void* h, int64_t* sizes) {
+  const SubgridPlan* P = static_cast<const SubgridPlan*>(h);
+  sizes[0] = static_cast<int64_t>(P->bf_ent.size());
+  sizes[1] = P->max_bf;
+  sizes[2] = static_cast<int64_t>(P->F) + P->B;
+}
+
+void t8gpu_plan_subgrid_arrays(const void* h, int32_t* bf_off, int32_t* bf_ent, int32_t* face_rec) {
+  const SubgridPlan* P = static_cast<const SubgridPlan*>(h);
+  if (bf_off) std::memcpy(bf_off, P->bf_off.data(), P->bf_off.size() * sizeof(int32_t));
+  if (bf_ent && !P->bf_ent.empty()) std::memcpy(bf_ent, P->bf_ent.data(), P->bf_ent.size() * sizeof(int32_t));
+  if (face_rec && !P->face_rec.empty()) std::memcpy(face_rec, P->face_rec.data(), P->face_rec.size() * sizeof(int32_t));
+}
+
+}  // extern "C"

@@ -13,6 +13,7 @@
 //
 // Host-only: covered by the CPU test-suite through a numpy interpreter of the plan.
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -35,7 +36,7 @@ struct TilePlan {
   int32_t ell_width = 0;                               // padded per-element face-list width (multiple of 8)
   std::vector<uint16_t> ell;                           // [N][ell_width], 0xFFFF = padding
   std::vector<uint16_t> geo_idx;                       // per tile face: index into geo_table (empty if > 65535 distinct)
-  std::vector<double>   geo_table;                     // [n_geo][4]
+  std::vector<double>   geo_table;                     // [n_geo][12]: n, area, t1, 0, t2, 0
 };
 
 void build(TilePlan& P, const int32_t* fn, const double* normals, const double* areas) {
@@ -206,8 +207,22 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
     std::sort(uniq.begin(), uniq.end());
     uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
     if (uniq.size() <= 65535) {
-      P.geo_table.resize(uniq.size() * 4);
-      for (size_t i = 0; i < uniq.size(); i++) std::memcpy(&P.geo_table[4 * i], uniq[i].w, 32);
+      // table row = {nx, ny, nz, area, t1x, t1y, t1z, 0, t2x, t2y, t2z, 0}: the face frame (the reference
+      // rebuilds it per face and stage, kernels.cu:174-193) is computed once per distinct normal
+      P.geo_table.assign(uniq.size() * 12, 0.0);
+      for (size_t i = 0; i < uniq.size(); i++) {
+        double* row = &P.geo_table[12 * i];
+        std::memcpy(row, uniq[i].w, 32);
+        const double* n = row;
+        double t1[3] = {n[1], n[2], -n[0]};
+        const double dp = n[0] * t1[0] + n[1] * t1[1] + n[2] * t1[2];
+        for (int k = 0; k < 3; k++) t1[k] -= dp * n[k];
+        const double nrm = std::sqrt(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]);
+        for (int k = 0; k < 3; k++) row[4 + k] = t1[k] / nrm;
+        row[8]  = n[1] * row[6] - n[2] * row[5];
+        row[9]  = n[2] * row[4] - n[0] * row[6];
+        row[10] = n[0] * row[5] - n[1] * row[4];
+      }
       P.geo_idx.resize(nfaces);
       for (size_t f = 0; f < nfaces; f++)
         P.geo_idx[f] = static_cast<uint16_t>(std::lower_bound(uniq.begin(), uniq.end(), keys[f]) - uniq.begin());
@@ -250,7 +265,7 @@ void t8gpu_plan_plain_sizes(const void* h, int64_t* sizes) {
   sizes[8] = P->N;
   sizes[9] = P->F;
   sizes[10] = P->ell_width;
-  sizes[11] = static_cast<int64_t>(P->geo_table.size() / 4);
+  sizes[11] = static_cast<int64_t>(P->geo_table.size() / 12);
 }
 
 void t8gpu_plan_plain_compressed(const void* h, uint16_t* ell, uint16_t* geo_idx, double* geo_table) {

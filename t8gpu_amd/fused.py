@@ -56,3 +56,39 @@ class PlainPlan:
                  solver.get_own_variables(solver.prev), solver.get_own_variables(src), solver.get_own_variables(dst),
                  hip.ptr(solver.planes[25]), hip.fscalar(self.dtype, dt), hip.ptr(solver.speed), stream)
         _timer_end(solver, ev)
+
+
+class T8gpuSubgridPlan(C.Structure):
+    _fields_ = [("bf_off", C.c_void_p), ("bf_ent", C.c_void_p), ("face_rec", C.c_void_p), ("face_surfaces", C.c_void_p),
+                ("num_elements", C.c_int32), ("rank", C.c_int32), ("max_faces_per_block", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SubgridPlan:
+    """Device copy of the per-block face lists for the fused Subgrid<4,4,4> kernel."""
+
+    def __init__(self, part, dtype):
+        from .plan import HostSubgridPlan
+        if part.mesh.dim != 3:
+            raise NotImplementedError("the fused block kernel covers Subgrid<4,4,4>; Subgrid<4,4> runs on the compat kernels")
+        self.host = HostSubgridPlan(part)
+        self.dtype = dtype
+        npf = np.float32 if dtype == torch.float32 else np.float64
+        self._keep = {
+            "bf_off": torch.from_numpy(self.host.bf_off).cuda(),
+            "bf_ent": torch.from_numpy(self.host.bf_ent if self.host.bf_ent.size else np.zeros(1, np.int32)).cuda(),
+            "face_rec": torch.from_numpy(self.host.face_rec if self.host.face_rec.size else np.zeros((1, 4), np.int32)).cuda(),
+            "face_surfaces": torch.from_numpy(np.ascontiguousarray(part.areas if part.areas.size else np.zeros(1), npf)).cuda(),
+        }
+        c = T8gpuSubgridPlan()
+        for k, t in self._keep.items():
+            setattr(c, k, t.data_ptr())
+        c.num_elements, c.rank, c.max_faces_per_block = part.N, 3, self.host.max_bf
+        self.c = c
+
+    def stage(self, solver, stage, src, dst, dt, stream):
+        from .solver import _timer_begin, _timer_end
+        ev = _timer_begin(solver)
+        hip.call("t8gpu_hip_subgrid_fused_stage", self.dtype, solver.kind, stage, C.byref(self.c),
+                 solver.get_own_variables(solver.prev), solver.get_own_variables(src), solver.get_own_variables(dst),
+                 hip.ptr(solver.volumes), hip.fscalar(self.dtype, dt), stream)
+        _timer_end(solver, ev)

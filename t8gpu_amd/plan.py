@@ -58,7 +58,7 @@ class HostPlainPlan:
             self.ell_width, n_geo = int(sz[10]), int(sz[11])
             self.ell = np.zeros((N, self.ell_width), np.uint16)
             self.geo_idx = np.zeros(n_faces if n_geo else 0, np.uint16)
-            self.geo_table = np.zeros((n_geo, 4), np.float64)
+            self.geo_table = np.zeros((n_geo, 12), np.float64)
             lib.t8gpu_plan_plain_compressed(h, p(self.ell), p(self.geo_idx) if n_geo else None,
                                             p(self.geo_table) if n_geo else None)
         finally:
@@ -67,3 +67,33 @@ class HostPlainPlan:
     @classmethod
     def from_partition(cls, part, **kw):
         return cls(part.N, part.G, part.F, part.B, part.normal_dim, part.face_neighbors, part.normals, part.areas, **kw)
+
+
+class HostSubgridPlan:
+    """Host arrays of the per-block face lists (see include/t8gpu_hip.h, T8gpuSubgridPlan)."""
+
+    def __init__(self, part):
+        assert part.subgrid
+        lib = _synth.lib()
+        lib.t8gpu_plan_subgrid_create.restype = C.c_void_p
+        lib.t8gpu_plan_subgrid_create.argtypes = [C.c_int32] * 4 + [C.c_void_p] * 4
+        lib.t8gpu_plan_subgrid_destroy.argtypes = [C.c_void_p]
+        lib.t8gpu_plan_subgrid_sizes.argtypes = [C.c_void_p, C.c_void_p]
+        lib.t8gpu_plan_subgrid_arrays.argtypes = [C.c_void_p] * 4
+        p = _synth._p
+        rank = part.mesh.dim
+        fn = np.ascontiguousarray(part.face_neighbors, np.int32)
+        nr = np.ascontiguousarray(part.normals, np.float64)
+        h = lib.t8gpu_plan_subgrid_create(part.N, part.F, part.B, rank, p(fn), p(part.level_diff), p(part.nb_offset), p(nr))
+        if not h:
+            raise ValueError("subgrid plan needs axis-aligned unit normals (as the reference's subgrid kernels do)")
+        try:
+            sz = np.zeros(3, np.int64)
+            lib.t8gpu_plan_subgrid_sizes(h, p(sz))
+            self.N, self.rank, self.max_bf = part.N, rank, int(sz[1])
+            self.bf_off = np.zeros(part.N + 1, np.int32)
+            self.bf_ent = np.zeros(int(sz[0]), np.int32)
+            self.face_rec = np.zeros((int(sz[2]), 4), np.int32)
+            lib.t8gpu_plan_subgrid_arrays(h, p(self.bf_off), p(self.bf_ent), p(self.face_rec))
+        finally:
+            lib.t8gpu_plan_subgrid_destroy(h)
