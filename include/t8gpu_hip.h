@@ -224,6 +224,23 @@ int t8gpu_hip_subgrid_fused_stage_f64(int flux_kind, int stage, const T8gpuSubgr
                                       T8gpuVars_f64 mid, T8gpuVars_f64 out, const double* volumes, double delta_t,
                                       void* stream);
 
+/* ---- scalar reductions next to the hot path -------------------------------------------
+ * Device-side replacements of the two host round trips of the reference solvers; results are device
+ * scalars (double) written on `stream`; `workspace` = t8gpu_hip_reduce_workspace_bytes() device bytes.
+ * Fixed reduction tree, no atomics: bitwise reproducible. */
+size_t t8gpu_hip_reduce_workspace_bytes(void);
+/* max over the per-face speed estimates: thrust::reduce(..., maximum) in compute_timestep,
+ * examples/compressible_euler/solver.cu:213-217 (the caller all-reduces the scalar across ranks, :218-223,
+ * and forms dt = cfl * 0.5^max_level / speed, :225-228). */
+int t8gpu_hip_max_speed_f32(size_t n, const float* speed_estimates, void* workspace, double* result, void* stream);
+int t8gpu_hip_max_speed_f64(size_t n, const double* speed_estimates, void* workspace, double* result, void* stream);
+/* sum of volume * variable over the owned cells: compute_integral, solver.cu:190-211; with
+ * cells_per_element = Subgrid::size the per-cell volume is volume[e] / size (examples/subgrid/solver.inl:295-297). */
+int t8gpu_hip_integral_f32(size_t num_cells, int cells_per_element, const float* variable, const float* volume,
+                           void* workspace, double* result, void* stream);
+int t8gpu_hip_integral_f64(size_t num_cells, int cells_per_element, const double* variable, const double* volume,
+                           void* workspace, double* result, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,16 @@ def main(out):
         f = fs[0] / fs[1] if fs[1] else 0.0
         w = ws[0] / ws[1] if ws[1] else 0.0
         print(f"| {k} | {f:.0f} | {2 * f * 1024 / 1e6:.1f} | {w:.0f} | {w * 1024 / 1e6:.1f} | {(2 * f + w) * 1024 / 1e6:.1f} |")
+    # machine-readable traffic per launch of the dominant kernel family (bench.py reports it as roofline.traffic)
+    dom = [k for k in sorted(set(fetch) | set(write)) if k.startswith(("k_plain_fused", "k_subgrid444_fused", "k_flux_faces", "k_subgrid_inner"))]
+    if dom:
+        tot = 0.0
+        for k in dom:
+            fs, ws = fetch[k]["FETCH_SIZE"], write[k]["WRITE_SIZE"]
+            tot += (2 * (fs[0] / fs[1] if fs[1] else 0.0) + (ws[0] / ws[1] if ws[1] else 0.0)) * 1024
+        with open(os.path.join(out, "traffic.json"), "w") as fjs:
+            json.dump({"kernels": dom, "avg_hbm_bytes_per_launch": tot / len(dom),
+                       "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 (gfx950), KiB -> bytes"}, fjs)
     print("\n## SQ counters per launch (averages)\n")
     names = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
              "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]

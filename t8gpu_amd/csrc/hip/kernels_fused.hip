@@ -160,17 +160,20 @@ __global__ __launch_bounds__(256) void k_plain_fused(T8gpuPlainPlan P, int tile_
 // The generic kernel above exposes three dependent memory latencies per tile (one per phase); here
 // they overlap, and the own state stays in registers for the RK stage. Needs tiles of <= 256 elements,
 // <= 512 own+halo elements and <= 512 faces (tile_plan.cpp guarantees it with the default caps).
+// Adds the entries of one ELL chunk whose face lies in pass `pass` (faces [256*pass, 256*pass+256) of the
+// tile are in the LDS flux buffer during that pass). Entries are in ascending face order, so visiting
+// pass 0 then pass 1 keeps the summation order of the single-pass form.
 template <class T>
-T8_DEV void ell_accumulate(uint4 w, const T* __restrict__ ff, int LF, T acc[5], bool& done) {
+T8_DEV void ell_accumulate(uint4 w, int pass, const T* __restrict__ ff, T acc[5], bool& done) {
   const unsigned ent[8] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     if (ent[j] == 0xFFFFu) done = true;
-    if (!done) {
-      const int f   = ent[j] & 0x7FFFu;
-      const T   sgn = (ent[j] & 0x8000u) ? T(1) : T(-1);
+    const int f = ent[j] & 0x7FFFu;
+    if (!done && (f >> 8) == pass) {
+      const T sgn = (ent[j] & 0x8000u) ? T(1) : T(-1);
 #pragma unroll
-      for (int k = 0; k < 5; k++) acc[k] += sgn * ff[k * LF + f];
+      for (int k = 0; k < 5; k++) acc[k] += sgn * ff[k * 256 + (f & 255)];
     }
   }
 }
@@ -204,9 +207,8 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
   T* const      lds = reinterpret_cast<T*>(lds_raw);
   constexpr int NW  = KIND == 0 ? kPrimWords : 5;
   const int     LE  = P.max_elems + P.max_halo;
-  const int     LF  = P.max_faces;
   T* const      pe  = lds;
-  T* const      ff  = lds + (size_t)NW * LE;
+  T* const      ff  = lds + (size_t)NW * LE;  // [5][256]: one pass of 256 faces at a time
 
   const int tile = P.tile_order[tile_begin + xcd_position(blockIdx.x, gridDim.x)];
   const int e0 = P.elem_off[tile], ne = P.elem_off[tile + 1] - e0;
@@ -275,14 +277,15 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
   }
   __syncthreads();
 
-  // ---- phase 2 -----------------------------------------------------------------------------------
+  // ---- phases 2 + 3, one pass of 256 faces at a time (halves the LDS flux buffer -> 4 workgroups/CU) ---
+  T acc[5] = {T(0), T(0), T(0), T(0), T(0)};
 #pragma unroll
   for (int it = 0; it < 2; it++) {
     const bool     valid = it == 0 ? va : vb;
     const uint32_t lr    = it == 0 ? lra : lrb;
     const V4       gm    = it == 0 ? gma : gmb;
     const int      orig  = it == 0 ? oa : ob;
-    const int      f     = it == 0 ? tid : fb;
+    if (it == 1 && nf <= 256) break;
     if (valid) {
       const int  l = lr & 0xFFFFu, r16 = lr >> 16;
       const bool wall = r16 == 0xFFFFu;
@@ -316,17 +319,19 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
         from_face_frame<T>(n, t1, t2, Ff, g);
       }
 #pragma unroll
-      for (int k = 0; k < 5; k++) ff[k * LF + f] = g[k];
+      for (int k = 0; k < 5; k++) ff[k * 256 + tid] = g[k];
     }
+    __syncthreads();
+    if (own) {
+      bool done = false;
+      ell_accumulate<T>(ell0, it, ff, acc, done);
+      for (int c = 1; c < P.ell_width / 8 && !done; c++) ell_accumulate<T>(ellrow[c], it, ff, acc, done);
+    }
+    if (it == 0 && nf > 256) __syncthreads();   // the buffer is rewritten by the second pass
   }
-  __syncthreads();
 
-  // ---- phase 3 -----------------------------------------------------------------------------------
+  // ---- RK stage (ssp_runge_kutta.inl:30-99) ---------------------------------------------------------
   if (own) {
-    T    acc[5] = {T(0), T(0), T(0), T(0), T(0)};
-    bool done = false;
-    ell_accumulate<T>(ell0, ff, LF, acc, done);
-    for (int c = 1; c < P.ell_width / 8 && !done; c++) ell_accumulate<T>(ellrow[c], ff, LF, acc, done);
     const T scale = dt / volume;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
@@ -357,13 +362,13 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
   if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > plan->ntiles) return static_cast<int>(hipErrorInvalidValue);
   if (plan->max_elems > 256 * 4) return static_cast<int>(hipErrorInvalidValue);
   if (tile_count == 0) return 0;
-  const int    nw  = kind == 0 ? kPrimWords : 5;
-  const size_t lds = sizeof(T) * ((size_t)nw * (plan->max_elems + plan->max_halo) + (size_t)5 * plan->max_faces);
-  if (lds > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int   nw = kind == 0 ? kPrimWords : 5;
+  hipStream_t s  = static_cast<hipStream_t>(stream);
   const dim3  grid(tile_count), block(256);
   const bool  pipelined = plan->ell && plan->ell_width >= 8 && plan->ell_width % 8 == 0 && plan->max_elems <= 256 &&
                          plan->max_elems + plan->max_halo <= 512 && plan->max_faces <= 512;
+  const size_t lds = sizeof(T) * ((size_t)nw * (plan->max_elems + plan->max_halo) + (size_t)5 * (pipelined ? 256 : plan->max_faces));
+  if (lds > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
   const bool  dict = pipelined && plan->geo_idx && plan->geo_table && plan->n_geo > 0;
 #define T8_LAUNCH(KERNEL)                                                                                    \
   do {                                                                                                       \

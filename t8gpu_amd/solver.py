@@ -95,6 +95,38 @@ class PlainSolver:
         hip.call("t8gpu_hip_rk3_stage", self.dtype, stage, self.N, self.get_own_variables(self.prev), st,
                  self.get_own_variables(dst), fl, hip.ptr(self.planes[25]), hip.fscalar(self.dtype, dt), stream)
 
+    # -- scalar diagnostics of the reference solver, computed on the device -----------------------
+    def _reduce_buffers(self):
+        if not hasattr(self, "_ws"):
+            n = hip.lib().t8gpu_hip_reduce_workspace_bytes
+            n.restype = C.c_size_t
+            self._ws = torch.zeros(n() // 8, dtype=torch.float64, device="cuda")
+            self._scalar = torch.zeros(1, dtype=torch.float64, device="cuda")
+        return self._ws, self._scalar
+
+    def compute_integral(self, variable=0, step=None):
+        """sum(volume * variable) over the owned elements (CompressibleEulerSolver::compute_integral)."""
+        ws, res = self._reduce_buffers()
+        s = self.next if step is None else step
+        hip.call("t8gpu_hip_integral", self.dtype, C.c_size_t(self.N), 1, hip.ptr(self.planes[5 * s + variable]),
+                 hip.ptr(self.planes[25]), hip.ptr(ws), hip.ptr(res), hip.stream_ptr())
+        return float(res.item())
+
+    def max_speed(self):
+        """max of the per-face wave-speed estimates of the last stage (input of compute_timestep)."""
+        ws, res = self._reduce_buffers()
+        hip.call("t8gpu_hip_max_speed", self.dtype, C.c_size_t(self.F + self.B), hip.ptr(self.speed), hip.ptr(ws),
+                 hip.ptr(res), hip.stream_ptr())
+        return float(res.item())
+
+    def compute_timestep(self, cfl=0.7, max_level=None, dist=None):
+        """cfl * 0.5^max_level / max speed (solver.cu:213-229); `dist` all-reduces the maximum over ranks."""
+        speed = torch.tensor([self.max_speed()], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(speed, op=dist.ReduceOp.MAX)
+        level = self.part.mesh.finest_level if max_level is None else max_level
+        return cfl * 0.5 ** level / float(speed.item())
+
     def begin_step(self):
         self.next, self.prev = self.prev, self.next  # solver.cu:76
 
