@@ -177,8 +177,10 @@ def main():
             per_launch = local_cells * flux_stage
             kname = "flux_faces" if w["kind"] == "plain" else "subgrid_inner+outer"
         achieved = per_launch / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(args.workload, dts, args.flux, mode, world)
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": int(per_launch), "launches_timed": kernel_launches}
         if kernel_launches != 3 * args.steps:
             roof["note"] = "stage kernel split into interior + ghost-reading tile ranges; avg_launch_ms is their sum per stage"
@@ -208,6 +210,20 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(workload, dts, flux, mode, world):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json, written by scripts/profile_gpu.sh for exactly this workload / dtype / flux /
+    kernel tier at N = 1); None when no matching profile is committed."""
+    if world != 1:
+        return None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            rec = json.load(f).get(f"{workload}|{dts}|{flux}|{mode}")
+        return (rec["hbm_bytes_per_launch"], rec["source"]) if rec else (None, None)
+    except (OSError, ValueError, KeyError):
+        return None, None
 
 
 def make_native_halo(part, tdtype, solver, torch_halo, dist, rank, world):
