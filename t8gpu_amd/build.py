@@ -56,7 +56,7 @@ def build_hip(force=False):
     if force or _newer(HIP_LIB, deps):
         os.makedirs(LIB, exist_ok=True)
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        _run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-shared", "-munsafe-fp-atomics",
+        _run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-shared", "-munsafe-fp-atomics", "-fno-slp-vectorize",
               "-I", os.path.join(ROOT, "include"), "-I", os.path.join(CSRC, "hip"),
               "-Wall", "-Wno-unused-function", "-o", HIP_LIB] + srcs + ["-L/opt/rocm/lib", "-lrccl"])
     return HIP_LIB

@@ -255,6 +255,17 @@ T8_DEV double t8_rcp(double x) {
   r        = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
   return r;
 }
+// sqrt for the fast tier: fp64 v_rsq_f64 + Goldschmidt step + residual (x > 0, normal range)
+T8_DEV float  t8_sqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }
+T8_DEV double t8_sqrt_fast(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double       g = x * y, h = 0.5 * y;
+  double       r = __builtin_fma(-h, g, 0.5);
+  g              = __builtin_fma(g, r, g);
+  h              = __builtin_fma(h, r, h);
+  const double d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+}
 T8_DEV float  t8_div(float a, float b) { return a * t8_rcp(b); }
 T8_DEV double t8_div(double a, double b) {
   const double r = t8_rcp(b);
@@ -336,7 +347,7 @@ T8_DEV void kepes_prim(const Prim<T>& L, const Prim<T>& R, bool mirror, const T 
   const T ib   = t8_rcp(bhat);
   const T rho_mean = half * (L.rho + R.rho);
   const T u = half * (uL + uR), v = half * (vL + vR), w = half * (wL + wR);
-  const T a  = t8_sqrt(t8_div(kappa * half * (L.p + R.p), rho));
+  const T a  = t8_sqrt_fast(t8_div(kappa * half * (L.p + R.p), rho));
   const T h  = (kappa / (T(2) * km1)) * ib + half * (uL * uR + vL * vR + wL * wR);
   const T p1 = t8_div(rho_mean, L.beta + R.beta);
   const T q2 = qL + qR;
@@ -381,6 +392,45 @@ T8_DEV void kepes_prim(const Prim<T>& L, const Prim<T>& R, bool mirror, const T 
   g[2] = f1 * n[1] + f2 * t1[1] + f3 * t2[1];
   g[3] = f1 * n[2] + f2 * t1[2] + f3 * t2[2];
   g[4] = f4;
+}
+
+// HLL for the fast tier: the formulas of hll_ref (examples/subgrid/kernels.inl:263-332) with shared
+// reciprocals and the fast division above; takes the states already rotated into the face frame.
+template <class T>
+T8_DEV void hll_fast(const T uL[5], const T uR[5], T F[5]) {
+  const T zero = T(0), one = T(1), half = T(0.5);
+  const T gm1 = T(1.4) - one;
+  const T irl = t8_rcp(uL[0]), irr = t8_rcp(uR[0]);
+  const T v1l = uL[1] * irl, v2l = uL[2] * irl, v3l = uL[3] * irl;
+  const T v1r = uR[1] * irr, v2r = uR[2] * irr, v3r = uR[3] * irr;
+  const T kl = half * (v1l * v1l + v2l * v2l + v3l * v3l), kr = half * (v1r * v1r + v2r * v2r + v3r * v3r);
+  const T pl = gm1 * (uL[4] - uL[0] * kl), pr = gm1 * (uR[4] - uR[0] * kr);
+  const T Hl = (uL[4] + pl) * irl, Hr = (uR[4] + pr) * irr;
+  const T cl = t8_sqrt_fast(gm1 * (Hl - kl)), cr = t8_sqrt_fast(gm1 * (Hr - kr));
+  const T wl = t8_sqrt_fast(uL[0]), wr = t8_sqrt_fast(uR[0]);
+  const T iw = t8_rcp(wl + wr);
+  const T v1 = (wl * v1l + wr * v1r) * iw, v2 = (wl * v2l + wr * v2r) * iw, v3 = (wl * v3l + wr * v3r) * iw;
+  const T H  = (wl * Hl + wr * Hr) * iw;
+  const T c  = t8_sqrt_fast(gm1 * (H - half * (v1 * v1 + v2 * v2 + v3 * v3)));
+  const T sl = t8_min(t8_min(v1 - c, v1l - cl), zero);
+  const T sr = t8_max(t8_max(v1 + c, v1r + cr), zero);
+  const T Fl[5] = {uL[1], uL[1] * v1l + pl, uL[1] * v2l, uL[1] * v3l, uL[1] * Hl};
+  const T Fr[5] = {uR[1], uR[1] * v1r + pr, uR[1] * v2r, uR[1] * v3r, uR[1] * Hr};
+  const T id = t8_rcp(sr - sl);
+#pragma unroll
+  for (int k = 0; k < 5; k++) F[k] = ((sr * Fl[k] - sl * Fr[k]) + sr * sl * (uR[k] - uL[k])) * id;
+}
+
+// face-frame HLL flux of an xyz state pair, scaled by `area`, rotated back to xyz (fast tier)
+template <class T>
+T8_DEV void hll_face(const T sL[5], const T sR[5], bool mirror, const T n[3], const T t1[3], const T t2[3], T area, T g[5]) {
+  T a[5], b[5], Ff[5];
+  to_face_frame<T>(n, t1, t2, sL, a, false);
+  to_face_frame<T>(n, t1, t2, mirror ? sL : sR, b, mirror);
+  hll_fast<T>(a, b, Ff);
+#pragma unroll
+  for (int k = 0; k < 5; k++) Ff[k] = area * Ff[k];
+  from_face_frame<T>(n, t1, t2, Ff, g);
 }
 
 }  // namespace t8gpu_hip

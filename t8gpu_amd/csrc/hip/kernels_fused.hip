@@ -105,16 +105,13 @@ __global__ __launch_bounds__(256) void k_plain_fused(T8gpuPlainPlan P, int tile_
         if (orig >= 0) speed[orig] = spd;
       }
     } else {
-      T sl[5], sr[5], Ff[5];
+      T sl[5], sr[5];
 #pragma unroll
       for (int k = 0; k < 5; k++) {
         sl[k] = pe[k * LE + l];
         sr[k] = pe[k * LE + r];
       }
-      face_frame_flux_ref<T, 1>(n, t1, t2, sl, sr, wall, Ff, spd);
-#pragma unroll
-      for (int k = 0; k < 5; k++) Ff[k] = gm.w * Ff[k];
-      from_face_frame<T>(n, t1, t2, Ff, g);
+      hll_face<T>(sl, sr, wall, n, t1, t2, gm.w, g);
     }
 #pragma unroll
     for (int k = 0; k < 5; k++) ff[k * LF + f] = g[k];
@@ -169,11 +166,14 @@ T8_DEV void ell_accumulate(uint4 w, int pass, const T* __restrict__ ff, T acc[5]
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     if (ent[j] == 0xFFFFu) done = true;
-    const int f = ent[j] & 0x7FFFu;
-    if (!done && (f >> 8) == pass) {
-      const T sgn = (ent[j] & 0x8000u) ? T(1) : T(-1);
+    const int  f      = ent[j] & 0x7FFFu;
+    const bool active = !done && (f >> 8) == pass;
+    if (__any(active)) {  // wave-uniform skip: padding slots and the other pass cost nothing
+      // inactive lanes read slot 0 (always written in the current pass) with weight 0: one FMA per value
+      const int idx = active ? (f & 255) : 0;
+      const T   wgt = active ? ((ent[j] & 0x8000u) ? T(1) : T(-1)) : T(0);
 #pragma unroll
-      for (int k = 0; k < 5; k++) acc[k] += sgn * ff[k * 256 + (f & 255)];
+      for (int k = 0; k < 5; k++) acc[k] = __builtin_fma(wgt, ff[k * 256 + idx], acc[k]);
     }
   }
 }
@@ -230,14 +230,11 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
   const bool     va = tid < nf, vb = fb < nf;
   const uint32_t lra = P.face_lr[f0 + (va ? tid : 0)];
   const uint32_t lrb = P.face_lr[f0 + (vb ? fb : 0)];
-  V4             gma, gmb;
+  V4             gma = {}, gmb = {};
   int            gia = 0, gib = 0;
-  if (DICT) {
-    const V4* __restrict__ tab = reinterpret_cast<const V4*>(P.geo_table);
+  if (DICT) {  // only the 2-byte row index travels with the face; the (cache-resident) row is read in phase 2
     gia = 3 * P.geo_idx[f0 + (va ? tid : 0)];
     gib = 3 * P.geo_idx[f0 + (vb ? fb : 0)];
-    gma = tab[gia];
-    gmb = tab[gib];
   } else {
     const V4* __restrict__ geo = reinterpret_cast<const V4*>(P.face_geo) + f0;
     gma = geo[va ? tid : 0];
@@ -249,12 +246,7 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
     ob = P.face_orig[f0 + (vb ? fb : 0)];
   }
   const int e = e0 + (own ? tid : 0);
-  T         pv[5];
-  if (STAGE > 1) {
-#pragma unroll
-    for (int k = 0; k < 5; k++) pv[k] = prev.p[k][e];
-  }
-  const T     volume = vol[e];
+  T         pv[5] = {T(0), T(0), T(0), T(0), T(0)}, volume = T(1);   // fetched behind the last flux pass (register budget)
   const uint4* __restrict__ ellrow = reinterpret_cast<const uint4*>(P.ell + (size_t)e * P.ell_width);
   const uint4 ell0 = ellrow[0];
 
@@ -283,10 +275,10 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
   for (int it = 0; it < 2; it++) {
     const bool     valid = it == 0 ? va : vb;
     const uint32_t lr    = it == 0 ? lra : lrb;
-    const V4       gm    = it == 0 ? gma : gmb;
     const int      orig  = it == 0 ? oa : ob;
     if (it == 1 && nf <= 256) break;
     if (valid) {
+      const V4 gm = DICT ? reinterpret_cast<const V4*>(P.geo_table)[it == 0 ? gia : gib] : (it == 0 ? gma : gmb);
       const int  l = lr & 0xFFFFu, r16 = lr >> 16;
       const bool wall = r16 == 0xFFFFu;
       const int  r = wall ? l : r16;
@@ -307,19 +299,23 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
         kepes_prim<T>(L, R, wall, n, t1, t2, gm.w, g, spd);
         if (orig >= 0) speed[orig] = spd;
       } else {
-        T sl[5], sr[5], Ff[5];
+        T sl[5], sr[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) {
           sl[k] = pe[k * LE + l];
           sr[k] = pe[k * LE + r];
         }
-        face_frame_flux_ref<T, 1>(n, t1, t2, sl, sr, wall, Ff, spd);
-#pragma unroll
-        for (int k = 0; k < 5; k++) Ff[k] = gm.w * Ff[k];
-        from_face_frame<T>(n, t1, t2, Ff, g);
+        hll_face<T>(sl, sr, wall, n, t1, t2, gm.w, g);
       }
 #pragma unroll
       for (int k = 0; k < 5; k++) ff[k * 256 + tid] = g[k];
+    }
+    if (it == 1 || nf <= 256) {  // last pass: start the RK stage's loads; they fly during the barrier + gather
+      if (STAGE > 1) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) pv[k] = prev.p[k][e];
+      }
+      volume = vol[e];
     }
     __syncthreads();
     if (own) {

@@ -76,11 +76,7 @@ T8_DEV void cell_flux(const CellData<T, KIND>& L, const CellData<T, KIND>& R, bo
     b.rho = R.v[0]; b.vx = R.v[1]; b.vy = R.v[2]; b.vz = R.v[3]; b.p = R.v[4]; b.beta = R.v[5]; b.lrho = R.v[6]; b.lbeta = R.v[7]; b.v0 = R.v[8];
     kepes_prim<T>(a, b, wall, n, t1, t2, area, g, spd);
   } else {
-    T Ff[5], q[5];
-    face_frame_flux_ref<T, 1>(n, t1, t2, L.v, R.v, wall, Ff, spd);
-    from_face_frame<T>(n, t1, t2, Ff, q);
-#pragma unroll
-    for (int k = 0; k < 5; k++) g[k] = q[k] * area;
+    hll_face<T>(L.v, R.v, wall, n, t1, t2, area, g);
   }
 }
 
