@@ -210,8 +210,10 @@ int t8gpu_hip_plain_stepper_elapsed(void* stepper, double* total_ms, int* launch
  * share it) and applies the RK stage; the Fluxes planes are neither read nor written. The plan is the
  * per-block face list built by t8gpu_plan_subgrid_create() (csrc/host/subgrid_plan.cpp). */
 typedef struct T8gpuSubgridPlan {
+  const int32_t* plus;          /* [num_elements][3] face on the block's +x/+y/+z side that is folded into the
+                                   inner passes (bit 31: block is the RIGHT side), -1 = none             */
   const int32_t* bf_off;        /* [num_elements+1] into bf_ent                                         */
-  const int32_t* bf_ent;        /* face index (bit 31: the block is the face's RIGHT side); walls first */
+  const int32_t* bf_ent;        /* remaining faces (bit 31: the block is the face's RIGHT side); walls first */
   const int32_t* face_rec;      /* [F+B][4] = left slot, right slot (-1 wall), code, 0 (16-byte aligned) */
   const void*    face_surfaces; /* float_type [F+B], the reference's face_surfaces array                 */
   int32_t num_elements, rank, max_faces_per_block, reserved;

@@ -5,11 +5,14 @@
 // (up to 6 read-modify-writes per cell and variable in the inner kernel, 10 atomics per sub-face in the
 // outer one). Lane c owns subcell (i, j, k) = (c & 3, (c >> 2) & 3, c >> 4) of block blockIdx:
 //   1. own state -> per-cell primitives, registers + LDS (neighbours: lane +1 / +4 / +16);
-//   2. inner faces, x then y then z: lanes with coordinate < 3 evaluate the flux to their + neighbour,
-//      the wave exchanges it through LDS (-own, +lower, the reference's order);
-//   3. the block's coarse faces (walls first), four at a time: lane = (face slot, sub-face), the far
-//      side's subcell is gathered from the neighbour block (2:1 hanging map of kernels.inl:752-758), the
-//      sub-face fluxes go to LDS and every cell picks up the ones that end on it, in list order;
+//   2. + faces, x then y then z: EVERY lane evaluates the flux through its +d face. Lanes with coordinate
+//      < 3 have their + neighbour in the block (the wave exchanges the flux through LDS: -own, +lower);
+//      lanes with coordinate 3 sit on the block surface and take the far cell from the block on the +d
+//      side (same level, wall, or the coarser side of a hanging face: one sub-face per cell), so these
+//      passes run with all 64 lanes busy;
+//   3. the block's remaining coarse faces (-d sides, and faces towards finer blocks: 4 sub-faces per
+//      cell), four at a time: lane = (face slot, sub-face), far cell gathered through the 2:1 hanging
+//      map of kernels.inl:752-758, sub-face fluxes to LDS, every cell picks up the ones that end on it;
 //   4. RK stage on the accumulated flux, coalesced store.
 // An outer sub-face is evaluated by both blocks that share it (same arguments, same result), so there
 // are no atomics, no flux planes and the result is bitwise reproducible. The wave runs in lock-step,
@@ -31,18 +34,31 @@ T8_DEV int sg_xcd_position(int b, int nb) {
   return x * q + (x < rem ? x : rem) + k;
 }
 
+// Everything below is written with shifts instead of small arrays: a runtime-indexed per-lane array
+// would be placed in scratch memory.
 struct FaceCode {
-  int axis, positive, hanging, off[3];
+  int axis, positive, hanging, code;
+  T8_DEV int off(int a) const { return (code >> (4 + 2 * a)) & 3; }   // anchor inside the right block
+  T8_DEV int ta() const { return axis == 0 ? 1 : 0; }                  // tangential axes (i, j) of the sub-face grid
+  T8_DEV int tb() const { return axis == 2 ? 1 : 2; }
 };
 T8_DEV FaceCode decode(int code) {
   FaceCode f;
   f.axis     = code & 3;
   f.positive = (code >> 2) & 1;
   f.hanging  = (code >> 3) & 1;
-  f.off[0]   = (code >> 4) & 3;
-  f.off[1]   = (code >> 6) & 3;
-  f.off[2]   = (code >> 8) & 3;
+  f.code     = code;
   return f;
+}
+T8_DEV int cell_coord(int flat, int a) { return (flat >> (2 * a)) & 3; }   // flat = i + 4 j + 16 k
+T8_DEV int cell_stride(int a) { return 1 << (2 * a); }
+// left / right cell of sub-face (si, sj): kernels.inl:710-758
+T8_DEV int left_cell(const FaceCode& fc, int si, int sj) {
+  return (fc.positive ? 3 : 0) * cell_stride(fc.axis) + si * cell_stride(fc.ta()) + sj * cell_stride(fc.tb());
+}
+T8_DEV int right_cell(const FaceCode& fc, int si, int sj) {
+  return fc.off(fc.axis) * cell_stride(fc.axis) + (fc.off(fc.ta()) + (fc.hanging ? si / 2 : si)) * cell_stride(fc.ta()) +
+         (fc.off(fc.tb()) + (fc.hanging ? sj / 2 : sj)) * cell_stride(fc.tb());
 }
 
 template <class T, int KIND>
@@ -105,20 +121,46 @@ T8_DEV FaceLane<T> load_face_lane(const T8gpuSubgridPlan& P, const SVars<T>& src
     L.wall         = rec.y < 0;
     L.area         = reinterpret_cast<const T*>(P.face_surfaces)[fid];
     const FaceCode fc = decode(rec.z);
-    const int  ta = fc.axis == 0 ? 1 : 0, tb = fc.axis == 2 ? 1 : 2;
-    int        lc[3], rc[3];
-    lc[fc.axis] = fc.positive ? 3 : 0;
-    lc[ta]      = si;
-    lc[tb]      = sj;
-    rc[fc.axis] = fc.off[fc.axis];
-    rc[ta]      = fc.off[ta] + (fc.hanging ? si / 2 : si);
-    rc[tb]      = fc.off[tb] + (fc.hanging ? sj / 2 : sj);
-    const int lflat = lc[0] + 4 * lc[1] + 16 * lc[2], rflat = rc[0] + 4 * rc[1] + 16 * rc[2];
+    const int lflat = left_cell(fc, si, sj), rflat = right_cell(fc, si, sj);
     L.myflat   = L.right ? rflat : lflat;
     L.axis     = fc.axis;
     L.positive = fc.positive;
     if (!L.wall) {
       const size_t far = (size_t)(L.right ? rec.x : rec.y) * 64 + (L.right ? lflat : rflat);
+#pragma unroll
+      for (int k = 0; k < 5; k++) L.sf[k] = src.p[k][far];
+    }
+  }
+  return L;
+}
+
+// The +d coarse face of a block as seen by the surface lane with tangential coordinates (ti, tj).
+template <class T>
+struct PlusLane {
+  bool on, right, wall;
+  T    area, sf[5];
+};
+
+template <class T>
+T8_DEV PlusLane<T> load_plus_lane(const T8gpuSubgridPlan& P, const SVars<T>& src, int e, int d, bool surface_lane, int ti, int tj) {
+  PlusLane<T> L;
+  L.on = L.right = L.wall = false;
+  L.area = T(0);
+#pragma unroll
+  for (int k = 0; k < 5; k++) L.sf[k] = T(1);
+  const int ent = P.plus[(size_t)e * 3 + d];   // wave-uniform
+  if (ent != -1 && surface_lane) {
+    const int  fid = ent & 0x7FFFFFFF;
+    const int4 rec = reinterpret_cast<const int4*>(P.face_rec)[fid];
+    const FaceCode fc = decode(rec.z);
+    L.on    = true;
+    L.right = ent < 0;
+    L.wall  = rec.y < 0;
+    L.area  = reinterpret_cast<const T*>(P.face_surfaces)[fid];
+    if (!L.wall) {
+      // far cell: in the left block on its face plane, or in the right block at the stored anchor
+      const int    fcell = L.right ? left_cell(fc, ti, tj) : right_cell(fc, ti, tj);
+      const size_t far   = (size_t)(L.right ? rec.x : rec.y) * 64 + fcell;
 #pragma unroll
       for (int k = 0; k < 5; k++) L.sf[k] = src.p[k][far];
     }
@@ -134,7 +176,7 @@ __global__ __launch_bounds__(64) void k_subgrid444_fused(T8gpuSubgridPlan P, SVa
   __shared__ T  xb[5][64];   // flux exchange buffer (inner: per cell; outer: [slot * 16 + sub-face])
   const int    e = sg_xcd_position(blockIdx.x, gridDim.x);
   const int    c = threadIdx.x;
-  const int    cc[3] = {c & 3, (c >> 2) & 3, c >> 4};
+  const int    cc[3] = {c & 3, (c >> 2) & 3, c >> 4};   // only ever indexed with compile-time constants
   const size_t o = (size_t)e * 64 + c;
 
   T s0[5], pv[5];
@@ -150,11 +192,13 @@ __global__ __launch_bounds__(64) void k_subgrid444_fused(T8gpuSubgridPlan P, SVa
   const T   edge    = t8_cbrt(vol) / T(4);
   const T   surface = edge * edge;
 
-  // the first two outer passes (8 coarse faces: every block of a uniform region) are fetched NOW, so
-  // that their dependent loads (face list -> face record -> far cell) overlap the inner-face arithmetic
+  // the far cells of the three + faces and the first generic pass are fetched NOW, so that their
+  // dependent loads (face list -> face record -> far cell) overlap the arithmetic
   const int slot = c >> 4, sub = c & 15, si = sub & 3, sj = sub >> 2;
   const FaceLane<T> pre0 = load_face_lane<T>(P, src, b0, nbf, slot, si, sj);
-  const FaceLane<T> pre1 = load_face_lane<T>(P, src, b0, nbf, 4 + slot, si, sj);
+  const PlusLane<T> px = load_plus_lane<T>(P, src, e, 0, cc[0] == 3, cc[1], cc[2]);
+  const PlusLane<T> py = load_plus_lane<T>(P, src, e, 1, cc[1] == 3, cc[0], cc[2]);
+  const PlusLane<T> pz = load_plus_lane<T>(P, src, e, 2, cc[2] == 3, cc[0], cc[1]);
 
   const CellData<T, KIND> mine = cell_from_state<T, KIND>(s0);
 #pragma unroll
@@ -163,25 +207,39 @@ __global__ __launch_bounds__(64) void k_subgrid444_fused(T8gpuSubgridPlan P, SVa
 
   T acc[5] = {T(0), T(0), T(0), T(0), T(0)};
 
-  // ---- inner faces (kernels.inl:364-533) ---------------------------------------------------------
+  // ---- + faces: inner (kernels.inl:364-533) and, on the block surface, the +d coarse face ------------
 #pragma unroll
   for (int d = 0; d < 3; d++) {
-    const int str = d == 0 ? 1 : (d == 1 ? 4 : 16);
-    T         g[5] = {T(0), T(0), T(0), T(0), T(0)};
-    if (cc[d] < 3) {
-      CellData<T, KIND> nbr;
+    const int          str = d == 0 ? 1 : (d == 1 ? 4 : 16);
+    const PlusLane<T>& pl  = d == 0 ? px : (d == 1 ? py : pz);
+    const bool         inner = cc[d] < 3;
+    // operand selection first, ONE flux evaluation for all 64 lanes afterwards (no divergent flux code)
+    CellData<T, KIND> other = mine;
+    if (inner) {
 #pragma unroll
-      for (int w = 0; w < NW; w++) nbr.v[w] = pe[w][c + str];
-      cell_flux<T, KIND>(mine, nbr, false, d, true, surface, g);
+      for (int w = 0; w < NW; w++) other.v[w] = pe[w][c + str];
+    } else if (pl.on && !pl.wall) {
+      other = cell_from_state<T, KIND>(pl.sf);
     }
+    const bool flip = !inner && pl.right;           // stored orientation: left = far block, normal -e_d
+    const bool wall = !inner && pl.wall;
+    const T    ar   = inner ? surface : pl.area / T(16);
+    CellData<T, KIND> L, R;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      L.v[w] = flip ? other.v[w] : mine.v[w];
+      R.v[w] = flip ? mine.v[w] : other.v[w];
+    }
+    T g[5] = {T(0), T(0), T(0), T(0), T(0)};
+    if (inner || pl.on) cell_flux<T, KIND>(L, R, wall, d, !flip, ar, g);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 5; k++) xb[k][c] = g[k];
     __syncthreads();
-    if (cc[d] < 3) {
+    // own + face: leaves the cell, except where the cell is the RIGHT side of the stored face
+    const T sgn = flip ? T(1) : T(-1);
 #pragma unroll
-      for (int k = 0; k < 5; k++) acc[k] -= g[k];
-    }
+    for (int k = 0; k < 5; k++) acc[k] += sgn * g[k];
     if (cc[d] > 0) {
 #pragma unroll
       for (int k = 0; k < 5; k++) acc[k] += xb[k][c - str];
@@ -191,7 +249,7 @@ __global__ __launch_bounds__(64) void k_subgrid444_fused(T8gpuSubgridPlan P, SVa
   // ---- coarse faces of this block: walls (kernels.inl:913-1107), then outer faces (:664-802) -------
   for (int p0 = 0; p0 < nbf; p0 += 4) {
     T                 g[5] = {T(0), T(0), T(0), T(0), T(0)};
-    const FaceLane<T> fl = p0 == 0 ? pre0 : (p0 == 4 ? pre1 : load_face_lane<T>(P, src, b0, nbf, p0 + slot, si, sj));
+    const FaceLane<T> fl = p0 == 0 ? pre0 : load_face_lane<T>(P, src, b0, nbf, p0 + slot, si, sj);
     if (fl.active) {
       CellData<T, KIND> here;
 #pragma unroll
@@ -217,15 +275,15 @@ __global__ __launch_bounds__(64) void k_subgrid444_fused(T8gpuSubgridPlan P, SVa
       const int  fid   = ent & 0x7FFFFFFF;
       const bool right = ent < 0;
       const FaceCode fc = decode(reinterpret_cast<const int4*>(P.face_rec)[fid].z);
-      const int  ta = fc.axis == 0 ? 1 : 0, tb = fc.axis == 2 ? 1 : 2;
+      const int  ca = cell_coord(c, fc.axis), ci = cell_coord(c, fc.ta()), cj = cell_coord(c, fc.tb());
       if (!right) {
-        if (cc[fc.axis] == (fc.positive ? 3 : 0)) {
-          const int q = 16 * s + cc[ta] + 4 * cc[tb];
+        if (ca == (fc.positive ? 3 : 0)) {
+          const int q = 16 * s + ci + 4 * cj;
 #pragma unroll
           for (int k = 0; k < 5; k++) acc[k] -= xb[k][q];
         }
-      } else if (cc[fc.axis] == fc.off[fc.axis]) {
-        const int di = cc[ta] - fc.off[ta], dj = cc[tb] - fc.off[tb];
+      } else if (ca == fc.off(fc.axis)) {
+        const int di = ci - fc.off(fc.ta()), dj = cj - fc.off(fc.tb());
         if (!fc.hanging) {
           const int q = 16 * s + di + 4 * dj;
 #pragma unroll

@@ -6,7 +6,11 @@
 // applies the RK stage, so it needs, per block, the coarse faces that touch it and on which side.
 // Input = the reference-format arrays (face_neighbors, face_level_difference, face_neighbor_offset,
 // face_normals, face_surfaces); output:
-//   bf_off[N+1], bf_ent[]  : per owned block its faces (wall faces first, then interior faces in
+//   plus[N][rank]          : the coarse face on the block's +x/+y/+z side when each of the block's surface
+//                            cells sees exactly ONE sub-face of it (same level, wall, or the block is the
+//                            fine side of a hanging face): the kernel folds these into its inner-face passes;
+//                            -1 otherwise. Bit 31 = the block is the face's RIGHT side.
+//   bf_off[N+1], bf_ent[]  : per owned block its remaining faces (wall faces first, then interior faces in
 //                            original order); bit 31 set when the block is the face's RIGHT side
 //   face_rec[F+B][4]       : {left slot, right slot (-1: wall), code, 0} with
 //                            code = axis | positive<<2 | hanging<<3 | off0<<4 | off1<<6 | off2<<8
@@ -19,7 +23,7 @@
 namespace {
 struct SubgridPlan {
   int32_t N = 0, F = 0, B = 0, rank = 3, max_bf = 0;
-  std::vector<int32_t> bf_off, bf_ent, face_rec;
+  std::vector<int32_t> bf_off, bf_ent, face_rec, plus;
 };
 }  // namespace
 
@@ -58,8 +62,33 @@ void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, c
     }
     int32_t* rec = &P->face_rec[4 * static_cast<size_t>(f)];
     rec[0] = l; rec[1] = r; rec[2] = code; rec[3] = 0;
-    if (l < N) cnt[l + 1]++;
-    if (r >= 0 && r < N && r != l) cnt[r + 1]++;
+  }
+  // pass 1: which faces fold into the +side passes
+  P->plus.assign(static_cast<size_t>(N) * rank, -1);
+  std::vector<uint8_t> folded_l(static_cast<size_t>(F) + B, 0), folded_r(static_cast<size_t>(F) + B, 0);
+  for (int32_t f = 0; f < F + B; f++) {
+    const int32_t* rec = &P->face_rec[4 * static_cast<size_t>(f)];
+    const int32_t  l = rec[0], r = rec[1], code = rec[2];
+    const int      axis = code & 3, positive = (code >> 2) & 1, hanging = (code >> 3) & 1;
+    // left block: the face is on its +axis side iff the normal (outward from left) is positive
+    if (l < N && positive && P->plus[static_cast<size_t>(l) * rank + axis] < 0) {
+      P->plus[static_cast<size_t>(l) * rank + axis] = f;
+      folded_l[f] = 1;
+    }
+    // right block (never a wall, never finer than left): on ITS +axis side iff the normal is negative;
+    // foldable only at equal level (as the coarse side of a hanging face it sees 4 sub-faces per cell)
+    if (r >= 0 && r < N && r != l && !positive && !hanging && P->plus[static_cast<size_t>(r) * rank + axis] < 0) {
+      P->plus[static_cast<size_t>(r) * rank + axis] = f | static_cast<int32_t>(0x80000000u);
+      folded_r[f] = 1;
+    }
+  }
+  // pass 2: everything else goes to the generic per-block lists
+  std::fill(cnt.begin(), cnt.end(), 0);
+  for (int32_t f = 0; f < F + B; f++) {
+    const int32_t* rec = &P->face_rec[4 * static_cast<size_t>(f)];
+    const int32_t  l = rec[0], r = rec[1];
+    if (l < N && !folded_l[f]) cnt[l + 1]++;
+    if (r >= 0 && r < N && r != l && !folded_r[f]) cnt[r + 1]++;
   }
   for (int32_t e = 0; e < N; e++) {
     if (cnt[e + 1] > P->max_bf) P->max_bf = cnt[e + 1];
@@ -70,12 +99,12 @@ void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, c
   std::vector<int32_t> cur(cnt.begin(), cnt.end() - 1);
   for (int32_t b = 0; b < B; b++) {                      // walls first (reference order: inner, boundary, outer)
     const int32_t l = fn[2 * static_cast<size_t>(F) + b];
-    if (l < N) P->bf_ent[cur[l]++] = F + b;
+    if (l < N && !folded_l[F + b]) P->bf_ent[cur[l]++] = F + b;
   }
   for (int32_t f = 0; f < F; f++) {
     const int32_t l = fn[2 * static_cast<size_t>(f)], r = fn[2 * static_cast<size_t>(f) + 1];
-    if (l < N) P->bf_ent[cur[l]++] = f;
-    if (r < N && r != l) P->bf_ent[cur[r]++] = f | static_cast<int32_t>(0x80000000u);
+    if (l < N && !folded_l[f]) P->bf_ent[cur[l]++] = f;
+    if (r < N && r != l && !folded_r[f]) P->bf_ent[cur[r]++] = f | static_cast<int32_t>(0x80000000u);
   }
   return P;
 }
@@ -90,8 +119,9 @@ void t8gpu_plan_subgrid_sizes(const void* h, int64_t* sizes) {
   sizes[2] = static_cast<int64_t>(P->F) + P->B;
 }
 
-void t8gpu_plan_subgrid_arrays(const void* h, int32_t* bf_off, int32_t* bf_ent, int32_t* face_rec) {
+void t8gpu_plan_subgrid_arrays(const void* h, int32_t* bf_off, int32_t* bf_ent, int32_t* face_rec, int32_t* plus) {
   const SubgridPlan* P = static_cast<const SubgridPlan*>(h);
+  if (plus && !P->plus.empty()) std::memcpy(plus, P->plus.data(), P->plus.size() * sizeof(int32_t));
   if (bf_off) std::memcpy(bf_off, P->bf_off.data(), P->bf_off.size() * sizeof(int32_t));
   if (bf_ent && !P->bf_ent.empty()) std::memcpy(bf_ent, P->bf_ent.data(), P->bf_ent.size() * sizeof(int32_t));
   if (face_rec && !P->face_rec.empty()) std::memcpy(face_rec, P->face_rec.data(), P->face_rec.size() * sizeof(int32_t));

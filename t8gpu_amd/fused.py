@@ -59,7 +59,8 @@ class PlainPlan:
 
 
 class T8gpuSubgridPlan(C.Structure):
-    _fields_ = [("bf_off", C.c_void_p), ("bf_ent", C.c_void_p), ("face_rec", C.c_void_p), ("face_surfaces", C.c_void_p),
+    _fields_ = [("plus", C.c_void_p), ("bf_off", C.c_void_p), ("bf_ent", C.c_void_p), ("face_rec", C.c_void_p),
+                ("face_surfaces", C.c_void_p),
                 ("num_elements", C.c_int32), ("rank", C.c_int32), ("max_faces_per_block", C.c_int32), ("reserved", C.c_int32)]
 
 
@@ -74,6 +75,7 @@ class SubgridPlan:
         self.dtype = dtype
         npf = np.float32 if dtype == torch.float32 else np.float64
         self._keep = {
+            "plus": torch.from_numpy(self.host.plus if self.host.plus.size else np.full((1, 3), -1, np.int32)).cuda(),
             "bf_off": torch.from_numpy(self.host.bf_off).cuda(),
             "bf_ent": torch.from_numpy(self.host.bf_ent if self.host.bf_ent.size else np.zeros(1, np.int32)).cuda(),
             "face_rec": torch.from_numpy(self.host.face_rec if self.host.face_rec.size else np.zeros((1, 4), np.int32)).cuda(),

@@ -79,7 +79,7 @@ class HostSubgridPlan:
         lib.t8gpu_plan_subgrid_create.argtypes = [C.c_int32] * 4 + [C.c_void_p] * 4
         lib.t8gpu_plan_subgrid_destroy.argtypes = [C.c_void_p]
         lib.t8gpu_plan_subgrid_sizes.argtypes = [C.c_void_p, C.c_void_p]
-        lib.t8gpu_plan_subgrid_arrays.argtypes = [C.c_void_p] * 4
+        lib.t8gpu_plan_subgrid_arrays.argtypes = [C.c_void_p] * 5
         p = _synth._p
         rank = part.mesh.dim
         fn = np.ascontiguousarray(part.face_neighbors, np.int32)
@@ -94,6 +94,7 @@ class HostSubgridPlan:
             self.bf_off = np.zeros(part.N + 1, np.int32)
             self.bf_ent = np.zeros(int(sz[0]), np.int32)
             self.face_rec = np.zeros((int(sz[2]), 4), np.int32)
-            lib.t8gpu_plan_subgrid_arrays(h, p(self.bf_off), p(self.bf_ent), p(self.face_rec))
+            self.plus = np.zeros((part.N, rank), np.int32)
+            lib.t8gpu_plan_subgrid_arrays(h, p(self.bf_off), p(self.bf_ent), p(self.face_rec), p(self.plus))
         finally:
             lib.t8gpu_plan_subgrid_destroy(h)
