@@ -203,14 +203,14 @@ int t8gpu_hip_plain_stepper_iterate_f64(void* stepper, int flux_kind, double* pl
 int t8gpu_hip_plain_stepper_timing(void* stepper, int enable);
 int t8gpu_hip_plain_stepper_elapsed(void* stepper, double* total_ms, int* launches);
 
-/* ---- Subgrid<4,4,4>, fused block kernel ("fast" tier) ----------------------------------------------
+/* ---- Subgrid<4,4,4> and Subgrid<4,4>, fused block kernels ("fast" tier) -----------------------------
  * One launch per RK stage replaces compute_inner_fluxes + compute_boundary_fluxes + compute_outer_fluxes
  * + subgrid::SSP_3RK_stepK of that stage (examples/subgrid/solver.inl:166-195): one 64-lane wavefront per
- * 4x4x4 block evaluates every flux its subcells need (an outer sub-face is evaluated by both blocks that
+ * 4x4x4 block (or per four 4x4 blocks) evaluates every flux its subcells need (an outer sub-face is evaluated by both blocks that
  * share it) and applies the RK stage; the Fluxes planes are neither read nor written. The plan is the
  * per-block face list built by t8gpu_plan_subgrid_create() (csrc/host/subgrid_plan.cpp). */
 typedef struct T8gpuSubgridPlan {
-  const int32_t* plus;          /* [num_elements][3] face on the block's +x/+y/+z side that is folded into the
+  const int32_t* plus;          /* [num_elements][rank] face on the block's +x/+y/+z side that is folded into the
                                    inner passes (bit 31: block is the RIGHT side), -1 = none             */
   const int32_t* bf_off;        /* [num_elements+1] into bf_ent                                         */
   const int32_t* bf_ent;        /* remaining faces (bit 31: the block is the face's RIGHT side); walls first */

@@ -1,4 +1,5 @@
-// kernels_subgrid_fused.hip -- Subgrid<4,4,4>: one 64-lane wavefront = one block, one launch per RK stage.
+// kernels_subgrid_fused.hip -- Subgrid<4,4,4> (one 64-lane wavefront = one block) and Subgrid<4,4> (four
+// blocks per wavefront): one launch per RK stage.
 //
 // Replaces, per stage, compute_inner_fluxes + compute_boundary_fluxes + compute_outer_fluxes +
 // subgrid::SSP_3RK_stepK (examples/subgrid/solver.inl:166-195) and their flux-plane round trips
@@ -96,7 +97,7 @@ T8_DEV void cell_flux(const CellData<T, KIND>& L, const CellData<T, KIND>& R, bo
   }
 }
 
-// What one lane needs for its (face slot, sub-face) of an outer pass; `sf` is the far cell's state.
+// What one lane needs for its (face slot, sub-face) of a generic pass; `sf` is the far cell's state.
 template <class T>
 struct FaceLane {
   bool active, right, wall;
@@ -104,7 +105,7 @@ struct FaceLane {
   T    area, sf[5];
 };
 
-template <class T>
+template <class T, int S>
 T8_DEV FaceLane<T> load_face_lane(const T8gpuSubgridPlan& P, const SVars<T>& src, int b0, int nbf, int idx, int si, int sj) {
   FaceLane<T> L;
   L.active = idx < nbf;
@@ -126,7 +127,7 @@ T8_DEV FaceLane<T> load_face_lane(const T8gpuSubgridPlan& P, const SVars<T>& src
     L.axis     = fc.axis;
     L.positive = fc.positive;
     if (!L.wall) {
-      const size_t far = (size_t)(L.right ? rec.x : rec.y) * 64 + (L.right ? lflat : rflat);
+      const size_t far = (size_t)(L.right ? rec.x : rec.y) * S + (L.right ? lflat : rflat);
 #pragma unroll
       for (int k = 0; k < 5; k++) L.sf[k] = src.p[k][far];
     }
@@ -141,43 +142,55 @@ struct PlusLane {
   T    area, sf[5];
 };
 
-template <class T>
+template <class T, int S, int RANK>
 T8_DEV PlusLane<T> load_plus_lane(const T8gpuSubgridPlan& P, const SVars<T>& src, int e, int d, bool surface_lane, int ti, int tj) {
   PlusLane<T> L;
   L.on = L.right = L.wall = false;
   L.area = T(0);
 #pragma unroll
   for (int k = 0; k < 5; k++) L.sf[k] = T(1);
-  const int ent = P.plus[(size_t)e * 3 + d];   // wave-uniform
-  if (ent != -1 && surface_lane) {
-    const int  fid = ent & 0x7FFFFFFF;
-    const int4 rec = reinterpret_cast<const int4*>(P.face_rec)[fid];
-    const FaceCode fc = decode(rec.z);
-    L.on    = true;
-    L.right = ent < 0;
-    L.wall  = rec.y < 0;
-    L.area  = reinterpret_cast<const T*>(P.face_surfaces)[fid];
-    if (!L.wall) {
-      // far cell: in the left block on its face plane, or in the right block at the stored anchor
-      const int    fcell = L.right ? left_cell(fc, ti, tj) : right_cell(fc, ti, tj);
-      const size_t far   = (size_t)(L.right ? rec.x : rec.y) * 64 + fcell;
+  if (surface_lane) {
+    const int ent = P.plus[(size_t)e * RANK + d];
+    if (ent != -1) {
+      const int  fid = ent & 0x7FFFFFFF;
+      const int4 rec = reinterpret_cast<const int4*>(P.face_rec)[fid];
+      const FaceCode fc = decode(rec.z);
+      L.on    = true;
+      L.right = ent < 0;
+      L.wall  = rec.y < 0;
+      L.area  = reinterpret_cast<const T*>(P.face_surfaces)[fid];
+      if (!L.wall) {
+        // far cell: in the left block on its face plane, or in the right block at the stored anchor
+        const int    fcell = L.right ? left_cell(fc, ti, tj) : right_cell(fc, ti, tj);
+        const size_t far   = (size_t)(L.right ? rec.x : rec.y) * S + fcell;
 #pragma unroll
-      for (int k = 0; k < 5; k++) L.sf[k] = src.p[k][far];
+        for (int k = 0; k < 5; k++) L.sf[k] = src.p[k][far];
+      }
     }
   }
   return L;
 }
 
-template <class T, int KIND, int STAGE>
-__global__ __launch_bounds__(64) void k_subgrid444_fused(T8gpuSubgridPlan P, SVars<T> prev, SVars<T> src, SVars<T> out,
-                                                         const T* __restrict__ volumes, T dt) {
-  constexpr int NW = CellData<T, KIND>::words;
-  __shared__ T  pe[NW][64];  // this block's cells
-  __shared__ T  xb[5][64];   // flux exchange buffer (inner: per cell; outer: [slot * 16 + sub-face])
-  const int    e = sg_xcd_position(blockIdx.x, gridDim.x);
-  const int    c = threadIdx.x;
-  const int    cc[3] = {c & 3, (c >> 2) & 3, c >> 4};   // only ever indexed with compile-time constants
-  const size_t o = (size_t)e * 64 + c;
+// RANK 3: one Subgrid<4,4,4> block per wavefront. RANK 2: four Subgrid<4,4> blocks per wavefront
+// (16 lanes each; every index below is relative to the lane's own block).
+template <class T, int KIND, int STAGE, int RANK>
+__global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, SVars<T> prev, SVars<T> src, SVars<T> out,
+                                                      const T* __restrict__ volumes, T dt) {
+  constexpr int NW  = CellData<T, KIND>::words;
+  constexpr int S   = RANK == 3 ? 64 : 16;  // cells per block
+  constexpr int SF  = RANK == 3 ? 16 : 4;   // sub-faces per coarse face
+  constexpr int BPW = 64 / S;               // blocks per wavefront
+  __shared__ T  pe[NW][64];  // cells of the wave's block(s)
+  __shared__ T  xb[5][64];   // flux exchange buffer (+ passes: per cell; generic passes: [slot * SF + sub-face])
+  const int    c    = threadIdx.x;
+  const int    base = (c / S) * S, cl = c - base;
+  // RANK 3: the block index is wave-uniform -- say so explicitly (blockIdx arithmetic only), so that the
+  // per-block loads (volume, face lists, face records) stay scalar loads and their branches scalar branches
+  const int    eraw = RANK == 3 ? sg_xcd_position(blockIdx.x, gridDim.x) : sg_xcd_position(blockIdx.x, gridDim.x) * BPW + c / S;
+  const bool   live = eraw < P.num_elements;
+  const int    e    = live ? eraw : 0;
+  const int    cc[3] = {cl & 3, (cl >> 2) & 3, RANK == 3 ? cl >> 4 : 0};   // compile-time indices only
+  const size_t o = (size_t)e * S + cl;
 
   T s0[5], pv[5];
 #pragma unroll
@@ -188,17 +201,22 @@ __global__ __launch_bounds__(64) void k_subgrid444_fused(T8gpuSubgridPlan P, SVa
   }
   const T   vol     = volumes[e];
   const int b0      = P.bf_off[e];
-  const int nbf     = P.bf_off[e + 1] - b0;
-  const T   edge    = t8_cbrt(vol) / T(4);
-  const T   surface = edge * edge;
+  const int nbf     = live ? P.bf_off[e + 1] - b0 : 0;
+  const T   edge    = (RANK == 3 ? t8_cbrt(vol) : t8_sqrt(vol)) / T(4);
+  const T   surface = RANK == 3 ? edge * edge : edge;
+  int       npass   = nbf;  // generic passes run until the busiest block of the wave is done
+  if (RANK == 2) {
+    npass = max(npass, __shfl_xor(npass, 16, 64));
+    npass = max(npass, __shfl_xor(npass, 32, 64));
+  }
 
-  // the far cells of the three + faces and the first generic pass are fetched NOW, so that their
-  // dependent loads (face list -> face record -> far cell) overlap the arithmetic
-  const int slot = c >> 4, sub = c & 15, si = sub & 3, sj = sub >> 2;
-  const FaceLane<T> pre0 = load_face_lane<T>(P, src, b0, nbf, slot, si, sj);
-  const PlusLane<T> px = load_plus_lane<T>(P, src, e, 0, cc[0] == 3, cc[1], cc[2]);
-  const PlusLane<T> py = load_plus_lane<T>(P, src, e, 1, cc[1] == 3, cc[0], cc[2]);
-  const PlusLane<T> pz = load_plus_lane<T>(P, src, e, 2, cc[2] == 3, cc[0], cc[1]);
+  // the far cells of the + faces and the first generic pass are fetched NOW, so that their dependent
+  // loads (face list -> face record -> far cell) overlap the arithmetic
+  const int slot = cl / SF, sub = cl % SF, si = sub & 3, sj = RANK == 3 ? sub >> 2 : 0;
+  const FaceLane<T> pre0 = load_face_lane<T, S>(P, src, b0, nbf, slot, si, sj);
+  const PlusLane<T> px = load_plus_lane<T, S, RANK>(P, src, e, 0, live && cc[0] == 3, cc[1], cc[2]);
+  const PlusLane<T> py = load_plus_lane<T, S, RANK>(P, src, e, 1, live && cc[1] == 3, cc[0], cc[2]);
+  const PlusLane<T> pz = load_plus_lane<T, S, RANK>(P, src, e, 2, RANK == 3 && live && cc[2] == 3, cc[0], cc[1]);
 
   const CellData<T, KIND> mine = cell_from_state<T, KIND>(s0);
 #pragma unroll
@@ -207,9 +225,9 @@ __global__ __launch_bounds__(64) void k_subgrid444_fused(T8gpuSubgridPlan P, SVa
 
   T acc[5] = {T(0), T(0), T(0), T(0), T(0)};
 
-  // ---- + faces: inner (kernels.inl:364-533) and, on the block surface, the +d coarse face ------------
+  // ---- + faces: inner (kernels.inl:364-533, 2D :554-660) and, on the block surface, the +d coarse face -
 #pragma unroll
-  for (int d = 0; d < 3; d++) {
+  for (int d = 0; d < RANK; d++) {
     const int          str = d == 0 ? 1 : (d == 1 ? 4 : 16);
     const PlusLane<T>& pl  = d == 0 ? px : (d == 1 ? py : pz);
     const bool         inner = cc[d] < 3;
@@ -223,7 +241,7 @@ __global__ __launch_bounds__(64) void k_subgrid444_fused(T8gpuSubgridPlan P, SVa
     }
     const bool flip = !inner && pl.right;           // stored orientation: left = far block, normal -e_d
     const bool wall = !inner && pl.wall;
-    const T    ar   = inner ? surface : pl.area / T(16);
+    const T    ar   = inner ? surface : pl.area / T(SF);
     CellData<T, KIND> L, R;
 #pragma unroll
     for (int w = 0; w < NW; w++) {
@@ -246,75 +264,78 @@ __global__ __launch_bounds__(64) void k_subgrid444_fused(T8gpuSubgridPlan P, SVa
     }
   }
 
-  // ---- coarse faces of this block: walls (kernels.inl:913-1107), then outer faces (:664-802) -------
-  for (int p0 = 0; p0 < nbf; p0 += 4) {
+  // ---- remaining coarse faces: walls (kernels.inl:913-1107), then outer faces (:664-911) ---------------
+  for (int p0 = 0; p0 < npass; p0 += 4) {
     T                 g[5] = {T(0), T(0), T(0), T(0), T(0)};
-    const FaceLane<T> fl = p0 == 0 ? pre0 : load_face_lane<T>(P, src, b0, nbf, p0 + slot, si, sj);
+    const FaceLane<T> fl = p0 == 0 ? pre0 : load_face_lane<T, S>(P, src, b0, nbf, p0 + slot, si, sj);
     if (fl.active) {
-      CellData<T, KIND> here;
+      CellData<T, KIND> here, there;
 #pragma unroll
-      for (int w = 0; w < NW; w++) here.v[w] = pe[w][fl.myflat];
-      const T sfc = fl.area / T(16);
-      if (fl.wall) {
-        cell_flux<T, KIND>(here, here, true, fl.axis, fl.positive, sfc, g);
-      } else {
-        const CellData<T, KIND> there = cell_from_state<T, KIND>(fl.sf);
-        if (fl.right)
-          cell_flux<T, KIND>(there, here, false, fl.axis, fl.positive, sfc, g);
-        else
-          cell_flux<T, KIND>(here, there, false, fl.axis, fl.positive, sfc, g);
+      for (int w = 0; w < NW; w++) here.v[w] = pe[w][base + fl.myflat];
+      there = fl.wall ? here : cell_from_state<T, KIND>(fl.sf);
+      CellData<T, KIND> L, R;
+#pragma unroll
+      for (int w = 0; w < NW; w++) {
+        L.v[w] = fl.right ? there.v[w] : here.v[w];
+        R.v[w] = fl.right ? here.v[w] : there.v[w];
       }
+      cell_flux<T, KIND>(L, R, fl.wall, fl.axis, fl.positive, fl.area / T(SF), g);
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 5; k++) xb[k][c] = g[k];
     __syncthreads();
     // every cell collects the sub-face fluxes that end on it, slot by slot (list order)
-    for (int s = 0; s < 4 && p0 + s < nbf; s++) {
-      const int  ent   = P.bf_ent[b0 + p0 + s];
-      const int  fid   = ent & 0x7FFFFFFF;
-      const bool right = ent < 0;
-      const FaceCode fc = decode(reinterpret_cast<const int4*>(P.face_rec)[fid].z);
-      const int  ca = cell_coord(c, fc.axis), ci = cell_coord(c, fc.ta()), cj = cell_coord(c, fc.tb());
-      if (!right) {
-        if (ca == (fc.positive ? 3 : 0)) {
-          const int q = 16 * s + ci + 4 * cj;
+    for (int s = 0; s < 4; s++) {
+      if (p0 + s < nbf) {
+        const int  ent   = P.bf_ent[b0 + p0 + s];
+        const int  fid   = ent & 0x7FFFFFFF;
+        const bool right = ent < 0;
+        const FaceCode fc = decode(reinterpret_cast<const int4*>(P.face_rec)[fid].z);
+        const int  ca = cell_coord(cl, fc.axis), ci = cell_coord(cl, fc.ta()), cj = RANK == 3 ? cell_coord(cl, fc.tb()) : 0;
+        const int  q0 = base + SF * s;
+        if (!right) {
+          if (ca == (fc.positive ? 3 : 0)) {
+            const int q = q0 + ci + 4 * cj;
 #pragma unroll
-          for (int k = 0; k < 5; k++) acc[k] -= xb[k][q];
-        }
-      } else if (ca == fc.off(fc.axis)) {
-        const int di = ci - fc.off(fc.ta()), dj = cj - fc.off(fc.tb());
-        if (!fc.hanging) {
-          const int q = 16 * s + di + 4 * dj;
+            for (int k = 0; k < 5; k++) acc[k] -= xb[k][q];
+          }
+        } else if (ca == fc.off(fc.axis)) {
+          const int di = ci - fc.off(fc.ta()), dj = RANK == 3 ? cj - fc.off(fc.tb()) : 0;
+          if (!fc.hanging) {
+            const int q = q0 + di + 4 * dj;
 #pragma unroll
-          for (int k = 0; k < 5; k++) acc[k] += xb[k][q];
-        } else if (di >= 0 && di < 2 && dj >= 0 && dj < 2) {
+            for (int k = 0; k < 5; k++) acc[k] += xb[k][q];
+          } else if (di >= 0 && di < 2 && dj >= 0 && dj < 2) {
 #pragma unroll
-          for (int jj = 0; jj < 2; jj++)
+            for (int jj = 0; jj < (RANK == 3 ? 2 : 1); jj++)
 #pragma unroll
-            for (int ii = 0; ii < 2; ii++) {
-              const int q = 16 * s + (2 * di + ii) + 4 * (2 * dj + jj);
+              for (int ii = 0; ii < 2; ii++) {
+                const int q = q0 + (2 * di + ii) + (RANK == 3 ? 4 * (2 * dj + jj) : 0);
 #pragma unroll
-              for (int k = 0; k < 5; k++) acc[k] += xb[k][q];
-            }
+                for (int k = 0; k < 5; k++) acc[k] += xb[k][q];
+              }
+          }
         }
       }
     }
   }
 
-  // ---- RK stage (ssp_runge_kutta.inl:101-221): per-subcell volume = volumes[e] / 64 ------------------
-  const T scale = dt / (vol / T(64));
+  // ---- RK stage (ssp_runge_kutta.inl:101-221): per-subcell volume = volumes[e] / Subgrid::size --------
+  if (live) {
+    const T scale = dt / (vol / T(S));
 #pragma unroll
-  for (int k = 0; k < 5; k++) {
-    T r;
-    if (STAGE == 1) {
-      r = s0[k] + scale * acc[k];
-    } else if (STAGE == 2) {
-      r = rk3c<T>::c21 * pv[k] + rk3c<T>::c22 * s0[k] + rk3c<T>::c23 * scale * acc[k];
-    } else {
-      r = rk3c<T>::c31 * pv[k] + rk3c<T>::c32 * s0[k] + rk3c<T>::c33 * scale * acc[k];
+    for (int k = 0; k < 5; k++) {
+      T r;
+      if (STAGE == 1) {
+        r = s0[k] + scale * acc[k];
+      } else if (STAGE == 2) {
+        r = rk3c<T>::c21 * pv[k] + rk3c<T>::c22 * s0[k] + rk3c<T>::c23 * scale * acc[k];
+      } else {
+        r = rk3c<T>::c31 * pv[k] + rk3c<T>::c32 * s0[k] + rk3c<T>::c33 * scale * acc[k];
+      }
+      out.p[k][o] = r;
     }
-    out.p[k][o] = r;
   }
 }
 
@@ -328,17 +349,26 @@ SVars<T> smk(const V& v) {
 template <class T, class V>
 int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, V prev, V mid, V out, const T* volumes, T dt,
                         void* stream) {
-  if (!plan || (kind != 0 && kind != 1) || stage < 1 || stage > 3 || plan->rank != 3) return static_cast<int>(hipErrorInvalidValue);
+  if (!plan || (kind != 0 && kind != 1) || stage < 1 || stage > 3 || (plan->rank != 2 && plan->rank != 3))
+    return static_cast<int>(hipErrorInvalidValue);
   if (plan->num_elements <= 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3  grid(plan->num_elements), block(64);
-#define T8_SG(K, S) \
-  hipLaunchKernelGGL((k_subgrid444_fused<T, K, S>), grid, block, 0, s, *plan, smk<T>(prev), smk<T>(mid), smk<T>(out), volumes, dt)
+  const dim3  grid(plan->rank == 3 ? plan->num_elements : (plan->num_elements + 3) / 4), block(64);
+#define T8_SG(K, S, R) \
+  hipLaunchKernelGGL((k_subgrid_fused<T, K, S, R>), grid, block, 0, s, *plan, smk<T>(prev), smk<T>(mid), smk<T>(out), volumes, dt)
+#define T8_SGR(K, S)     \
+  do {                   \
+    if (plan->rank == 3) \
+      T8_SG(K, S, 3);    \
+    else                 \
+      T8_SG(K, S, 2);    \
+  } while (0)
   if (kind == 0) {
-    if (stage == 1) T8_SG(0, 1); else if (stage == 2) T8_SG(0, 2); else T8_SG(0, 3);
+    if (stage == 1) T8_SGR(0, 1); else if (stage == 2) T8_SGR(0, 2); else T8_SGR(0, 3);
   } else {
-    if (stage == 1) T8_SG(1, 1); else if (stage == 2) T8_SG(1, 2); else T8_SG(1, 3);
+    if (stage == 1) T8_SGR(1, 1); else if (stage == 2) T8_SGR(1, 2); else T8_SGR(1, 3);
   }
+#undef T8_SGR
 #undef T8_SG
   return static_cast<int>(hipGetLastError());
 }

@@ -65,17 +65,15 @@ class T8gpuSubgridPlan(C.Structure):
 
 
 class SubgridPlan:
-    """Device copy of the per-block face lists for the fused Subgrid<4,4,4> kernel."""
+    """Device copy of the per-block face lists for the fused Subgrid<4,4> / Subgrid<4,4,4> kernels."""
 
     def __init__(self, part, dtype):
         from .plan import HostSubgridPlan
-        if part.mesh.dim != 3:
-            raise NotImplementedError("the fused block kernel covers Subgrid<4,4,4>; Subgrid<4,4> runs on the compat kernels")
         self.host = HostSubgridPlan(part)
         self.dtype = dtype
         npf = np.float32 if dtype == torch.float32 else np.float64
         self._keep = {
-            "plus": torch.from_numpy(self.host.plus if self.host.plus.size else np.full((1, 3), -1, np.int32)).cuda(),
+            "plus": torch.from_numpy(self.host.plus if self.host.plus.size else np.full((1, part.mesh.dim), -1, np.int32)).cuda(),
             "bf_off": torch.from_numpy(self.host.bf_off).cuda(),
             "bf_ent": torch.from_numpy(self.host.bf_ent if self.host.bf_ent.size else np.zeros(1, np.int32)).cuda(),
             "face_rec": torch.from_numpy(self.host.face_rec if self.host.face_rec.size else np.zeros((1, 4), np.int32)).cuda(),
@@ -84,7 +82,7 @@ class SubgridPlan:
         c = T8gpuSubgridPlan()
         for k, t in self._keep.items():
             setattr(c, k, t.data_ptr())
-        c.num_elements, c.rank, c.max_faces_per_block = part.N, 3, self.host.max_bf
+        c.num_elements, c.rank, c.max_faces_per_block = part.N, part.mesh.dim, self.host.max_bf
         self.c = c
 
     def stage(self, solver, stage, src, dst, dt, stream):

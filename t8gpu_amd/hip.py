@@ -30,7 +30,7 @@ def lib():
         # torch bundles its own libamdhip64 / librccl (same SONAMEs as /opt/rocm): load torch FIRST so that
         # this library binds to the runtime that owns torch's streams and allocations.
         import torch  # noqa: F401
-        path = _build.HIP_LIB
+        path = os.environ.get("T8GPU_HIP_LIB", _build.HIP_LIB)   # override: A/B runs of two builds
         if not os.path.exists(path):
             raise T8gpuHipError(f"{path} is missing: run `python -m t8gpu_amd.build` (hipcc --offload-arch=gfx950). "
                                 "There is no CPU fallback for the hot path.")

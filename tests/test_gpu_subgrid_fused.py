@@ -14,10 +14,12 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("kind", [hip.KEPES, hip.HLL])
-@pytest.mark.parametrize("mesh_args", [dict(base_level=2, max_level=2), dict(base_level=3, max_level=4, band=0.03),
-                                       dict(base_level=3, max_level=4, band=0.03, periodic=False)])
-def test_fused_block_kernel_vs_oracle(dtype, kind, mesh_args):
-    mesh = SynthMesh(3, **mesh_args)
+@pytest.mark.parametrize("dim,mesh_args", [(3, dict(base_level=2, max_level=2)), (3, dict(base_level=3, max_level=4, band=0.03)),
+                                           (3, dict(base_level=3, max_level=4, band=0.03, periodic=False)),
+                                           (2, dict(base_level=3, max_level=3)), (2, dict(base_level=3, max_level=6, band=0.03)),
+                                           (2, dict(base_level=3, max_level=5, band=0.03, periodic=False))])
+def test_fused_block_kernel_vs_oracle(dtype, kind, dim, mesh_args):
+    mesh = SynthMesh(dim, **mesh_args)
     part = mesh.partition(subgrid=True)
     st = perturbed_state(part, 31)
     g = SubgridSolver(part, dtype, flux_kind=kind, mode="fused", state=st)
@@ -26,7 +28,7 @@ def test_fused_block_kernel_vs_oracle(dtype, kind, mesh_args):
     g.iterate(dt)
     o.iterate(dt, kind=kind)
     torch.cuda.synchronize()
-    n = part.N * 64
+    n = part.N * g.S
     assert rel_err(g.state().cpu().numpy(), o.current()[:, :n]) < TOL1[dtype]
     assert (g.planes[20:25] == 0).all()
     for _ in range(4):
