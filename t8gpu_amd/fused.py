@@ -16,7 +16,10 @@ class T8gpuPlainPlan(C.Structure):
 
 
 class PlainPlan:
-    def __init__(self, part, dtype, tmax=256, fcap=512, compressed=True):
+    def __init__(self, part, dtype, tmax=None, fcap=None, compressed=True):
+        import os
+        tmax = int(os.environ.get("T8GPU_TMAX", 256)) if tmax is None else tmax     # tuning knobs of the tiling
+        fcap = int(os.environ.get("T8GPU_FCAP", 512)) if fcap is None else fcap
         self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap)
         self.dtype = dtype
         self._keep = {}
