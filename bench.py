@@ -30,6 +30,9 @@ WORKLOADS = {
     "c2": dict(kind="plain", dim=2, base=6, lmax=11, band=0.0596, dtype="f64", desc="2D KH AMR levels 6-11 (~1.03 M elements)"),
     "c3": dict(kind="subgrid", dim=3, base=5, lmax=6, band=0.17, dtype="f32", desc="3D Subgrid<4,4,4> AMR levels 5-6"),
     "c4": dict(kind="plain", dim=2, base=7, lmax=12, band=0.1472, dtype="f64", desc="2D KH AMR levels 7-12 (~9.93 M elements)"),
+    # BASELINE config 5 needs a real t8code mixed tet/hex cmesh; this is its geometry-synthetic stand-in (hex only,
+    # no repartition): it exercises the 3D plain-element path (phi = 3, 6-24 faces per element) at that size.
+    "c5": dict(kind="plain", dim=3, base=6, lmax=8, band=0.05, dtype="f64", desc="3D hex AMR levels 6-8 (~3.93 M elements), geometry-synthetic"),
 }
 
 

@@ -156,13 +156,17 @@ int t8gpu_hip_plain_fused_stage_f64(int flux_kind, int stage, const T8gpuPlainPl
  * Wire format: 5 values per element, element-major (sendbuf[5*t + var]); each peer's elements are a
  * contiguous run of send_idx / of the ghost slots, so one message per peer and direction. The
  * transport (ncclSend/ncclRecv in one group, on the stream of these kernels) is issued by the host
- * side (t8gpu_amd/halo.py through torch.distributed's RCCL communicator). */
-int t8gpu_hip_halo_pack_f32(int n_send, const int32_t* send_idx, T8gpuVars_f32 state, float* sendbuf, void* stream);
-int t8gpu_hip_halo_pack_f64(int n_send, const int32_t* send_idx, T8gpuVars_f64 state, double* sendbuf, void* stream);
-int t8gpu_hip_halo_unpack_f32(int num_ghosts, int first_ghost_slot, const float* recvbuf, T8gpuVars_f32 state,
-                              void* stream);
-int t8gpu_hip_halo_unpack_f64(int num_ghosts, int first_ghost_slot, const double* recvbuf, T8gpuVars_f64 state,
-                              void* stream);
+ * side (t8gpu_amd/halo.py through torch.distributed's RCCL communicator) or natively (T8gpuHalo below).
+ * cells_per_element = 1 for plain elements, Subgrid::size (16 / 64) for blocks (a ghost block mirrors all
+ * its subcells; wire format (element, cell, variable)). */
+int t8gpu_hip_halo_pack_f32(int n_send, int cells_per_element, const int32_t* send_idx, T8gpuVars_f32 state,
+                            float* sendbuf, void* stream);
+int t8gpu_hip_halo_pack_f64(int n_send, int cells_per_element, const int32_t* send_idx, T8gpuVars_f64 state,
+                            double* sendbuf, void* stream);
+int t8gpu_hip_halo_unpack_f32(int num_ghosts, int first_ghost_slot, int cells_per_element, const float* recvbuf,
+                              T8gpuVars_f32 state, void* stream);
+int t8gpu_hip_halo_unpack_f64(int num_ghosts, int first_ghost_slot, int cells_per_element, const double* recvbuf,
+                              T8gpuVars_f64 state, void* stream);
 
 /* ---- native RCCL transport + whole-step driver ----------------------------------------------------
  * One communicator per process (one rank per GPU); the 128-byte id is created on one rank and
@@ -176,12 +180,13 @@ int t8gpu_hip_stream_wait(void* stream, double timeout_s); /* 0 idle, 1 timed ou
 
 typedef struct T8gpuHalo {
   int32_t num_elements, num_ghosts, n_peers, n_send;
+  int32_t cells_per_element, reserved; /* 1 (plain elements) or Subgrid::size                            */
   const int32_t* peers;     /* HOST [n_peers] neighbour ranks, ascending                               */
   const int32_t* send_off;  /* HOST [n_peers+1] ranges of send_idx per peer                            */
   const int32_t* recv_off;  /* HOST [n_peers+1] ranges of the ghost slots (relative to N) per peer     */
   const int32_t* send_idx;  /* DEVICE [n_send] owned elements mirrored on a peer                       */
-  void* sendbuf;            /* DEVICE 5*n_send float_type                                              */
-  void* recvbuf;            /* DEVICE 5*num_ghosts float_type                                          */
+  void* sendbuf;            /* DEVICE 5*n_send*cells_per_element float_type                            */
+  void* recvbuf;            /* DEVICE 5*num_ghosts*cells_per_element float_type                        */
   void* comm;               /* from t8gpu_hip_comm_create                                              */
 } T8gpuHalo;
 
@@ -216,15 +221,18 @@ typedef struct T8gpuSubgridPlan {
   const int32_t* bf_ent;        /* remaining faces (bit 31: the block is the face's RIGHT side); walls first */
   const int32_t* face_rec;      /* [F+B][4] = left slot, right slot (-1 wall), code, 0 (16-byte aligned) */
   const void*    face_surfaces; /* float_type [F+B], the reference's face_surfaces array                 */
-  int32_t num_elements, rank, max_faces_per_block, reserved;
+  const int32_t* block_order;   /* [num_elements] blocks that touch no ghost block first, then the others  */
+  int32_t num_elements, rank, max_faces_per_block, n_interior_blocks;
 } T8gpuSubgridPlan;
 
-int t8gpu_hip_subgrid_fused_stage_f32(int flux_kind, int stage, const T8gpuSubgridPlan* plan, T8gpuVars_f32 prev,
-                                      T8gpuVars_f32 mid, T8gpuVars_f32 out, const float* volumes, float delta_t,
-                                      void* stream);
-int t8gpu_hip_subgrid_fused_stage_f64(int flux_kind, int stage, const T8gpuSubgridPlan* plan, T8gpuVars_f64 prev,
-                                      T8gpuVars_f64 mid, T8gpuVars_f64 out, const double* volumes, double delta_t,
-                                      void* stream);
+/* block_begin/block_count select a range of block_order (0, num_elements = everything; [0, n_interior_blocks)
+ * can run while the halo exchange of `mid` is in flight). */
+int t8gpu_hip_subgrid_fused_stage_f32(int flux_kind, int stage, const T8gpuSubgridPlan* plan, int block_begin,
+                                      int block_count, T8gpuVars_f32 prev, T8gpuVars_f32 mid, T8gpuVars_f32 out,
+                                      const float* volumes, float delta_t, void* stream);
+int t8gpu_hip_subgrid_fused_stage_f64(int flux_kind, int stage, const T8gpuSubgridPlan* plan, int block_begin,
+                                      int block_count, T8gpuVars_f64 prev, T8gpuVars_f64 mid, T8gpuVars_f64 out,
+                                      const double* volumes, double delta_t, void* stream);
 
 /* ---- scalar reductions next to the hot path -------------------------------------------
  * Device-side replacements of the two host round trips of the reference solvers; results are device

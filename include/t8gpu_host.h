@@ -57,8 +57,10 @@ void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, c
                                 const int32_t* face_level_difference, const int32_t* face_neighbor_offset,
                                 const double* normals);
 void  t8gpu_plan_subgrid_destroy(void* plan);
-/* sizes[3] = {n_entries, max faces per block, F + B} */
+/* sizes[4] = {n_entries, max faces per block, F + B, n_interior_blocks} */
 void t8gpu_plan_subgrid_sizes(const void* plan, int64_t* sizes);
+/* block_order[N]: blocks that touch no ghost block first (they can run during the halo exchange) */
+void t8gpu_plan_subgrid_order(const void* plan, int32_t* block_order);
 /* bf_off[N+1], bf_ent[n_entries], face_rec[(F+B)*4], plus[N*rank] (the +side face of each block, or -1) */
 void t8gpu_plan_subgrid_arrays(const void* plan, int32_t* bf_off, int32_t* bf_ent, int32_t* face_rec, int32_t* plus);
 

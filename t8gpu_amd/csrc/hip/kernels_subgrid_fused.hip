@@ -174,8 +174,8 @@ T8_DEV PlusLane<T> load_plus_lane(const T8gpuSubgridPlan& P, const SVars<T>& src
 // RANK 3: one Subgrid<4,4,4> block per wavefront. RANK 2: four Subgrid<4,4> blocks per wavefront
 // (16 lanes each; every index below is relative to the lane's own block).
 template <class T, int KIND, int STAGE, int RANK>
-__global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, SVars<T> prev, SVars<T> src, SVars<T> out,
-                                                      const T* __restrict__ volumes, T dt) {
+__global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int block_begin, int block_count, SVars<T> prev,
+                                                      SVars<T> src, SVars<T> out, const T* __restrict__ volumes, T dt) {
   constexpr int NW  = CellData<T, KIND>::words;
   constexpr int S   = RANK == 3 ? 64 : 16;  // cells per block
   constexpr int SF  = RANK == 3 ? 16 : 4;   // sub-faces per coarse face
@@ -186,9 +186,9 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, SVars<
   const int    base = (c / S) * S, cl = c - base;
   // RANK 3: the block index is wave-uniform -- say so explicitly (blockIdx arithmetic only), so that the
   // per-block loads (volume, face lists, face records) stay scalar loads and their branches scalar branches
-  const int    eraw = RANK == 3 ? sg_xcd_position(blockIdx.x, gridDim.x) : sg_xcd_position(blockIdx.x, gridDim.x) * BPW + c / S;
-  const bool   live = eraw < P.num_elements;
-  const int    e    = live ? eraw : 0;
+  const int    pos  = RANK == 3 ? sg_xcd_position(blockIdx.x, gridDim.x) : sg_xcd_position(blockIdx.x, gridDim.x) * BPW + c / S;
+  const bool   live = pos < block_count;
+  const int    e    = P.block_order[block_begin + (live ? pos : 0)];
   const int    cc[3] = {cl & 3, (cl >> 2) & 3, RANK == 3 ? cl >> 4 : 0};   // compile-time indices only
   const size_t o = (size_t)e * S + cl;
 
@@ -347,15 +347,17 @@ SVars<T> smk(const V& v) {
 }
 
 template <class T, class V>
-int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, V prev, V mid, V out, const T* volumes, T dt,
-                        void* stream) {
+int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, int block_begin, int block_count, V prev, V mid,
+                        V out, const T* volumes, T dt, void* stream) {
   if (!plan || (kind != 0 && kind != 1) || stage < 1 || stage > 3 || (plan->rank != 2 && plan->rank != 3))
     return static_cast<int>(hipErrorInvalidValue);
-  if (plan->num_elements <= 0) return 0;
+  if (block_begin < 0 || block_count < 0 || block_begin + block_count > plan->num_elements) return static_cast<int>(hipErrorInvalidValue);
+  if (block_count == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3  grid(plan->rank == 3 ? plan->num_elements : (plan->num_elements + 3) / 4), block(64);
-#define T8_SG(K, S, R) \
-  hipLaunchKernelGGL((k_subgrid_fused<T, K, S, R>), grid, block, 0, s, *plan, smk<T>(prev), smk<T>(mid), smk<T>(out), volumes, dt)
+  const dim3  grid(plan->rank == 3 ? block_count : (block_count + 3) / 4), block(64);
+#define T8_SG(K, S, R)                                                                                                   \
+  hipLaunchKernelGGL((k_subgrid_fused<T, K, S, R>), grid, block, 0, s, *plan, block_begin, block_count, smk<T>(prev), \
+                     smk<T>(mid), smk<T>(out), volumes, dt)
 #define T8_SGR(K, S)     \
   do {                   \
     if (plan->rank == 3) \
@@ -376,12 +378,14 @@ int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, V pre
 }  // namespace t8gpu_hip
 
 extern "C" {
-int t8gpu_hip_subgrid_fused_stage_f32(int kind, int stage, const T8gpuSubgridPlan* plan, T8gpuVars_f32 prev,
-                                      T8gpuVars_f32 mid, T8gpuVars_f32 out, const float* volumes, float dt, void* stream) {
-  return t8gpu_hip::subgrid_fused_stage<float>(kind, stage, plan, prev, mid, out, volumes, dt, stream);
+int t8gpu_hip_subgrid_fused_stage_f32(int kind, int stage, const T8gpuSubgridPlan* plan, int block_begin, int block_count,
+                                      T8gpuVars_f32 prev, T8gpuVars_f32 mid, T8gpuVars_f32 out, const float* volumes,
+                                      float dt, void* stream) {
+  return t8gpu_hip::subgrid_fused_stage<float>(kind, stage, plan, block_begin, block_count, prev, mid, out, volumes, dt, stream);
 }
-int t8gpu_hip_subgrid_fused_stage_f64(int kind, int stage, const T8gpuSubgridPlan* plan, T8gpuVars_f64 prev,
-                                      T8gpuVars_f64 mid, T8gpuVars_f64 out, const double* volumes, double dt, void* stream) {
-  return t8gpu_hip::subgrid_fused_stage<double>(kind, stage, plan, prev, mid, out, volumes, dt, stream);
+int t8gpu_hip_subgrid_fused_stage_f64(int kind, int stage, const T8gpuSubgridPlan* plan, int block_begin, int block_count,
+                                      T8gpuVars_f64 prev, T8gpuVars_f64 mid, T8gpuVars_f64 out, const double* volumes,
+                                      double dt, void* stream) {
+  return t8gpu_hip::subgrid_fused_stage<double>(kind, stage, plan, block_begin, block_count, prev, mid, out, volumes, dt, stream);
 }
 }

@@ -55,24 +55,26 @@ int exchange(const T8gpuHalo& h, const int32_t* peers, const int32_t* send_off, 
   if (h.n_peers <= 0) return 0;
   T*       sb = static_cast<T*>(h.sendbuf);
   T*       rb = static_cast<T*>(h.recvbuf);
+  const int cells = h.cells_per_element < 1 ? 1 : h.cells_per_element;
   if constexpr (sizeof(T) == 4) {
-    T8_TRY(t8gpu_hip_halo_pack_f32(h.n_send, h.send_idx, state, sb, s));
+    T8_TRY(t8gpu_hip_halo_pack_f32(h.n_send, cells, h.send_idx, state, sb, s));
   } else {
-    T8_TRY(t8gpu_hip_halo_pack_f64(h.n_send, h.send_idx, state, sb, s));
+    T8_TRY(t8gpu_hip_halo_pack_f64(h.n_send, cells, h.send_idx, state, sb, s));
   }
   ncclComm_t comm = static_cast<ncclComm_t>(h.comm);
   T8_TRY(nccl_code(ncclGroupStart()));
   for (int j = 0; j < h.n_peers; j++) {
-    const size_t rc = 5 * static_cast<size_t>(recv_off[j + 1] - recv_off[j]);
-    const size_t sc = 5 * static_cast<size_t>(send_off[j + 1] - send_off[j]);
-    if (rc) T8_TRY(nccl_code(ncclRecv(rb + 5 * static_cast<size_t>(recv_off[j]), rc, nccl_type<T>(), peers[j], comm, s)));
-    if (sc) T8_TRY(nccl_code(ncclSend(sb + 5 * static_cast<size_t>(send_off[j]), sc, nccl_type<T>(), peers[j], comm, s)));
+    const size_t w  = 5 * static_cast<size_t>(cells);   // values per element on the wire
+    const size_t rc = w * static_cast<size_t>(recv_off[j + 1] - recv_off[j]);
+    const size_t sc = w * static_cast<size_t>(send_off[j + 1] - send_off[j]);
+    if (rc) T8_TRY(nccl_code(ncclRecv(rb + w * static_cast<size_t>(recv_off[j]), rc, nccl_type<T>(), peers[j], comm, s)));
+    if (sc) T8_TRY(nccl_code(ncclSend(sb + w * static_cast<size_t>(send_off[j]), sc, nccl_type<T>(), peers[j], comm, s)));
   }
   T8_TRY(nccl_code(ncclGroupEnd()));
   if constexpr (sizeof(T) == 4) {
-    T8_TRY(t8gpu_hip_halo_unpack_f32(h.num_ghosts, h.num_elements, rb, state, s));
+    T8_TRY(t8gpu_hip_halo_unpack_f32(h.num_ghosts, h.num_elements, cells, rb, state, s));
   } else {
-    T8_TRY(t8gpu_hip_halo_unpack_f64(h.num_ghosts, h.num_elements, rb, state, s));
+    T8_TRY(t8gpu_hip_halo_unpack_f64(h.num_ghosts, h.num_elements, cells, rb, state, s));
   }
   return 0;
 }

@@ -23,7 +23,8 @@
 namespace {
 struct SubgridPlan {
   int32_t N = 0, F = 0, B = 0, rank = 3, max_bf = 0;
-  std::vector<int32_t> bf_off, bf_ent, face_rec, plus;
+  std::vector<int32_t> bf_off, bf_ent, face_rec, plus, block_order;  // block_order: interior blocks first
+  int32_t n_interior = 0;
 };
 }  // namespace
 
@@ -106,17 +107,35 @@ void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, c
     if (l < N && !folded_l[f]) P->bf_ent[cur[l]++] = f;
     if (r < N && r != l && !folded_r[f]) P->bf_ent[cur[r]++] = f | static_cast<int32_t>(0x80000000u);
   }
+  // blocks whose faces all stay among owned blocks can run while the halo exchange is in flight
+  std::vector<uint8_t> ghosty(static_cast<size_t>(N), 0);
+  for (int32_t f = 0; f < F; f++) {
+    const int32_t l = fn[2 * static_cast<size_t>(f)], r = fn[2 * static_cast<size_t>(f) + 1];
+    if (l >= N && r < N) ghosty[r] = 1;
+    if (r >= N && l < N) ghosty[l] = 1;
+  }
+  for (int32_t e = 0; e < N; e++)
+    if (!ghosty[e]) P->block_order.push_back(e);
+  P->n_interior = static_cast<int32_t>(P->block_order.size());
+  for (int32_t e = 0; e < N; e++)
+    if (ghosty[e]) P->block_order.push_back(e);
   return P;
 }
 
 void t8gpu_plan_subgrid_destroy(void* h) { delete static_cast<SubgridPlan*>(h); }
 
-/* sizes[3] = {n_entries, max faces per block, F + B} */
+/* sizes[4] = {n_entries, max faces per block, F + B, n_interior_blocks} */
 void t8gpu_plan_subgrid_sizes(const void* h, int64_t* sizes) {
   const SubgridPlan* P = static_cast<const SubgridPlan*>(h);
   sizes[0] = static_cast<int64_t>(P->bf_ent.size());
   sizes[1] = P->max_bf;
   sizes[2] = static_cast<int64_t>(P->F) + P->B;
+  sizes[3] = P->n_interior;
+}
+
+void t8gpu_plan_subgrid_order(const void* h, int32_t* block_order) {
+  const SubgridPlan* P = static_cast<const SubgridPlan*>(h);
+  if (block_order && !P->block_order.empty()) std::memcpy(block_order, P->block_order.data(), P->block_order.size() * sizeof(int32_t));
 }
 
 void t8gpu_plan_subgrid_arrays(const void* h, int32_t* bf_off, int32_t* bf_ent, int32_t* face_rec, int32_t* plus) {

@@ -63,8 +63,9 @@ class PlainPlan:
 
 class T8gpuSubgridPlan(C.Structure):
     _fields_ = [("plus", C.c_void_p), ("bf_off", C.c_void_p), ("bf_ent", C.c_void_p), ("face_rec", C.c_void_p),
-                ("face_surfaces", C.c_void_p),
-                ("num_elements", C.c_int32), ("rank", C.c_int32), ("max_faces_per_block", C.c_int32), ("reserved", C.c_int32)]
+                ("face_surfaces", C.c_void_p), ("block_order", C.c_void_p),
+                ("num_elements", C.c_int32), ("rank", C.c_int32), ("max_faces_per_block", C.c_int32),
+                ("n_interior_blocks", C.c_int32)]
 
 
 class SubgridPlan:
@@ -81,17 +82,20 @@ class SubgridPlan:
             "bf_ent": torch.from_numpy(self.host.bf_ent if self.host.bf_ent.size else np.zeros(1, np.int32)).cuda(),
             "face_rec": torch.from_numpy(self.host.face_rec if self.host.face_rec.size else np.zeros((1, 4), np.int32)).cuda(),
             "face_surfaces": torch.from_numpy(np.ascontiguousarray(part.areas if part.areas.size else np.zeros(1), npf)).cuda(),
+            "block_order": torch.from_numpy(self.host.block_order if self.host.block_order.size else np.zeros(1, np.int32)).cuda(),
         }
         c = T8gpuSubgridPlan()
         for k, t in self._keep.items():
             setattr(c, k, t.data_ptr())
         c.num_elements, c.rank, c.max_faces_per_block = part.N, part.mesh.dim, self.host.max_bf
+        c.n_interior_blocks = self.host.n_interior
         self.c = c
 
-    def stage(self, solver, stage, src, dst, dt, stream):
+    def stage(self, solver, stage, src, dst, dt, stream, block_begin=0, block_count=None):
         from .solver import _timer_begin, _timer_end
+        n = self.host.N - block_begin if block_count is None else block_count
         ev = _timer_begin(solver)
-        hip.call("t8gpu_hip_subgrid_fused_stage", self.dtype, solver.kind, stage, C.byref(self.c),
+        hip.call("t8gpu_hip_subgrid_fused_stage", self.dtype, solver.kind, stage, C.byref(self.c), block_begin, n,
                  solver.get_own_variables(solver.prev), solver.get_own_variables(src), solver.get_own_variables(dst),
                  hip.ptr(solver.volumes), hip.fscalar(self.dtype, dt), stream)
         _timer_end(solver, ev)

@@ -26,11 +26,12 @@ class HaloExchange:
         self.send_off = [int(x) for x in part.send_off]
         self.recv_off = [int(x) for x in part.recv_off]
         self.n_send = int(part.send_idx.size)
+        self.cells = S = part.cells_per_element          # 1 (plain) or Subgrid::size: a ghost block mirrors all its cells
         self.on_gpu = str(device).startswith("cuda")
         self.send_idx = torch.from_numpy(part.send_idx.copy()).to(device)
-        self.send_idx64 = self.send_idx.long()
-        self.sendbuf = torch.zeros(max(1, 5 * self.n_send), dtype=dtype, device=device)
-        self.recvbuf = torch.zeros(max(1, 5 * self.G), dtype=dtype, device=device)
+        self.send_cells64 = (self.send_idx.long()[:, None] * S + torch.arange(S, device=device)[None, :]).reshape(-1)
+        self.sendbuf = torch.zeros(max(1, 5 * self.n_send * S), dtype=dtype, device=device)
+        self.recvbuf = torch.zeros(max(1, 5 * self.G * S), dtype=dtype, device=device)
         self.comm_stream = torch.cuda.Stream() if (self.on_gpu and overlap) else None
         self.ev_state = torch.cuda.Event() if self.on_gpu else None
         self.ev_ghost = torch.cuda.Event() if self.on_gpu else None
@@ -43,25 +44,28 @@ class HaloExchange:
         if self.n_send == 0:
             return
         if self.on_gpu:
-            hip.call("t8gpu_hip_halo_pack", self.dtype, self.n_send, hip.ptr(self.send_idx), hip.vars_of(planes5),
+            hip.call("t8gpu_hip_halo_pack", self.dtype, self.n_send, self.cells, hip.ptr(self.send_idx), hip.vars_of(planes5),
                      hip.ptr(self.sendbuf), hip.stream_ptr())
         else:
-            self.sendbuf[:5 * self.n_send].view(self.n_send, 5).copy_(planes5[:, self.send_idx64].t())
+            n = self.n_send * self.cells
+            self.sendbuf[:5 * n].view(n, 5).copy_(planes5[:, self.send_cells64].t())
 
     def _unpack(self, planes5):
         if self.G == 0:
             return
         if self.on_gpu:
-            hip.call("t8gpu_hip_halo_unpack", self.dtype, self.G, self.N, hip.ptr(self.recvbuf), hip.vars_of(planes5),
-                     hip.stream_ptr())
+            hip.call("t8gpu_hip_halo_unpack", self.dtype, self.G, self.N, self.cells, hip.ptr(self.recvbuf),
+                     hip.vars_of(planes5), hip.stream_ptr())
         else:
-            planes5[:, self.N:self.N + self.G] = self.recvbuf[:5 * self.G].view(self.G, 5).t()
+            S = self.cells
+            planes5[:, self.N * S:(self.N + self.G) * S] = self.recvbuf[:5 * self.G * S].view(self.G * S, 5).t()
 
     def _transport(self):
         ops = []
         for j, p in enumerate(self.peers):
-            r0, r1 = 5 * self.recv_off[j], 5 * self.recv_off[j + 1]
-            s0, s1 = 5 * self.send_off[j], 5 * self.send_off[j + 1]
+            w = 5 * self.cells
+            r0, r1 = w * self.recv_off[j], w * self.recv_off[j + 1]
+            s0, s1 = w * self.send_off[j], w * self.send_off[j + 1]
             if r1 > r0:
                 ops.append(self.dist.P2POp(self.dist.irecv, self.recvbuf[r0:r1], p))
             if s1 > s0:

@@ -9,7 +9,7 @@ from . import hip
 
 class T8gpuHalo(C.Structure):
     _fields_ = [("num_elements", C.c_int32), ("num_ghosts", C.c_int32), ("n_peers", C.c_int32), ("n_send", C.c_int32),
-                ("peers", C.c_void_p), ("send_off", C.c_void_p), ("recv_off", C.c_void_p), ("send_idx", C.c_void_p),
+                ("cells_per_element", C.c_int32), ("reserved", C.c_int32), ("peers", C.c_void_p), ("send_off", C.c_void_p), ("recv_off", C.c_void_p), ("send_idx", C.c_void_p),
                 ("sendbuf", C.c_void_p), ("recvbuf", C.c_void_p), ("comm", C.c_void_p)]
 
 
@@ -49,10 +49,12 @@ class NativeHalo:
         self.recv_off = np.ascontiguousarray(part.recv_off, np.int32)
         self.send_idx = torch.from_numpy(np.ascontiguousarray(part.send_idx, np.int32)).cuda()
         n_send = int(part.send_idx.size)
-        self.sendbuf = torch.zeros(max(1, 5 * n_send), dtype=dtype, device="cuda")
-        self.recvbuf = torch.zeros(max(1, 5 * part.G), dtype=dtype, device="cuda")
+        cells = part.cells_per_element
+        self.sendbuf = torch.zeros(max(1, 5 * n_send * cells), dtype=dtype, device="cuda")
+        self.recvbuf = torch.zeros(max(1, 5 * part.G * cells), dtype=dtype, device="cuda")
         c = T8gpuHalo()
         c.num_elements, c.num_ghosts, c.n_peers, c.n_send = part.N, part.G, len(self.peers), n_send
+        c.cells_per_element = cells
         c.peers = self.peers.ctypes.data
         c.send_off = self.send_off.ctypes.data
         c.recv_off = self.recv_off.ctypes.data

@@ -88,9 +88,12 @@ class HostSubgridPlan:
         if not h:
             raise ValueError("subgrid plan needs axis-aligned unit normals (as the reference's subgrid kernels do)")
         try:
-            sz = np.zeros(3, np.int64)
+            sz = np.zeros(4, np.int64)
             lib.t8gpu_plan_subgrid_sizes(h, p(sz))
-            self.N, self.rank, self.max_bf = part.N, rank, int(sz[1])
+            self.N, self.rank, self.max_bf, self.n_interior = part.N, rank, int(sz[1]), int(sz[3])
+            lib.t8gpu_plan_subgrid_order.argtypes = [C.c_void_p, C.c_void_p]
+            self.block_order = np.zeros(part.N, np.int32)
+            lib.t8gpu_plan_subgrid_order(h, p(self.block_order))
             self.bf_off = np.zeros(part.N + 1, np.int32)
             self.bf_ent = np.zeros(int(sz[0]), np.int32)
             self.face_rec = np.zeros((int(sz[2]), 4), np.int32)

@@ -232,15 +232,40 @@ class SubgridSolver:
                  self.get_own_variables(self.prev), st, self.get_own_variables(dst), fl, hip.ptr(self.volumes),
                  hip.fscalar(self.dtype, dt), stream)
 
-    def iterate(self, delta_t, stream=None, halo=None):
+    def begin_step(self):
         self.prev, self.next = self.next, self.prev  # solver.inl:154
+
+    def stage_steps(self, k):
+        return (self.prev, STEP1, STEP2)[k], (STEP1, STEP2, self.next)[k]
+
+    def step_planes(self, step):
+        return self.planes[5 * step:5 * step + 5]
+
+    def run_stage(self, k, delta_t, stream=None, halo=None, split=False):
+        """One flux evaluation + RK stage; with a halo exchange (or split=True) the fused kernel runs the
+        blocks that touch no ghost block first and the others after the ghosts have arrived."""
         s = hip.stream_ptr(stream)
-        srcs = (self.prev, STEP1, STEP2)
-        dsts = (STEP1, STEP2, self.next)
-        for k in range(3):
+        src, dst = self.stage_steps(k)
+        if halo is not None:
+            halo.start(self.step_planes(src))
+        if self.mode == "compat":
             if halo is not None:
-                raise NotImplementedError("multi-rank Subgrid runs need block-sized halo messages (next round)")
-            if self.mode == "compat":
-                self._stage_compat(k + 1, srcs[k], dsts[k], delta_t, s)
-            else:
-                self.plan.stage(self, k + 1, srcs[k], dsts[k], delta_t, s)
+                halo.finish()
+            self._stage_compat(k + 1, src, dst, delta_t, s)
+            return
+        ni, nt = self.plan.host.n_interior, self.N
+        if (halo is None and not split) or ni == nt or ni == 0:
+            if halo is not None:
+                halo.finish()
+            self.plan.stage(self, k + 1, src, dst, delta_t, s)
+        else:
+            self.plan.stage(self, k + 1, src, dst, delta_t, s, 0, ni)
+            if halo is not None:
+                halo.finish()
+            self.plan.stage(self, k + 1, src, dst, delta_t, s, ni, nt - ni)
+
+    def iterate(self, delta_t, stream=None, halo=None):
+        """SubgridCompressibleEulerSolver::iterate; `halo` refreshes the ghost blocks of each stage's source."""
+        self.begin_step()
+        for k in range(3):
+            self.run_stage(k, delta_t, stream, halo)

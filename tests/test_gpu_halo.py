@@ -9,7 +9,7 @@ import torch
 
 from _gpu import perturbed_state, rel_err
 from t8gpu_amd.halo import HaloExchange
-from t8gpu_amd.solver import PlainSolver
+from t8gpu_amd.solver import PlainSolver, SubgridSolver
 from t8gpu_amd.synth import SynthMesh
 
 pytestmark = pytest.mark.gpu
@@ -22,8 +22,9 @@ def loopback(halos):
         for j, p in enumerate(h.peers):
             peer = by_rank[p]
             jj = peer.peers.index(h.rank)
-            src = h.sendbuf[5 * h.send_off[j]:5 * h.send_off[j + 1]]
-            dst = peer.recvbuf[5 * peer.recv_off[jj]:5 * peer.recv_off[jj + 1]]
+            w = 5 * h.cells
+            src = h.sendbuf[w * h.send_off[j]:w * h.send_off[j + 1]]
+            dst = peer.recvbuf[w * peer.recv_off[jj]:w * peer.recv_off[jj + 1]]
             assert src.numel() == dst.numel() > 0
             dst.copy_(src)
 
@@ -86,3 +87,46 @@ def test_pack_unpack_kernels_match_numpy():
     h._unpack(planes)
     assert torch.equal(planes[:, :part.N], before[:, :part.N])
     assert torch.equal(planes[:, part.N:], h.recvbuf[:5 * part.G].view(part.G, 5).t())
+
+
+@pytest.mark.parametrize("world", [2, 5])
+@pytest.mark.parametrize("mode", ["fused", "compat"])
+@pytest.mark.parametrize("dim", [3, 2])
+def test_k_way_subgrid_partition_on_one_gpu_equals_single_rank(world, mode, dim):
+    """Ghost BLOCKS (all 16 / 64 subcells mirrored), interior / ghost-touching block split of the fused kernel."""
+    mesh = SynthMesh(dim, 3, 4 if dim == 3 else 6, band=0.03)
+    whole = mesh.partition(subgrid=True)
+    S = 4 ** dim
+    st = perturbed_state(whole, 78)
+    dtype = torch.float64
+    ref = SubgridSolver(whole, dtype, mode=mode, state=st)
+    parts = [mesh.partition(r, world, subgrid=True) for r in range(world)]
+    solvers, halos = [], []
+    for part in parts:
+        blocks = np.concatenate([part.first_global + np.arange(part.N), part.ghost_global])
+        cells = (blocks[:, None] * S + np.arange(S)[None, :]).reshape(-1)
+        local = st[:, cells].copy()
+        local[:, part.N * S:] = np.nan
+        solvers.append(SubgridSolver(part, dtype, mode=mode, state=local))
+        halos.append(HaloExchange(part, dtype, dist=None, overlap=False))
+    if mode == "fused":
+        assert all(0 < s.plan.host.n_interior < s.N for s in solvers)
+    dt = 0.1 * 2.0 ** -(mesh.finest_level + 2)
+    for _ in range(2):
+        ref.iterate(dt)
+        for s in solvers:
+            s.begin_step()
+        for k in range(3):
+            for s, h in zip(solvers, halos):
+                h._pack(s.step_planes(s.stage_steps(k)[0]))
+            loopback(halos)
+            for s, h in zip(solvers, halos):
+                h._unpack(s.step_planes(s.stage_steps(k)[0]))
+            for s in solvers:
+                s.run_stage(k, dt, split=True)
+    torch.cuda.synchronize()
+    full = torch.cat([s.state() for s in solvers], dim=1).cpu().numpy()
+    assert not np.isnan(full).any()
+    assert rel_err(full, ref.state().cpu().numpy()) < 1e-13
+    if mode == "fused":
+        assert np.array_equal(full, ref.state().cpu().numpy())      # same sums in the same order on every rank
