@@ -251,6 +251,35 @@ int t8gpu_hip_integral_f32(size_t num_cells, int cells_per_element, const float*
 int t8gpu_hip_integral_f64(size_t num_cells, int cells_per_element, const double* variable, const double* volume,
                            void* workspace, double* result, void* stream);
 
+/* ---- AMR indicator and data transfer for plain elements ---------------------------------
+ * estimate_gradient<<<>>>: examples/compressible_euler/kernels.cu:471-501 (|rho_r - rho_l| added to both
+ * neighbours; the reference accumulates into its Fluxes/Rho plane, any zeroed plane works). */
+int t8gpu_hip_estimate_gradient_f32(int num_faces, const int32_t* face_neighbors, const int32_t* indices,
+                                    const float* rho, float* gradient, void* stream);
+int t8gpu_hip_estimate_gradient_f64(int num_faces, const int32_t* face_neighbors, const int32_t* indices,
+                                    const double* rho, double* gradient, void* stream);
+/* compute_refinement_criteria<<<>>>: examples/compressible_euler/solver.cu:231-241 (gradient / cbrt(volume)). */
+int t8gpu_hip_refinement_criteria_f32(int num_elements, const float* gradient, const float* volume, float* criteria,
+                                      void* stream);
+int t8gpu_hip_refinement_criteria_f64(int num_elements, const double* gradient, const double* volume, double* criteria,
+                                      void* stream);
+/* adapt_variables_and_volume<<<>>>: t8gpu/mesh/mesh_manager.inl:165-193. adapt_data[n_new+1] = first old element of
+ * each new element (mesh_manager.inl:258-281): equal neighbours = children of a refined element (injection, volume
+ * / 2^dim), difference 2^dim = coarsened family (mean, volume * 2^dim). dim = 3 reproduces the reference's
+ * hard-coded factors 0.125 / 8.0; pass 2 for quad forests. */
+int t8gpu_hip_adapt_variables_and_volume_f32(int num_new_elements, int dim, const int32_t* adapt_data,
+                                             T8gpuVars_f32 old_variables, T8gpuVars_f32 new_variables,
+                                             const float* volume_old, float* volume_new, void* stream);
+int t8gpu_hip_adapt_variables_and_volume_f64(int num_new_elements, int dim, const int32_t* adapt_data,
+                                             T8gpuVars_f64 old_variables, T8gpuVars_f64 new_variables,
+                                             const double* volume_old, double* volume_new, void* stream);
+/* device half of partition_data<<<>>> (mesh_manager.inl:626-643): a contiguous run of elements <-> one message of
+ * 6 planes (5 variables + volume) of n values. */
+int t8gpu_hip_gather_elements_f32(int n, int first, T8gpuVars_f32 variables, const float* volume, float* out, void* stream);
+int t8gpu_hip_gather_elements_f64(int n, int first, T8gpuVars_f64 variables, const double* volume, double* out, void* stream);
+int t8gpu_hip_scatter_elements_f32(int n, int first, const float* in, T8gpuVars_f32 variables, float* volume, void* stream);
+int t8gpu_hip_scatter_elements_f64(int n, int first, const double* in, T8gpuVars_f64 variables, double* volume, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,16 @@ void t8gpu_synth_part_halo(const void* part, int64_t* ghost_global, int32_t* gho
  * `stride` doubles; cells_per_dim = 1 (plain) or 4 (Subgrid<4,..>, index e*S + i + 4j + 16k). */
 void t8gpu_synth_part_kh_ic(const void* part, int cells_per_dim, double* out, size_t stride);
 
+/* ---- adaptation of the synthetic forest (stands where t8_forest adapt + balance run, mesh_manager.inl:196-213) --
+ * marks: the reference's adapt callback (mesh_manager.inl:125-162): +1 refine, -1 coarsen (whole family), 0 keep;
+ * family_members_averaged = 4 reproduces the reference, 0 = all 2^dim members.
+ * adapt: refine / coarsen once + 2:1 balance; returns a new mesh (NULL on failure).
+ * adapt_data[n_new+1]: first old element of every new element (mesh_manager.inl:258-281); returns 0 on success. */
+void  t8gpu_synth_mesh_marks(const void* mesh, const double* criteria, double threshold, int min_level, int max_level,
+                             int family_members_averaged, int8_t* marks);
+void* t8gpu_synth_mesh_adapt(const void* mesh, const int8_t* marks);
+int   t8gpu_synth_mesh_adapt_data(const void* old_mesh, const void* new_mesh, int32_t* adapt_data);
+
 /* ---- tile plan of the fused plain-element kernels --------------------------------------------- */
 void* t8gpu_plan_plain_create(int32_t N, int32_t G, int32_t F, int32_t B, int32_t ndim, const int32_t* face_neighbors,
                               const double* normals, const double* areas, int32_t tmax, int32_t fcap);

@@ -16,6 +16,7 @@
 // vectors parity is UNPINNED and rests on algebraic invariants.
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -615,6 +616,48 @@ void subgrid_iterate(int kind, int rank, int N, int F, int B, const int32_t* fac
     if (B > 0) subgrid_boundary<T>(kind, rank, F, B, face_neighbors, normals, areas, st, fl);
     subgrid_outer<T>(kind, rank, F, face_neighbors, indices, level_diff, nb_offset, normals, areas, st, fl);
     subgrid_rk_stage<T>(s + 1, rank, N, pv, st, ot, fl, volumes, dt);
+  }
+}
+
+// ===========================================================================
+// AMR indicator and data transfer (plain elements).
+// ===========================================================================
+// estimate_gradient, examples/compressible_euler/kernels.cu:471-501.
+template <class T>
+void estimate_gradient(int F, const int32_t* fn, const int32_t* indices, const T* rho, T* gradient) {
+  for (int i = 0; i < F; i++) {
+    int l = fn[2 * static_cast<size_t>(i)], r = fn[2 * static_cast<size_t>(i) + 1];
+    if (indices) {
+      l = indices[l];
+      r = indices[r];
+    }
+    const T g = std::abs(rho[r] - rho[l]);
+    gradient[l] += g;
+    gradient[r] += g;
+  }
+}
+
+// compute_refinement_criteria, examples/compressible_euler/solver.cu:231-241.
+template <class T>
+void refinement_criteria(int N, const T* gradient, const T* volume, T* criteria) {
+  for (int i = 0; i < N; i++) criteria[i] = gradient[i] / std::cbrt(volume[i]);
+}
+
+// adapt_variables_and_volume, t8gpu/mesh/mesh_manager.inl:165-193. The reference's factors are
+// 0.125 / 8.0 whatever the dimension (dim = 3 here); dim = 2 uses 0.25 / 4.0.
+template <class T>
+void adapt_variables_and_volume(int n_new, int dim, const int32_t* adapt_data, const T* const old_v[5], T* const new_v[5],
+                                const T* vol_old, T* vol_new) {
+  const T down = dim == 3 ? T(0.125) : T(0.25), up = dim == 3 ? T(8.0) : T(4.0);
+  for (int i = 0; i < n_new; i++) {
+    const int diff = adapt_data[i + 1] - adapt_data[i];
+    const int nsum = std::max(1, diff);
+    vol_new[i]     = vol_old[adapt_data[i]] * (diff == 0 ? down : (diff == 1 ? T(1.0) : up));
+    if (i > 0 && adapt_data[i - 1] == adapt_data[i]) vol_new[i] = vol_old[adapt_data[i]] * down;
+    for (int k = 0; k < 5; k++) {
+      new_v[k][i] = T(0.0);
+      for (int j = 0; j < nsum; j++) new_v[k][i] += old_v[k][adapt_data[i] + j] / static_cast<T>(nsum);
+    }
   }
 }
 

@@ -142,5 +142,27 @@ extern "C" int oracle_num_threads() {
                        Planes<T>{planes, stride}, volumes, prev, next, dt);                                           \
   }
 
+#define ORACLE_DEFINE_AMR(SUF, T)                                                                                  \
+  extern "C" void oracle_estimate_gradient_##SUF(int F, const int32_t* fn, const int32_t* idx, const T* rho,        \
+                                                 T* gradient) {                                                     \
+    estimate_gradient<T>(F, fn, idx, rho, gradient);                                                                \
+  }                                                                                                                 \
+  extern "C" void oracle_refinement_criteria_##SUF(int N, const T* gradient, const T* volume, T* criteria) {        \
+    refinement_criteria<T>(N, gradient, volume, criteria);                                                          \
+  }                                                                                                                 \
+  extern "C" void oracle_adapt_variables_and_volume_##SUF(int n_new, int dim, const int32_t* adapt_data,            \
+                                                          const T* old_planes, size_t old_stride, T* new_planes,    \
+                                                          size_t new_stride, const T* vol_old, T* vol_new) {        \
+    const T* ov[5];                                                                                                 \
+    T*       nv[5];                                                                                                 \
+    for (int k = 0; k < 5; k++) {                                                                                   \
+      ov[k] = old_planes + k * old_stride;                                                                          \
+      nv[k] = new_planes + k * new_stride;                                                                          \
+    }                                                                                                               \
+    adapt_variables_and_volume<T>(n_new, dim, adapt_data, ov, nv, vol_old, vol_new);                                \
+  }
+ORACLE_DEFINE_AMR(f32, float)
+ORACLE_DEFINE_AMR(f64, double)
+
 ORACLE_DEFINE(f32, float)
 ORACLE_DEFINE(f64, double)

@@ -419,4 +419,169 @@ void t8gpu_synth_part_kh_ic(const void* h, int cells_per_dim, double* out, size_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Adaptation of the synthetic forest (stands where t8_forest adapt + balance run in
+// MeshManager::adapt, t8gpu/mesh/mesh_manager.inl:196-213).
+//
+// t8gpu_synth_mesh_marks: the reference's adapt callback (mesh_manager.inl:125-162) applied to every
+// element: +1 (refine) if level < max_level and criteria > threshold; -1 (coarsen) for ALL members of a
+// complete family if level > min_level and the mean criterion is < threshold. The reference averages only
+// the first 4 members even for 8-child families; `family_members_averaged` = 4
+// reproduces that, 0 means "all 2^dim members".
+// t8gpu_synth_mesh_adapt: new forest = old forest with marked elements refined once, marked complete
+// families coarsened once, then 2:1 face balance (refinement wins over coarsening, as t8code's
+// adapt-then-balance does). Every element changes by at most one level.
+// t8gpu_synth_mesh_adapt_data: the old->new correspondence of mesh_manager.inl:258-281:
+// adapt_data[i] = first old element of new element i (n_new + 1 entries).
+// ---------------------------------------------------------------------------------------------------
+static bool is_family_start(const Mesh& M, size_t e) {
+  const int nsub = 1 << M.dim;
+  if (e + nsub > M.leaves.size()) return false;
+  const Leaf& a = M.leaves[e];
+  if (a.level == 0) return false;
+  for (int d = 0; d < M.dim; d++)
+    if (a.c[d] & 1u) return false;  // must be child 0
+  for (int ch = 0; ch < nsub; ch++) {
+    const Leaf& b = M.leaves[e + ch];
+    if (b.level != a.level) return false;
+    for (int d = 0; d < M.dim; d++)
+      if (b.c[d] != a.c[d] + ((ch >> d) & 1)) return false;
+  }
+  return true;
+}
+
+void t8gpu_synth_mesh_marks(const void* mesh, const double* criteria, double threshold, int min_level, int max_level,
+                            int family_members_averaged, int8_t* marks) {
+  const Mesh&  M    = *static_cast<const Mesh*>(mesh);
+  const size_t n    = M.leaves.size();
+  const int    nsub = 1 << M.dim;
+  const int    navg = family_members_averaged > 0 ? std::min(family_members_averaged, nsub) : nsub;
+  std::fill(marks, marks + n, static_cast<int8_t>(0));
+  // t8code calls the callback element by element; with is_family = 1 only when the element opens a
+  // complete family. Refinement is tested first and on the element's own criterion only; -1 coarsens
+  // the whole family and skips its other members.
+  for (size_t e = 0; e < n;) {
+    const Leaf& l   = M.leaves[e];
+    const bool  fam = is_family_start(M, e);
+    if (l.level < max_level && criteria[e] > threshold) {
+      marks[e++] = 1;
+      continue;
+    }
+    if (l.level > min_level && fam) {
+      double mean = 0;
+      for (int ch = 0; ch < navg; ch++) mean += criteria[e + ch] / navg;
+      if (mean < threshold) {
+        for (int ch = 0; ch < nsub; ch++) marks[e + ch] = -1;
+        e += nsub;
+        continue;
+      }
+    }
+    e++;
+  }
+}
+
+void* t8gpu_synth_mesh_adapt(const void* mesh, const int8_t* marks) {
+  const Mesh& O    = *static_cast<const Mesh*>(mesh);
+  const int   nsub = 1 << O.dim;
+  Mesh*       M    = new Mesh;
+  M->dim = O.dim; M->base = O.base; M->band = O.band; M->shrink = O.shrink; M->periodic = O.periodic;
+  // the finest-level lookup grid is sized for lmax: refining a finest leaf needs one more level
+  int newmax = O.lmax;
+  for (size_t e = 0; e < O.leaves.size(); e++)
+    if (marks[e] > 0 && O.leaves[e].level + 1 > newmax) newmax = O.leaves[e].level + 1;
+  if (O.dim * newmax > 28) {
+    delete M;
+    return nullptr;
+  }
+  M->lmax = newmax;
+  // 1. refinements and tentative coarsenings; `origin` remembers how each new leaf was made:
+  //    0 kept, 1 refined child, 2 coarsened parent (can be undone by the balance step)
+  std::vector<uint8_t> origin;
+  for (size_t e = 0; e < O.leaves.size();) {
+    const Leaf& l = O.leaves[e];
+    if (marks[e] < 0 && is_family_start(O, e)) {
+      bool all = true;
+      for (int ch = 0; ch < nsub; ch++) all = all && marks[e + ch] < 0;
+      if (all) {
+        Leaf p;
+        p.level = l.level - 1;
+        for (int d = 0; d < 3; d++) p.c[d] = l.c[d] >> 1;
+        M->leaves.push_back(p);
+        origin.push_back(2);
+        e += nsub;
+        continue;
+      }
+    }
+    if (marks[e] > 0) {
+      M->push_children(M->leaves, l);
+      origin.insert(origin.end(), nsub, 1);
+    } else {
+      M->leaves.push_back(l);
+      origin.push_back(0);
+    }
+    e++;
+  }
+  M->fill_owner();
+  // 2. balance: a leaf two or more levels coarser than a face neighbour is split. A leaf made by
+  //    coarsening goes back to its children (net change 0); a kept leaf is refined once (net +1).
+  for (;;) {
+    std::vector<uint8_t> mark(M->leaves.size(), 0);
+    bool                 any = false;
+    for (size_t e = 0; e < M->leaves.size(); e++)
+      for (int f = 0; f < 2 * M->dim; f++) {
+        const int32_t nb = M->across(e, f);
+        if (nb >= 0 && M->leaves[nb].level < M->leaves[e].level - 1) {
+          mark[nb] = 1;
+          any      = true;
+        }
+      }
+    if (!any) break;
+    std::vector<Leaf>    next;
+    std::vector<uint8_t> norigin;
+    for (size_t e = 0; e < M->leaves.size(); e++) {
+      if (mark[e]) {
+        M->push_children(next, M->leaves[e]);
+        norigin.insert(norigin.end(), nsub, origin[e] == 2 ? 0 : 1);
+      } else {
+        next.push_back(M->leaves[e]);
+        norigin.push_back(origin[e]);
+      }
+    }
+    M->leaves.swap(next);
+    origin.swap(norigin);
+    M->fill_owner();
+  }
+  return M;
+}
+
+int t8gpu_synth_mesh_adapt_data(const void* old_mesh, const void* new_mesh, int32_t* adapt_data) {
+  const Mesh&  O = *static_cast<const Mesh*>(old_mesh);
+  const Mesh&  N = *static_cast<const Mesh*>(new_mesh);
+  const int    nsub = 1 << O.dim;
+  size_t       oi = 0, ni = 0;
+  const size_t no = O.leaves.size(), nn = N.leaves.size();
+  while (oi < no && ni < nn) {
+    const int lo = O.leaves[oi].level, ln = N.leaves[ni].level;
+    if (lo < ln) {  // refined: nsub children point at the same old element
+      if (ln != lo + 1 || ni + nsub > nn) return 1;
+      for (int i = 0; i < nsub; i++) adapt_data[ni + i] = static_cast<int32_t>(oi);
+      oi += 1;
+      ni += nsub;
+    } else if (lo > ln) {  // coarsened
+      if (lo != ln + 1 || oi + nsub > no) return 1;
+      adapt_data[ni] = static_cast<int32_t>(oi);
+      oi += nsub;
+      ni += 1;
+    } else {
+      adapt_data[ni] = static_cast<int32_t>(oi);
+      oi += 1;
+      ni += 1;
+    }
+  }
+  if (oi != no || ni != nn) return 1;
+  adapt_data[nn] = static_cast<int32_t>(no);
+  return 0;
+}
+
 }  // extern "C"

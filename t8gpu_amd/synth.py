@@ -26,6 +26,11 @@ def lib():
         _lib.t8gpu_synth_part_elements.argtypes = [C.c_void_p] + [C.c_void_p] * 3
         _lib.t8gpu_synth_part_halo.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         _lib.t8gpu_synth_part_kh_ic.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        _lib.t8gpu_synth_mesh_marks.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _lib.t8gpu_synth_mesh_adapt.restype = C.c_void_p
+        _lib.t8gpu_synth_mesh_adapt.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.t8gpu_synth_mesh_adapt_data.restype = C.c_int
+        _lib.t8gpu_synth_mesh_adapt_data.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -51,6 +56,34 @@ class SynthMesh:
 
     def partition(self, rank=0, nranks=1, subgrid=False, normal_dim=None):
         return Partition(self, rank, nranks, subgrid, normal_dim)
+
+    # -- adaptation (MeshManager::adapt without the data transfer, which runs on the device) --------
+    def marks_from_criteria(self, criteria, threshold, min_level, max_level, family_members_averaged=4):
+        """The reference's adapt callback for every element: +1 refine, -1 coarsen, 0 keep."""
+        crit = np.ascontiguousarray(criteria, np.float64)
+        assert crit.size == self.num_elements
+        marks = np.zeros(self.num_elements, np.int8)
+        lib().t8gpu_synth_mesh_marks(self._h, _p(crit), float(threshold), int(min_level), int(max_level),
+                                     int(family_members_averaged), _p(marks))
+        return marks
+
+    def adapt(self, marks):
+        """Returns (new mesh, adapt_data[n_new + 1]); every element changes by at most one level."""
+        marks = np.ascontiguousarray(marks, np.int8)
+        assert marks.size == self.num_elements
+        h = lib().t8gpu_synth_mesh_adapt(self._h, _p(marks))
+        if not h:
+            raise ValueError("adaptation exceeds the finest representable level")
+        new = object.__new__(SynthMesh)
+        new.dim, new.base_level = self.dim, self.base_level
+        new._h = h
+        new.num_elements = lib().t8gpu_synth_mesh_num_elements(h)
+        new.finest_level = lib().t8gpu_synth_mesh_finest_level(h)
+        new.max_level = max(self.max_level, new.finest_level)
+        adapt_data = np.zeros(new.num_elements + 1, np.int32)
+        if lib().t8gpu_synth_mesh_adapt_data(self._h, h, _p(adapt_data)) != 0:
+            raise RuntimeError("old and new forests are not one refinement / coarsening step apart")
+        return new, adapt_data
 
 
 class Partition:

@@ -1,0 +1,108 @@
+"""-m gpu: SURVEY 8f-3 -- AMR indicator, data-transfer kernel and the adapt loop against the CPU oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import _oracle as O
+from _gpu import NP, TOL10, perturbed_state, rel_err
+from t8gpu_amd import amr, hip
+from t8gpu_amd.solver import PlainSolver
+from t8gpu_amd.synth import SynthMesh
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_indicator_kernels_vs_oracle(dtype):
+    mesh = SynthMesh(2, 3, 6, band=0.06)
+    part = mesh.partition()
+    st = perturbed_state(part, 3)
+    g = PlainSolver(part, dtype, state=st)
+    crit = amr.refinement_criteria(g).cpu().numpy()
+    npdt = NP[dtype]
+    rho = st[0].astype(npdt)
+    grad = np.zeros(part.N, npdt)
+    sf = O.suf(npdt)
+    getattr(O.lib(), "oracle_estimate_gradient_" + sf)(part.F, O.p(part.face_neighbors), None, O.p(rho), O.p(grad))
+    want = np.zeros(part.N, npdt)
+    vol = part.volumes.astype(npdt)
+    getattr(O.lib(), "oracle_refinement_criteria_" + sf)(part.N, O.p(grad), O.p(vol), O.p(want))
+    assert np.abs(crit - want).max() <= (1e-12 if dtype == torch.float64 else 1e-4) * np.abs(want).max()
+    assert (g.planes[20, :part.N] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("dim", [2, 3])
+def test_transfer_kernel_vs_oracle_and_conservation(dtype, dim):
+    mesh = SynthMesh(dim, 3, 5 if dim == 2 else 4, band=0.06)
+    part = mesh.partition()
+    rng = np.random.default_rng(5)
+    x = part.centres[:part.N, 0]
+    marks = np.where(x < 0.5, -1, np.where(x > 0.75, rng.integers(0, 2, part.N), 0)).astype(np.int8)   # coarsen left, refine right
+    new_mesh, ad = mesh.adapt(marks)
+    assert set(np.unique(np.diff(ad))) >= {0, 1, 2 ** dim}
+    new_part = new_mesh.partition()
+    npdt = NP[dtype]
+    st = perturbed_state(part, 8).astype(npdt)
+    vol = part.volumes.astype(npdt)
+    old = torch.from_numpy(np.vstack([st, vol[None]])).cuda().contiguous()
+    new = torch.zeros((6, new_part.N), dtype=dtype, device="cuda")
+    dad = torch.from_numpy(ad).cuda()
+    hip.call("t8gpu_hip_adapt_variables_and_volume", dtype, new_part.N, dim, hip.ptr(dad), hip.vars_of(old), hip.vars_of(new),
+             hip.ptr(old[5]), hip.ptr(new[5]), hip.stream_ptr())
+    torch.cuda.synchronize()
+    got = new.cpu().numpy()
+    want = np.zeros((5, new_part.N), npdt)
+    wvol = np.zeros(new_part.N, npdt)
+    getattr(O.lib(), "oracle_adapt_variables_and_volume_" + O.suf(npdt))(new_part.N, dim, O.p(ad), O.p(st), C.c_size_t(part.N),
+                                                                           O.p(want), C.c_size_t(new_part.N), O.p(vol), O.p(wvol))
+    assert np.array_equal(got[:5], want) and np.array_equal(got[5], wvol)       # same operation order: bit-exact
+    assert np.allclose(got[5], new_part.volumes, rtol=1e-6)                      # the transferred volumes ARE the new cells' volumes
+    m_old = (st.astype(np.float64) * part.volumes).sum(1)
+    m_new = (got[:5].astype(np.float64) * new_part.volumes).sum(1)
+    assert np.abs(m_new - m_old).max() < (1e-13 if dtype == torch.float64 else 1e-6) * np.abs(m_old).max()
+
+
+def test_adaptive_run_follows_the_oracle():
+    """iterate / adapt / iterate ... on the device vs the same sequence with the oracle's kernels on the host."""
+    mesh = SynthMesh(2, 4, 6, band=0.03)
+    part = mesh.partition()
+    g = PlainSolver(part, torch.float64, mode="fused")
+    g.use_native_stepper()
+    o = O.PlainCase(part, np.float64)
+    m0 = g.compute_integral(0)
+    sizes = [part.N]
+    for cycle in range(3):
+        dt = 0.1 * 2.0 ** -g.part.mesh.finest_level
+        for _ in range(5):
+            g.iterate(dt)
+            o.iterate(dt)
+        # device adapt
+        g, marks, ad = amr.adapt(g, threshold=10.0, min_level=3, max_level=7)
+        # host adapt with the oracle's kernels on the oracle's state
+        opart = o.part
+        rho = o.current()[0, :opart.N].copy()
+        grad = np.zeros(opart.N)
+        O.lib().oracle_estimate_gradient_f64(opart.F, O.p(opart.face_neighbors), None, O.p(rho), O.p(grad))
+        crit = np.zeros(opart.N)
+        O.lib().oracle_refinement_criteria_f64(opart.N, O.p(grad), O.p(opart.volumes), O.p(crit))
+        omarks = opart.mesh.marks_from_criteria(crit, 10.0, 3, 7)
+        assert np.array_equal(omarks, marks)                                      # same decisions on both sides
+        nmesh, oad = opart.mesh.adapt(omarks)
+        npart = nmesh.partition()
+        cur = np.ascontiguousarray(o.current()[:, :opart.N])
+        nst = np.zeros((5, npart.N))
+        nvol = np.zeros(npart.N)
+        O.lib().oracle_adapt_variables_and_volume_f64(npart.N, 2, O.p(oad), O.p(cur), C.c_size_t(opart.N), O.p(nst), C.c_size_t(npart.N),
+                                                      O.p(opart.volumes), O.p(nvol))
+        nxt, prv = o.next, o.prev
+        o = O.PlainCase(npart, np.float64, state=np.zeros((5, npart.N)))
+        o.next, o.prev = nxt, prv
+        o.planes[5 * o.next:5 * o.next + 5, :npart.N] = nst
+        sizes.append(npart.N)
+        assert g.N == npart.N
+        assert rel_err(g.state().cpu().numpy(), o.current()[:, :npart.N]) < TOL10[torch.float64]
+    assert len(set(sizes)) > 1                                                     # the mesh really changed
+    assert abs(g.compute_integral(0) - m0) < 1e-12 * abs(m0)                       # mass conserved through adapt cycles

@@ -95,3 +95,35 @@ def test_kh_initial_state_values():
     assert np.allclose(u[4], 2.5 / 0.4 + 0.5 * (u[1] ** 2 + u[2] ** 2) / u[0])
     ps = m.partition(subgrid=True)
     assert ps.kh_initial_state().shape == (5, ps.N * 16)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_adapt_refine_coarsen_balance_and_correspondence(dim):
+    """Host half of MeshManager::adapt (mesh_manager.inl:196-281): callback marks, one-level changes, 2:1 balance,
+    adapt_data = first old element of every new element."""
+    m = SynthMesh(dim, 2, 4, band=0.06)
+    p = m.partition()
+    nsub = 2 ** dim
+    # refine everything once, then coarsen everything once: back to the original forest
+    up, ad_up = m.adapt(np.ones(m.num_elements, np.int8))
+    assert up.num_elements == nsub * m.num_elements and (np.diff(ad_up).reshape(-1, nsub)[:, :-1] == 0).all()
+    down, ad_down = up.adapt(-np.ones(up.num_elements, np.int8))
+    assert down.num_elements == m.num_elements and (np.diff(ad_down) == nsub).all()
+    assert np.array_equal(down.partition().levels, p.levels) and np.allclose(down.partition().centres, p.centres)
+    # criteria-driven marks: > threshold refines (below max level), families with a small mean coarsen (above min level)
+    crit = np.where(p.centres[:p.N, 0] < 0.5, 20.0, 0.0)
+    marks = m.marks_from_criteria(crit, 10.0, 2, 4)
+    lv = p.levels[:p.N]
+    assert ((marks == 1) == ((crit > 10) & (lv < 4))).all()
+    assert (marks[(crit < 10) & (lv == 2)] == 0).all() and (marks == -1).any()
+    new, ad = m.adapt(marks)
+    q = new.partition()
+    l, r = q.face_neighbors[0::2], q.face_neighbors[1::2]
+    assert np.abs(q.levels[l] - q.levels[r]).max() <= 1                       # still 2:1 balanced
+    assert np.abs(q.levels[:q.N] - lv[ad[:-1]]).max() <= 1                     # one level per adapt
+    assert (np.diff(ad) >= 0).all() and ad[0] == 0 and ad[-1] == m.num_elements
+    assert set(np.unique(np.diff(ad))) <= {0, 1, nsub} and np.isclose(q.volumes.sum(), 1.0)
+    # quirk Q5: the reference averages only the first 4 members of a family
+    fam = np.zeros(up.num_elements)
+    fam[np.arange(up.num_elements) % nsub >= 4] = 1000.0
+    assert (up.marks_from_criteria(fam, 10.0, 0, 9, family_members_averaged=4)[np.arange(up.num_elements) % nsub < 4] == -1).all() or dim == 2
