@@ -46,6 +46,8 @@ void t8gpu_synth_part_kh_ic(const void* part, int cells_per_dim, double* out, si
  * adapt_data[n_new+1]: first old element of every new element (mesh_manager.inl:258-281); returns 0 on success. */
 void  t8gpu_synth_mesh_marks(const void* mesh, const double* criteria, double threshold, int min_level, int max_level,
                              int family_members_averaged, int8_t* marks);
+/* clears the -1 marks of families cut by a partition offset (a family is only coarsened on one process) */
+void  t8gpu_synth_mesh_unmark_split_families(const void* mesh, int8_t* marks, const int64_t* offsets, int n_offsets);
 void* t8gpu_synth_mesh_adapt(const void* mesh, const int8_t* marks);
 int   t8gpu_synth_mesh_adapt_data(const void* old_mesh, const void* new_mesh, int32_t* adapt_data);
 

@@ -48,3 +48,105 @@ def adapt(solver, threshold=10.0, min_level=1, max_level=4, family_members_avera
     if getattr(solver, "stepper", None) is not None:
         new.use_native_stepper()
     return new, marks, adapt_data
+
+
+class PartitionedAdapt:
+    """adapt() + partition() for an SFC-partitioned plain-element run (MeshManager::adapt followed by
+    MeshManager::partition, t8gpu/mesh/mesh_manager.inl:196-330, 645-723), one rank per GPU.
+
+    Every rank holds the (cheap) forest description, so the forest operations are replicated and only the
+    element payloads travel: each rank adapts its own elements on the device, then ships contiguous runs of
+    the adapted elements (5 variables + volume, one message per destination) to their owners in the new
+    equal split -- the reference instead lets the new owner PULL through CUDA-IPC pointers
+    (partition_data<<<>>>, mesh_manager.inl:626-643). Split in prepare / transport / finish so that the
+    transport can be RCCL (torch.distributed P2P), gloo (CPU tests) or a loopback (one-GPU tests).
+    """
+
+    def __init__(self, solver, all_criteria, threshold=10.0, min_level=1, max_level=4, family_members_averaged=4):
+        part = solver.part
+        self.solver, self.rank, self.world = solver, part.rank, part.nranks
+        mesh = part.mesh
+        old_off = mesh.partition_offsets(self.world)
+        marks = mesh.marks_from_criteria(all_criteria, threshold, min_level, max_level, family_members_averaged)
+        marks = mesh.unmark_split_families(marks, old_off[1:-1])
+        self.marks = marks
+        self.new_mesh, adapt_data = mesh.adapt(marks)
+        n_new = self.new_mesh.num_elements
+        # new elements made from rank p's old elements: [have_off[p], have_off[p+1])
+        self.have_off = np.searchsorted(adapt_data[:-1], old_off, side="left").astype(np.int64)
+        self.have_off[-1] = n_new
+        self.new_off = self.new_mesh.partition_offsets(self.world)
+        a, b = int(self.have_off[self.rank]), int(self.have_off[self.rank + 1])
+        self.n_have = b - a
+        dtype, dev = solver.dtype, solver.planes.device
+        # 1. local data transfer (adapt_variables_and_volume) into 6 temporary planes
+        self.tmp = torch.zeros((6, max(1, self.n_have)), dtype=dtype, device=dev)
+        ad_local = torch.from_numpy((adapt_data[a:b + 1] - old_off[self.rank]).astype(np.int32)).to(dev)
+        if self.n_have:
+            if dev.type == "cuda":
+                hip.call("t8gpu_hip_adapt_variables_and_volume", dtype, self.n_have, mesh.dim, hip.ptr(ad_local),
+                         solver.get_own_variables(solver.next), hip.vars_of(self.tmp), hip.ptr(solver.planes[25]),
+                         hip.ptr(self.tmp[5]), hip.stream_ptr())
+            else:
+                raise hip.T8gpuHipError("the data transfer kernel needs a GPU")
+        # 2. the new partition and an empty solver for it
+        self.new_part = self.new_mesh.partition(self.rank, self.world, subgrid=False, normal_dim=part.normal_dim)
+        self.new_solver = PlainSolver(self.new_part, dtype, flux_kind=solver.kind, mode=solver.mode,
+                                      state=np.zeros((5, self.new_part.N + self.new_part.G)))
+        self.new_solver.next, self.new_solver.prev = solver.next, solver.prev
+        # 3. message plan: intersections of what I have with what every rank will own (and vice versa)
+        self.sends, self.recvs = [], []
+        lo_r, hi_r = int(self.new_off[self.rank]), int(self.new_off[self.rank + 1])
+        for q in range(self.world):
+            s0, s1 = max(a, int(self.new_off[q])), min(b, int(self.new_off[q + 1]))
+            if s1 > s0:
+                self.sends.append((q, s0 - a, s1 - s0))                  # (peer, first in tmp, count)
+            r0, r1 = max(int(self.have_off[q]), lo_r), min(int(self.have_off[q + 1]), hi_r)
+            if r1 > r0:
+                self.recvs.append((q, r0 - lo_r, r1 - r0))               # (peer, first in the new planes, count)
+        self.sendbufs = {q: torch.empty(6 * n, dtype=dtype, device=dev) for q, _, n in self.sends if q != self.rank}
+        self.recvbufs = {q: torch.empty(6 * n, dtype=dtype, device=dev) for q, _, n in self.recvs if q != self.rank}
+        s = hip.stream_ptr()
+        for q, first, n in self.sends:
+            if q != self.rank:
+                hip.call("t8gpu_hip_gather_elements", dtype, n, first, hip.vars_of(self.tmp), hip.ptr(self.tmp[5]),
+                         hip.ptr(self.sendbufs[q]), s)
+
+    def transport(self, dist):
+        ops = []
+        for q, _, n in self.recvs:
+            if q != self.rank:
+                ops.append(dist.P2POp(dist.irecv, self.recvbufs[q], q))
+        for q, _, n in self.sends:
+            if q != self.rank:
+                ops.append(dist.P2POp(dist.isend, self.sendbufs[q], q))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+    def finish(self):
+        new, dtype = self.new_solver, self.solver.dtype
+        s = hip.stream_ptr()
+        nv = new.get_own_variables(new.next)
+        for q, first, n in self.recvs:
+            if q == self.rank:       # stays here: straight from the temporary planes
+                src_first = [f for p, f, m in self.sends if p == self.rank][0]
+                new.planes[5 * new.next:5 * new.next + 5, first:first + n] = self.tmp[0:5, src_first:src_first + n]
+                new.planes[25, first:first + n] = self.tmp[5, src_first:src_first + n]
+            else:
+                hip.call("t8gpu_hip_scatter_elements", dtype, n, first, hip.ptr(self.recvbufs[q]), nv, hip.ptr(new.planes[25]), s)
+        torch.cuda.synchronize()
+        return new
+
+
+def adapt_partitioned(solver, dist, **kw):
+    """Collective: every rank calls it with its own solver; returns the rank's new solver."""
+    crit = refinement_criteria(solver).double()
+    world = solver.part.nranks
+    sizes = [int(solver.part.mesh.partition_offsets(world)[r + 1] - solver.part.mesh.partition_offsets(world)[r]) for r in range(world)]
+    chunks = [torch.empty(n, dtype=torch.float64, device=crit.device) for n in sizes]
+    dist.all_gather(chunks, crit)
+    all_crit = torch.cat(chunks).cpu().numpy()
+    pa = PartitionedAdapt(solver, all_crit, **kw)
+    pa.transport(dist)
+    return pa.finish()

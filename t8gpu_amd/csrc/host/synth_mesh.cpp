@@ -481,6 +481,23 @@ void t8gpu_synth_mesh_marks(const void* mesh, const double* criteria, double thr
   }
 }
 
+// A family whose members live on two ranks is not coarsened (t8code only coarsens families that are
+// complete on one process): clear the -1 marks of families cut by a partition offset.
+void t8gpu_synth_mesh_unmark_split_families(const void* mesh, int8_t* marks, const int64_t* offsets, int n_offsets) {
+  const Mesh&   M    = *static_cast<const Mesh*>(mesh);
+  const int64_t n    = static_cast<int64_t>(M.leaves.size());
+  const int     nsub = 1 << M.dim;
+  for (int k = 0; k < n_offsets; k++) {
+    const int64_t b = offsets[k];
+    if (b <= 0 || b >= n || marks[b] >= 0 || marks[b - 1] >= 0) continue;
+    for (int64_t s = std::max<int64_t>(0, b - nsub + 1); s < b; s++)
+      if (is_family_start(M, static_cast<size_t>(s)) && s + nsub > b) {
+        for (int ch = 0; ch < nsub; ch++) marks[s + ch] = 0;
+        break;
+      }
+  }
+}
+
 void* t8gpu_synth_mesh_adapt(const void* mesh, const int8_t* marks) {
   const Mesh& O    = *static_cast<const Mesh*>(mesh);
   const int   nsub = 1 << O.dim;

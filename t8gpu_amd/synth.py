@@ -27,6 +27,7 @@ def lib():
         _lib.t8gpu_synth_part_halo.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         _lib.t8gpu_synth_part_kh_ic.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         _lib.t8gpu_synth_mesh_marks.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _lib.t8gpu_synth_mesh_unmark_split_families.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib.t8gpu_synth_mesh_adapt.restype = C.c_void_p
         _lib.t8gpu_synth_mesh_adapt.argtypes = [C.c_void_p, C.c_void_p]
         _lib.t8gpu_synth_mesh_adapt_data.restype = C.c_int
@@ -65,6 +66,17 @@ class SynthMesh:
         marks = np.zeros(self.num_elements, np.int8)
         lib().t8gpu_synth_mesh_marks(self._h, _p(crit), float(threshold), int(min_level), int(max_level),
                                      int(family_members_averaged), _p(marks))
+        return marks
+
+    def partition_offsets(self, nranks):
+        """first global element of every rank (+ the total): the SFC-contiguous equal split used by partition()."""
+        n = self.num_elements
+        return np.array([(n * r) // nranks for r in range(nranks + 1)], np.int64)
+
+    def unmark_split_families(self, marks, offsets):
+        marks = np.ascontiguousarray(marks, np.int8)
+        off = np.ascontiguousarray(offsets, np.int64)
+        lib().t8gpu_synth_mesh_unmark_split_families(self._h, _p(marks), _p(off), int(off.size))
         return marks
 
     def adapt(self, marks):

@@ -106,3 +106,44 @@ def test_adaptive_run_follows_the_oracle():
         assert rel_err(g.state().cpu().numpy(), o.current()[:, :npart.N]) < TOL10[torch.float64]
     assert len(set(sizes)) > 1                                                     # the mesh really changed
     assert abs(g.compute_integral(0) - m0) < 1e-12 * abs(m0)                       # mass conserved through adapt cycles
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_partitioned_adapt_and_repartition_equals_single_rank(world):
+    """k ranks on one GPU (loopback transport): criteria all-gathered, families cut by a rank boundary kept,
+    local transfer, element runs shipped to their owners in the new equal split."""
+    mesh = SynthMesh(2, 4, 6, band=0.03)
+    whole = mesh.partition()
+    st = perturbed_state(whole, 12)
+    st[0] += 1.0 * (np.abs(whole.centres[:, 0] - 0.3) < 0.1)          # a density bump: refinement away from the KH layers too
+    st[4] += 0.5
+    ref = PlainSolver(whole, torch.float64, mode="fused", state=st)
+    parts = [mesh.partition(r, world) for r in range(world)]
+    solvers = []
+    for part in parts:
+        gidx = np.concatenate([part.first_global + np.arange(part.N), part.ghost_global])
+        solvers.append(PlainSolver(part, torch.float64, mode="fused", state=st[:, gidx]))
+    kw = dict(threshold=10.0, min_level=3, max_level=7)
+    crits = [amr.refinement_criteria(s).double().cpu().numpy() for s in solvers]
+    all_crit = np.concatenate(crits)
+    ref_crit = amr.refinement_criteria(ref).double().cpu().numpy()
+    assert np.allclose(all_crit, ref_crit, rtol=1e-12, atol=1e-12)         # ghost values are current: same indicator
+    pas = [amr.PartitionedAdapt(s, all_crit, **kw) for s in solvers]
+    by_rank = {p.rank: p for p in pas}
+    for p in pas:                                                         # loopback transport
+        for q, _, n in p.sends:
+            if q != p.rank:
+                by_rank[q].recvbufs[p.rank].copy_(p.sendbufs[q])
+    news = [p.finish() for p in pas]
+    # reference: single-rank adapt with the same (split-family-aware) marks
+    new_mesh, ad = mesh.adapt(pas[0].marks)
+    npart = new_mesh.partition()
+    want = torch.zeros((6, npart.N), dtype=torch.float64, device="cuda")
+    hip.call("t8gpu_hip_adapt_variables_and_volume", torch.float64, npart.N, 2, hip.ptr(torch.from_numpy(ad).cuda()),
+             ref.get_own_variables(ref.next), hip.vars_of(want), hip.ptr(ref.planes[25]), hip.ptr(want[5]), hip.stream_ptr())
+    torch.cuda.synchronize()
+    got = torch.cat([n.state() for n in news], dim=1)
+    gvol = torch.cat([n.planes[25, :n.N] for n in news])
+    assert sum(n.N for n in news) == npart.N and max(n.N for n in news) - min(n.N for n in news) <= 1   # balanced again
+    assert torch.equal(got, want[:5]) and torch.equal(gvol, want[5])
+    assert any(len(p.sends) > 1 for p in pas)                              # elements really changed owner
