@@ -280,6 +280,22 @@ int t8gpu_hip_gather_elements_f64(int n, int first, T8gpuVars_f64 variables, con
 int t8gpu_hip_scatter_elements_f32(int n, int first, const float* in, T8gpuVars_f32 variables, float* volume, void* stream);
 int t8gpu_hip_scatter_elements_f64(int n, int first, const double* in, T8gpuVars_f64 variables, double* volume, void* stream);
 
+/* ---- AMR indicator and data transfer for Subgrid<4,4> / Subgrid<4,4,4> blocks -------------
+ * compute_refinement_criteria<Subgrid><<<>>>: examples/subgrid/kernels.inl:1110-1168 (discrete H1 seminorm of the
+ * density inside a block / block volume). */
+int t8gpu_hip_subgrid_refinement_criteria_f32(int rank, int num_elements, const float* rho, const float* volumes,
+                                              float* criteria, void* stream);
+int t8gpu_hip_subgrid_refinement_criteria_f64(int rank, int num_elements, const double* rho, const double* volumes,
+                                              double* criteria, void* stream);
+/* adapt_variables<Subgrid><<<>>> + adapt_volume<Subgrid><<<>>>: t8gpu/mesh/subgrid_mesh_manager.inl:246-425
+ * (refined block: injection from the parent's octant; coarsened block: mean of the 2^rank fine cells). */
+int t8gpu_hip_subgrid_adapt_variables_and_volume_f32(int rank, int num_new_elements, const int32_t* adapt_data,
+                                                     T8gpuVars_f32 old_variables, T8gpuVars_f32 new_variables,
+                                                     const float* volume_old, float* volume_new, void* stream);
+int t8gpu_hip_subgrid_adapt_variables_and_volume_f64(int rank, int num_new_elements, const int32_t* adapt_data,
+                                                     T8gpuVars_f64 old_variables, T8gpuVars_f64 new_variables,
+                                                     const double* volume_old, double* volume_new, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -661,4 +661,63 @@ void adapt_variables_and_volume(int n_new, int dim, const int32_t* adapt_data, c
   }
 }
 
+// compute_refinement_criteria<Subgrid>, examples/subgrid/kernels.inl:1110-1168.
+template <class T>
+void subgrid_refinement_criteria(int rank, int N, const T* rho, const T* volumes, T* criteria) {
+  const int S = sg_size(rank), nz = rank == 3 ? E : 1;
+  for (int e = 0; e < N; e++) {
+    const T* d   = rho + static_cast<size_t>(e) * S;
+    const T  h   = (rank == 3 ? std::cbrt(volumes[e]) : std::sqrt(volumes[e])) / static_cast<T>(E);
+    T        acc = T{0.0};
+    for (int p = 0; p < E - 1; p++)
+      for (int q = 0; q < E; q++)
+        for (int r = 0; r < nz; r++) acc += (d[p + 1 + 4 * q + 16 * r] - d[p + 4 * q + 16 * r]) * (d[p + 1 + 4 * q + 16 * r] - d[p + 4 * q + 16 * r]) * h;
+    for (int p = 0; p < E; p++)
+      for (int q = 0; q < E - 1; q++)
+        for (int r = 0; r < nz; r++) acc += (d[p + 4 * (q + 1) + 16 * r] - d[p + 4 * q + 16 * r]) * (d[p + 4 * (q + 1) + 16 * r] - d[p + 4 * q + 16 * r]) * h;
+    if (rank == 3)
+      for (int p = 0; p < E; p++)
+        for (int q = 0; q < E; q++)
+          for (int r = 0; r < E - 1; r++) acc += (d[p + 4 * q + 16 * (r + 1)] - d[p + 4 * q + 16 * r]) * (d[p + 4 * q + 16 * (r + 1)] - d[p + 4 * q + 16 * r]) * h;
+    criteria[e] = acc / volumes[e];
+  }
+}
+
+// adapt_volume + adapt_variables for subgrids, t8gpu/mesh/subgrid_mesh_manager.inl:246-425.
+template <class T>
+void subgrid_adapt_variables_and_volume(int rank, int n_new, const int32_t* adapt_data, const T* const old_v[5], T* const new_v[5],
+                                        const T* vol_old, T* vol_new) {
+  const int S = sg_size(rank);
+  const T   down = rank == 3 ? T(0.125) : T(0.25), up = rank == 3 ? T(8.0) : T(4.0);
+  for (int e = 0; e < n_new; e++) {
+    const int diff = adapt_data[e + 1] - adapt_data[e];
+    vol_new[e]     = vol_old[adapt_data[e]] * (diff == 0 ? down : (diff == 1 ? T(1.0) : up));
+    if (e > 0 && adapt_data[e - 1] == adapt_data[e]) vol_new[e] = vol_old[adapt_data[e]] * down;
+    for (int c = 0; c < S; c++) {
+      const int    i = c & 3, j = (c >> 2) & 3, k = rank == 3 ? c >> 4 : 0;
+      const size_t dst = static_cast<size_t>(e) * S + c;
+      if (diff == 0 || (e > 0 && adapt_data[e] == adapt_data[e - 1])) {
+        int refinement_index = 0;
+        while (e - refinement_index >= 0 && adapt_data[e - refinement_index] == adapt_data[e]) refinement_index++;
+        const int I = (refinement_index - 1) & 1, J = ((refinement_index - 1) >> 1) & 1, K = ((refinement_index - 1) >> 2) & 1;
+        const size_t src = static_cast<size_t>(adapt_data[e]) * S + (I * 2 + i / 2) + 4 * (J * 2 + j / 2) + (rank == 3 ? 16 * (K * 2 + k / 2) : 0);
+        for (int l = 0; l < 5; l++) new_v[l][dst] = old_v[l][src];
+      } else if (diff > 1) {
+        const int    z   = (i >> 1) | ((j >> 1) << 1) | (rank == 3 ? (k >> 1) << 2 : 0);
+        const size_t blk = static_cast<size_t>(adapt_data[e] + z) * S;
+        for (int l = 0; l < 5; l++) {
+          new_v[l][dst] = T(0.0);
+          for (int ii = 0; ii < 2; ii++)
+            for (int jj = 0; jj < 2; jj++)
+              for (int kk = 0; kk < (rank == 3 ? 2 : 1); kk++)
+                new_v[l][dst] += old_v[l][blk + (2 * (i & 1) + ii) + 4 * (2 * (j & 1) + jj) + (rank == 3 ? 16 * (2 * (k & 1) + kk) : 0)];
+          new_v[l][dst] /= static_cast<T>(1 << rank);
+        }
+      } else {
+        for (int l = 0; l < 5; l++) new_v[l][dst] = old_v[l][static_cast<size_t>(adapt_data[e]) * S + c];
+      }
+    }
+  }
+}
+
 }  // namespace oracle

@@ -161,6 +161,23 @@ extern "C" int oracle_num_threads() {
     }                                                                                                               \
     adapt_variables_and_volume<T>(n_new, dim, adapt_data, ov, nv, vol_old, vol_new);                                \
   }
+#define ORACLE_DEFINE_AMR_SUBGRID(SUF, T)                                                                               \
+  extern "C" void oracle_subgrid_refinement_criteria_##SUF(int rank, int N, const T* rho, const T* volumes, T* criteria) { \
+    subgrid_refinement_criteria<T>(rank, N, rho, volumes, criteria);                                                     \
+  }                                                                                                                      \
+  extern "C" void oracle_subgrid_adapt_variables_and_volume_##SUF(int rank, int n_new, const int32_t* adapt_data,        \
+                                                                  const T* old_planes, size_t old_stride, T* new_planes, \
+                                                                  size_t new_stride, const T* vol_old, T* vol_new) {     \
+    const T* ov[5];                                                                                                      \
+    T*       nv[5];                                                                                                      \
+    for (int k = 0; k < 5; k++) {                                                                                        \
+      ov[k] = old_planes + k * old_stride;                                                                               \
+      nv[k] = new_planes + k * new_stride;                                                                               \
+    }                                                                                                                    \
+    subgrid_adapt_variables_and_volume<T>(rank, n_new, adapt_data, ov, nv, vol_old, vol_new);                            \
+  }
+ORACLE_DEFINE_AMR_SUBGRID(f32, float)
+ORACLE_DEFINE_AMR_SUBGRID(f64, double)
 ORACLE_DEFINE_AMR(f32, float)
 ORACLE_DEFINE_AMR(f64, double)
 

@@ -150,3 +150,33 @@ def adapt_partitioned(solver, dist, **kw):
     pa = PartitionedAdapt(solver, all_crit, **kw)
     pa.transport(dist)
     return pa.finish()
+
+
+def subgrid_refinement_criteria(solver):
+    """compute_refinement_criteria<Subgrid> (examples/subgrid/solver.inl:329-340); device tensor [N]."""
+    crit = torch.empty(solver.N, dtype=solver.dtype, device="cuda")
+    hip.call("t8gpu_hip_subgrid_refinement_criteria", solver.dtype, solver.rank, solver.N, hip.ptr(solver.planes[5 * solver.next]),
+             hip.ptr(solver.volumes), hip.ptr(crit), hip.stream_ptr())
+    return crit
+
+
+def adapt_subgrid(solver, threshold=0.02, min_level=1, max_level=6, family_members_averaged=4):
+    """SubgridCompressibleEulerSolver::adapt (examples/subgrid/solver.inl:327-345) for a single-rank SubgridSolver:
+    H1-seminorm indicator, the forest adapt, block-wise data transfer (subgrid_mesh_manager.inl:246-425)."""
+    from .solver import SubgridSolver
+    part = solver.part
+    assert part.nranks == 1
+    mesh = part.mesh
+    crit = subgrid_refinement_criteria(solver).double().cpu().numpy()
+    marks = mesh.marks_from_criteria(crit, threshold, min_level, max_level, family_members_averaged)
+    new_mesh, adapt_data = mesh.adapt(marks)
+    new_part = new_mesh.partition(0, 1, subgrid=True)
+    S = solver.S
+    new = SubgridSolver(new_part, solver.dtype, flux_kind=solver.kind, mode=solver.mode, state=np.zeros((5, new_part.N * S)))
+    new.next, new.prev = solver.next, solver.prev
+    ad = torch.from_numpy(adapt_data).cuda()
+    hip.call("t8gpu_hip_subgrid_adapt_variables_and_volume", solver.dtype, solver.rank, new_part.N, hip.ptr(ad),
+             solver.get_own_variables(solver.next), new.get_own_variables(new.next), hip.ptr(solver.volumes),
+             hip.ptr(new.volumes), hip.stream_ptr())
+    torch.cuda.synchronize()
+    return new, marks, adapt_data

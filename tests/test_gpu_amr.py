@@ -147,3 +147,66 @@ def test_partitioned_adapt_and_repartition_equals_single_rank(world):
     assert sum(n.N for n in news) == npart.N and max(n.N for n in news) - min(n.N for n in news) <= 1   # balanced again
     assert torch.equal(got, want[:5]) and torch.equal(gvol, want[5])
     assert any(len(p.sends) > 1 for p in pas)                              # elements really changed owner
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("dim", [2, 3])
+def test_subgrid_indicator_and_transfer_vs_oracle(dtype, dim):
+    from t8gpu_amd.solver import SubgridSolver
+    mesh = SynthMesh(dim, 3, 5 if dim == 2 else 4, band=0.03)
+    part = mesh.partition(subgrid=True)
+    S = 4 ** dim
+    npdt = NP[dtype]
+    st = perturbed_state(part, 15)
+    g = SubgridSolver(part, dtype, state=st)
+    # indicator
+    crit = amr.subgrid_refinement_criteria(g).cpu().numpy()
+    want = np.zeros(part.N, npdt)
+    sf = O.suf(npdt)
+    rho = np.ascontiguousarray(st[0].astype(npdt))
+    vol = part.volumes.astype(npdt)
+    getattr(O.lib(), "oracle_subgrid_refinement_criteria_" + sf)(dim, part.N, O.p(rho), O.p(vol), O.p(want))
+    assert np.abs(crit - want).max() <= (1e-12 if dtype == torch.float64 else 2e-5) * np.abs(want).max()
+    # transfer: coarsen the left half, refine part of the right half
+    rng = np.random.default_rng(6)
+    x = part.centres[:part.N, 0]
+    marks = np.where(x < 0.5, -1, np.where(x > 0.75, rng.integers(0, 2, part.N), 0)).astype(np.int8)
+    new_mesh, ad = mesh.adapt(marks)
+    assert set(np.unique(np.diff(ad))) >= {0, 1, 2 ** dim}
+    npart = new_mesh.partition(subgrid=True)
+    new = torch.zeros((5, npart.N * S), dtype=dtype, device="cuda")
+    nvol = torch.zeros(npart.N, dtype=dtype, device="cuda")
+    hip.call("t8gpu_hip_subgrid_adapt_variables_and_volume", dtype, dim, npart.N, hip.ptr(torch.from_numpy(ad).cuda()),
+             g.get_own_variables(0), hip.vars_of(new), hip.ptr(g.volumes), hip.ptr(nvol), hip.stream_ptr())
+    torch.cuda.synchronize()
+    old = np.ascontiguousarray(st.astype(npdt))
+    wst = np.zeros((5, npart.N * S), npdt)
+    wvol = np.zeros(npart.N, npdt)
+    getattr(O.lib(), "oracle_subgrid_adapt_variables_and_volume_" + sf)(dim, npart.N, O.p(ad), O.p(old), C.c_size_t(part.N * S), O.p(wst),
+                                                                        C.c_size_t(npart.N * S), O.p(vol), O.p(wvol))
+    assert np.array_equal(new.cpu().numpy(), wst) and np.array_equal(nvol.cpu().numpy(), wvol)
+    assert np.allclose(wvol, npart.volumes, rtol=1e-6)
+    m_old = (old.astype(np.float64) * np.repeat(part.volumes / S, S)).sum(1)
+    m_new = (wst.astype(np.float64) * np.repeat(npart.volumes / S, S)).sum(1)
+    assert np.abs(m_new - m_old).max() < (1e-13 if dtype == torch.float64 else 1e-6) * np.abs(m_old).max()
+
+
+def test_subgrid_adaptive_run_stays_conservative():
+    from t8gpu_amd.solver import SubgridSolver
+    mesh = SynthMesh(2, 3, 3)
+    g = SubgridSolver(mesh.partition(subgrid=True), torch.float64, mode="fused")
+    S = g.S
+
+    def mass(s):
+        return float((s.state()[0] * torch.from_numpy(np.repeat(s.part.volumes[:s.N] / S, S)).cuda()).sum())
+
+    m0 = mass(g)
+    sizes = [g.N]
+    for _ in range(3):
+        g, _, _ = amr.adapt_subgrid(g, threshold=0.02, min_level=3, max_level=5)
+        sizes.append(g.N)
+        dt = 0.1 * 2.0 ** -(g.part.mesh.finest_level + 2)
+        for _ in range(4):
+            g.iterate(dt)
+    assert len(set(sizes)) > 1 and bool(torch.isfinite(g.state()).all())
+    assert abs(mass(g) - m0) < 1e-12 * abs(m0)
