@@ -70,6 +70,11 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the hot path has no CPU implementation")
+    # T8GPU_REHEARSAL=1: all ranks share GPU 0 and talk over gloo (host-staged halos). Lets the N > 1
+    # orchestration be rehearsed on a one-GPU box; the numbers it prints are NOT measurements.
+    rehearsal = os.environ.get("T8GPU_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     from t8gpu_amd import hip
@@ -80,7 +85,10 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     w = WORKLOADS[args.workload]
     dts = args.dtype or w["dtype"]
@@ -111,8 +119,8 @@ def main():
     stepper = None
     if world > 1:
         from t8gpu_amd import halo as halo_mod
-        halo = halo_mod.HaloExchange(part, tdtype, dist)      # torch.distributed (RCCL) transport: always available
-        halo_kind = "torch.distributed"
+        halo = halo_mod.HaloExchange(part, tdtype, dist, stage_through_host=rehearsal)   # torch.distributed transport
+        halo_kind = "torch.distributed (gloo, host-staged REHEARSAL)" if rehearsal else "torch.distributed"
     if mode == "fused" and w["kind"] == "plain" and os.environ.get("T8GPU_STEPPER", "native") == "native":
         native_halo = None
         if world > 1 and os.environ.get("T8GPU_HALO", "native") == "native":
@@ -158,7 +166,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t1
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     if stepper is not None:
@@ -270,7 +278,7 @@ def make_native_halo(part, tdtype, solver, torch_halo, dist, rank, world):
                 comm.abort()
             except Exception:  # noqa: BLE001
                 pass
-    flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+    flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     return nh if int(flag.item()) == 1 else None
 

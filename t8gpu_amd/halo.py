@@ -18,8 +18,10 @@ from . import hip
 
 
 class HaloExchange:
-    def __init__(self, part, dtype, dist, device="cuda", overlap=True):
+    def __init__(self, part, dtype, dist, device="cuda", overlap=True, stage_through_host=False):
         self.part, self.dist, self.dtype = part, dist, dtype
+        # rehearsal mode: several ranks share one GPU over gloo, which moves host memory only
+        self.stage_through_host = stage_through_host
         self.N, self.G = part.N, part.G
         self.rank = part.rank
         self.peers = [int(p) for p in part.peers]
@@ -61,6 +63,8 @@ class HaloExchange:
             planes5[:, self.N * S:(self.N + self.G) * S] = self.recvbuf[:5 * self.G * S].view(self.G * S, 5).t()
 
     def _transport(self):
+        if self.stage_through_host:
+            return self._transport_host_staged()
         ops = []
         for j, p in enumerate(self.peers):
             w = 5 * self.cells
@@ -73,6 +77,23 @@ class HaloExchange:
         if ops:
             for req in self.dist.batch_isend_irecv(ops):
                 req.wait()   # on CUDA: enqueues a stream wait, does not block the host
+
+    def _transport_host_staged(self):
+        torch.cuda.current_stream().synchronize()
+        send_h, recv_h = self.sendbuf.cpu(), torch.empty_like(self.recvbuf, device="cpu")
+        ops = []
+        w = 5 * self.cells
+        for j, p in enumerate(self.peers):
+            r0, r1 = w * self.recv_off[j], w * self.recv_off[j + 1]
+            s0, s1 = w * self.send_off[j], w * self.send_off[j + 1]
+            if r1 > r0:
+                ops.append(self.dist.P2POp(self.dist.irecv, recv_h[r0:r1], p))
+            if s1 > s0:
+                ops.append(self.dist.P2POp(self.dist.isend, send_h[s0:s1], p))
+        if ops:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
+        self.recvbuf.copy_(recv_h)
 
     # -- one exchange, split so that compute can run between start() and finish() ----------------
     def start(self, planes5):

@@ -1,0 +1,39 @@
+"""bench.py's N > 1 orchestration, rehearsed on ONE GPU: the ranks share cuda:0 and talk over gloo with
+host-staged halos (T8GPU_REHEARSAL=1). Covers process-group set-up, SFC partitioning, per-rank plans, the
+native-RCCL attempt and its agreed fall-back, the split interior / ghost-reading stage launches, the
+MAX-over-ranks timing and the JSON contract; only the RCCL transport itself is not reached (it needs one
+GPU per rank, which the driver's 8-GPU run provides)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(world, extra):
+    env = dict(os.environ, T8GPU_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29610 + world), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(world), "--steps", "3", "--warmup", "1", "--prewarm-seconds", "0.05"] + extra
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 must print exactly one JSON line"
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,workload", [(2, "c1"), (3, "c2")])
+def test_bench_multirank_rehearsal(world, workload):
+    rec = run_bench(world, ["--workload", workload])
+    assert rec["n_gpus"] == world and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["scaling"] == "strong" and rec["higher_is_better"] is True and rec["vs_baseline"] is None
+    assert rec["config"]["finite"] is True
+    assert rec["config"]["partition"] == f"sfc-contiguous x{world}"
+    assert "REHEARSAL" in rec["config"]["halo"]
+    assert rec["value"] > 0 and rec["ms_per_step"] > 0
+    assert rec["roofline"]["bound"] == "hbm" and 0 < rec["roofline"]["frac"] < 1.2
+    assert rec["cpu_baseline"] is None            # timed on rank 0 at N = 1 only
