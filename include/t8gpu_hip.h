@@ -296,6 +296,21 @@ int t8gpu_hip_subgrid_adapt_variables_and_volume_f64(int rank, int num_new_eleme
                                                      T8gpuVars_f64 old_variables, T8gpuVars_f64 new_variables,
                                                      const double* volume_old, double* volume_new, void* stream);
 
+/* ---- diagnostics -----------------------------------------------------------------------------------------
+ * Element-wise evaluation of the fast-tier scalar helpers (reciprocal / division / sqrt / log without the
+ * IEEE special-case handling, and the logarithmic mean built on them: kernels.cu:24-36) so that their
+ * accuracy can be pinned against a host libm. out[i] = op(a[i], b[i]); b may be null for unary ops. */
+enum {
+  T8GPU_PROBE_RCP = 0,
+  T8GPU_PROBE_DIV = 1,
+  T8GPU_PROBE_SQRT = 2,
+  T8GPU_PROBE_LOG = 3,
+  T8GPU_PROBE_LN_MEAN = 4,    /* fast tier: from the two values and the difference of their logs */
+  T8GPU_PROBE_LN_MEAN_REF = 5 /* compat tier: the reference formula, IEEE division and library log */
+};
+int t8gpu_hip_math_probe_f32(int op, int n, const float* a, const float* b, float* out, void* stream);
+int t8gpu_hip_math_probe_f64(int op, int n, const double* a, const double* b, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -273,6 +273,30 @@ T8_DEV double t8_div(double a, double b) {
   return __builtin_fma(__builtin_fma(-b, q, a), r, q);
 }
 
+// log for the fast tier (x > 0, normal range). fp64: the library routine is ~95 VALU instructions (special
+// cases, double-double reduction); per element and stage two of them dominated the per-cell work. This
+// is the classic reduction x = m 2^e, m in [sqrt(1/2), sqrt(2)), log m = 2 atanh(s), s = (m-1)/(m+1), with
+// the degree-7 minimax polynomial in s^2 of Sun's fdlibm e_log.c (error < 1 ulp; pinned against the
+// host libm in tests/test_gpu_fastmath.py): ~35 instructions.
+T8_DEV float  t8_log_fast(float x) { return logf(x); }
+T8_DEV double t8_log_fast(double x) {
+  double     m  = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  int        e  = __builtin_amdgcn_frexp_exp(x);
+  const bool lo = m < 0.70710678118654752440;
+  m             = lo ? m + m : m;
+  e             = lo ? e - 1 : e;
+  const double f = m - 1.0;
+  const double s = t8_div(f, 2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                                         2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double R    = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double dk   = static_cast<double>(e);
+  return dk * 6.93147180369123816490e-01 - ((hfsq - __builtin_fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+}
+
 template <class T>
 struct Prim {
   T rho, vx, vy, vz, p, beta, lrho, lbeta, v0;
@@ -293,8 +317,8 @@ T8_DEV Prim<T> prim_from_state(const T s[5]) {
   q.p        = km1 * (s[4] - s[0] * ke);
   const T rp = t8_div(s[0], q.p);
   q.beta     = half * rp;
-  q.lrho     = t8_log(s[0]);
-  const T lp = t8_log(q.p);
+  q.lrho     = t8_log_fast(s[0]);
+  const T lp = t8_log_fast(q.p);
   q.lbeta    = q.lrho - lp;
   q.v0       = (kappa - (lp - kappa * q.lrho)) * (one / km1) - rp * ke;
   return q;
@@ -323,22 +347,11 @@ T8_DEV float ln_mean_dlog(float aL, float aR, float /*dlog*/) {
 
 // KEPES flux through a face with unit normal n (basis n, t1, t2), scaled by `area`, in xyz.
 // mirror => the right state is the wall reflection of L (R is ignored).
+// core: velocities already in the face frame; f = area-scaled flux in the face frame
 template <class T>
-T8_DEV void kepes_prim(const Prim<T>& L, const Prim<T>& R, bool mirror, const T n[3], const T t1[3], const T t2[3],
-                       T area, T g[5], T& speed) {
+T8_DEV void kepes_core(const Prim<T>& L, const Prim<T>& R, T uL, T vL, T wL, T uR, T vR, T wR, T area, T f[5], T& speed) {
   const T one = T(1), half = T(0.5), kappa = T(1.4);
   const T km1 = kappa - one, skm1 = one / km1, ikappa = one / kappa;
-  const T uL = L.vx * n[0] + L.vy * n[1] + L.vz * n[2];
-  const T vL = L.vx * t1[0] + L.vy * t1[1] + L.vz * t1[2];
-  const T wL = L.vx * t2[0] + L.vy * t2[1] + L.vz * t2[2];
-  T       uR = R.vx * n[0] + R.vy * n[1] + R.vz * n[2];
-  T       vR = R.vx * t1[0] + R.vy * t1[1] + R.vz * t1[2];
-  T       wR = R.vx * t2[0] + R.vy * t2[1] + R.vz * t2[2];
-  if (mirror) {
-    uR = -uL;
-    vR = vL;
-    wR = wL;
-  }
   const T qL = half * (uL * uL + vL * vL + wL * wL);
   const T qR = half * (uR * uR + vR * vR + wR * wR);
 
@@ -387,11 +400,63 @@ T8_DEV void kepes_prim(const Prim<T>& L, const Prim<T>& R, bool mirror, const T 
   const T f2 = area * (Fs2 - half * (v * s014 + d2));
   const T f3 = area * (Fs3 - half * (w * s014 + d3));
   const T f4 = area * (Fs4 - half * (hm * d0 + k2 * d1 + v * d2 + w * d3 + hp * d4));
-  g[0] = f0;
-  g[1] = f1 * n[0] + f2 * t1[0] + f3 * t2[0];
-  g[2] = f1 * n[1] + f2 * t1[1] + f3 * t2[1];
-  g[3] = f1 * n[2] + f2 * t1[2] + f3 * t2[2];
-  g[4] = f4;
+  f[0] = f0;
+  f[1] = f1;
+  f[2] = f2;
+  f[3] = f3;
+  f[4] = f4;
+}
+
+template <class T>
+T8_DEV void kepes_prim(const Prim<T>& L, const Prim<T>& R, bool mirror, const T n[3], const T t1[3], const T t2[3],
+                       T area, T g[5], T& speed) {
+  const T uL = L.vx * n[0] + L.vy * n[1] + L.vz * n[2];
+  const T vL = L.vx * t1[0] + L.vy * t1[1] + L.vz * t1[2];
+  const T wL = L.vx * t2[0] + L.vy * t2[1] + L.vz * t2[2];
+  T       uR = R.vx * n[0] + R.vy * n[1] + R.vz * n[2];
+  T       vR = R.vx * t1[0] + R.vy * t1[1] + R.vz * t1[2];
+  T       wR = R.vx * t2[0] + R.vy * t2[1] + R.vz * t2[2];
+  if (mirror) {
+    uR = -uL;
+    vR = vL;
+    wR = wL;
+  }
+  T f[5];
+  kepes_core<T>(L, R, uL, vL, wL, uR, vR, wR, area, f, speed);
+  g[0] = f[0];
+  g[1] = f[1] * n[0] + f[2] * t1[0] + f[3] * t2[0];
+  g[2] = f[1] * n[1] + f[2] * t1[1] + f[3] * t2[1];
+  g[3] = f[1] * n[2] + f[2] * t1[2] + f[3] * t2[2];
+  g[4] = f[4];
+}
+
+// Axis-aligned face, normal +-e_axis (Subgrid blocks: kernels.inl:717-750 requires it). The frame is
+// (s e_axis, e_axis+1, e_axis+2): component selection and one sign instead of 27 multiplications by the
+// zeros and ones of a general basis. The flux does not depend on the choice of the two tangents.
+template <class T>
+T8_DEV T axis_pick(T x, T y, T z, int a) { return a == 0 ? x : (a == 1 ? y : z); }
+
+template <class T>
+T8_DEV void kepes_axis(const Prim<T>& L, const Prim<T>& R, bool mirror, int axis, bool positive, T area, T g[5], T& speed) {
+  const int a1 = axis == 2 ? 0 : axis + 1, a2 = axis == 0 ? 2 : axis - 1;
+  const T   uLp = axis_pick(L.vx, L.vy, L.vz, axis), uRp = axis_pick(R.vx, R.vy, R.vz, axis);
+  const T   uL = positive ? uLp : -uLp;
+  const T   vL = axis_pick(L.vx, L.vy, L.vz, a1), wL = axis_pick(L.vx, L.vy, L.vz, a2);
+  T         uR = positive ? uRp : -uRp;
+  T         vR = axis_pick(R.vx, R.vy, R.vz, a1), wR = axis_pick(R.vx, R.vy, R.vz, a2);
+  if (mirror) {
+    uR = -uL;
+    vR = vL;
+    wR = wL;
+  }
+  T f[5];
+  kepes_core<T>(L, R, uL, vL, wL, uR, vR, wR, area, f, speed);
+  const T fn = positive ? f[1] : -f[1];
+  g[0] = f[0];
+  g[1] = axis == 0 ? fn : (axis == 1 ? f[3] : f[2]);   // x is a2 of axis 1 and a1 of axis 2
+  g[2] = axis == 1 ? fn : (axis == 2 ? f[3] : f[2]);
+  g[3] = axis == 2 ? fn : (axis == 0 ? f[3] : f[2]);
+  g[4] = f[4];
 }
 
 // HLL for the fast tier: the formulas of hll_ref (examples/subgrid/kernels.inl:263-332) with shared

@@ -85,14 +85,15 @@ T8_DEV CellData<T, KIND> cell_from_state(const T s[5]) {
 // area-scaled xyz flux from L to R through a face with unit normal n
 template <class T, int KIND>
 T8_DEV void cell_flux(const CellData<T, KIND>& L, const CellData<T, KIND>& R, bool wall, int axis, bool positive, T area, T g[5]) {
-  T n[3], t1[3], t2[3], spd;
-  axis_basis<T>(axis, positive, n, t1, t2);   // subgrid faces are axis-aligned (kernels.inl:717-750 requires it)
   if (KIND == 0) {
+    T spd;
     Prim<T> a, b;
     a.rho = L.v[0]; a.vx = L.v[1]; a.vy = L.v[2]; a.vz = L.v[3]; a.p = L.v[4]; a.beta = L.v[5]; a.lrho = L.v[6]; a.lbeta = L.v[7]; a.v0 = L.v[8];
     b.rho = R.v[0]; b.vx = R.v[1]; b.vy = R.v[2]; b.vz = R.v[3]; b.p = R.v[4]; b.beta = R.v[5]; b.lrho = R.v[6]; b.lbeta = R.v[7]; b.v0 = R.v[8];
-    kepes_prim<T>(a, b, wall, n, t1, t2, area, g, spd);
+    kepes_axis<T>(a, b, wall, axis, positive, area, g, spd);   // subgrid faces are axis-aligned (kernels.inl:717-750 requires it)
   } else {
+    T n[3], t1[3], t2[3];
+    axis_basis<T>(axis, positive, n, t1, t2);
     hll_face<T>(L.v, R.v, wall, n, t1, t2, area, g);
   }
 }
