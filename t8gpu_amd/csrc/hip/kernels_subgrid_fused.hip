@@ -5,18 +5,23 @@
 // subgrid::SSP_3RK_stepK (examples/subgrid/solver.inl:166-195) and their flux-plane round trips
 // (up to 6 read-modify-writes per cell and variable in the inner kernel, 10 atomics per sub-face in the
 // outer one). Lane c owns subcell (i, j, k) = (c & 3, (c >> 2) & 3, c >> 4) of block blockIdx:
-//   1. own state -> per-cell primitives, registers + LDS (neighbours: lane +1 / +4 / +16);
+//   1. own state -> per-cell primitives, registers + LDS (neighbours: lane +1 / +4 / +16); the far cells
+//      of the block's three + faces (same level, or the coarser side of a hanging face: one per surface
+//      cell, 48 in all) are fetched by lanes 0..47 and their primitives appended to the same LDS array,
+//      i.e. one round of per-cell work for all three faces;
 //   2. + faces, x then y then z: EVERY lane evaluates the flux through its +d face. Lanes with coordinate
-//      < 3 have their + neighbour in the block (the wave exchanges the flux through LDS: -own, +lower);
-//      lanes with coordinate 3 sit on the block surface and take the far cell from the block on the +d
-//      side (same level, wall, or the coarser side of a hanging face: one sub-face per cell), so these
-//      passes run with all 64 lanes busy;
+//      < 3 have their + neighbour in the block, lanes with coordinate 3 sit on the block surface and read
+//      the far cell's primitives from the appended part, so these passes run with all 64 lanes busy and
+//      no divergence (the wave exchanges the flux through LDS: -own, +lower);
 //   3. the block's remaining coarse faces (-d sides, and faces towards finer blocks: 4 sub-faces per
 //      cell), four at a time: lane = (face slot, sub-face), far cell gathered through the 2:1 hanging
 //      map of kernels.inl:752-758, sub-face fluxes to LDS, every cell picks up the ones that end on it;
 //   4. RK stage on the accumulated flux, coalesced store.
-// An outer sub-face is evaluated by both blocks that share it (same arguments, same result), so there
-// are no atomics, no flux planes and the result is bitwise reproducible. The wave runs in lock-step,
+// An outer sub-face is evaluated by both blocks that share it, both in the GEOMETRIC orientation (left =
+// the block on the low side, normal +e_d; walls: left = the block, outward normal) rather than the one the
+// face list happens to store: same arguments, same result, no operand swapping in the + passes, and the
+// result does not depend on the listing rule (quirk Q4) or on the partition. There are no atomics, no flux
+// planes and the result is bitwise reproducible. The wave runs in lock-step,
 // so the reference's unsynchronised LDS reuse has no counterpart here.
 #include <hip/hip_runtime.h>
 
@@ -136,40 +141,48 @@ T8_DEV FaceLane<T> load_face_lane(const T8gpuSubgridPlan& P, const SVars<T>& src
   return L;
 }
 
-// The +d coarse face of a block as seen by the surface lane with tangential coordinates (ti, tj).
+// The +d coarse face of a block (wave-uniform for RANK 3: these are scalar loads, which keeps the
+// dependent chain face list -> face record -> far cell short).
 template <class T>
-struct PlusLane {
-  bool on, right, wall;
-  T    area, sf[5];
+struct PlusFace {
+  bool on, right, wall;   // on: listed as ONE coarse face (faces towards finer blocks are in the generic list)
+  int  lblock, rblock, code;
+  T    area;
 };
-
-template <class T, int S, int RANK>
-T8_DEV PlusLane<T> load_plus_lane(const T8gpuSubgridPlan& P, const SVars<T>& src, int e, int d, bool surface_lane, int ti, int tj) {
-  PlusLane<T> L;
-  L.on = L.right = L.wall = false;
-  L.area = T(0);
-#pragma unroll
-  for (int k = 0; k < 5; k++) L.sf[k] = T(1);
-  if (surface_lane) {
-    const int ent = P.plus[(size_t)e * RANK + d];
-    if (ent != -1) {
-      const int  fid = ent & 0x7FFFFFFF;
-      const int4 rec = reinterpret_cast<const int4*>(P.face_rec)[fid];
-      const FaceCode fc = decode(rec.z);
-      L.on    = true;
-      L.right = ent < 0;
-      L.wall  = rec.y < 0;
-      L.area  = reinterpret_cast<const T*>(P.face_surfaces)[fid];
-      if (!L.wall) {
-        // far cell: in the left block on its face plane, or in the right block at the stored anchor
-        const int    fcell = L.right ? left_cell(fc, ti, tj) : right_cell(fc, ti, tj);
-        const size_t far   = (size_t)(L.right ? rec.x : rec.y) * S + fcell;
-#pragma unroll
-        for (int k = 0; k < 5; k++) L.sf[k] = src.p[k][far];
-      }
-    }
+template <class T, int RANK>
+T8_DEV PlusFace<T> plus_face(const T8gpuSubgridPlan& P, int e, int d, bool live) {
+  PlusFace<T> f;
+  f.on = f.right = f.wall = false;
+  f.lblock = f.rblock = f.code = 0;
+  f.area = T(0);
+  const int ent = P.plus[(size_t)e * RANK + d];
+  if (live && ent != -1) {
+    const int  fid = ent & 0x7FFFFFFF;
+    const int4 rec = reinterpret_cast<const int4*>(P.face_rec)[fid];
+    f.on     = true;
+    f.right  = ent < 0;
+    f.wall   = rec.y < 0;
+    f.lblock = rec.x;
+    f.rblock = rec.y;
+    f.code   = rec.z;
+    f.area   = reinterpret_cast<const T*>(P.face_surfaces)[fid];
   }
-  return L;
+  return f;
+}
+// state of the far cell behind sub-face (ti, tj) of that face: in the left block on its face plane, or in
+// the right block at the stored anchor (kernels.inl:710-758)
+template <class T, int S>
+T8_DEV void load_plus_far(const SVars<T>& src, bool on, bool right, bool wall, int lblock, int rblock, int code, int ti, int tj,
+                          T sf[5]) {
+#pragma unroll
+  for (int k = 0; k < 5; k++) sf[k] = T(1);
+  if (on && !wall) {
+    const FaceCode fc    = decode(code);
+    const int      fcell = right ? left_cell(fc, ti, tj) : right_cell(fc, ti, tj);
+    const size_t   far   = (size_t)(right ? lblock : rblock) * S + fcell;
+#pragma unroll
+    for (int k = 0; k < 5; k++) sf[k] = src.p[k][far];
+  }
 }
 
 // RANK 3: one Subgrid<4,4,4> block per wavefront. RANK 2: four Subgrid<4,4> blocks per wavefront
@@ -181,7 +194,8 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
   constexpr int S   = RANK == 3 ? 64 : 16;  // cells per block
   constexpr int SF  = RANK == 3 ? 16 : 4;   // sub-faces per coarse face
   constexpr int BPW = 64 / S;               // blocks per wavefront
-  __shared__ T  pe[NW][64];  // cells of the wave's block(s)
+  constexpr int PF  = RANK * SF;            // far cells of a block's + faces
+  __shared__ T  pe[NW][64 + BPW * PF];  // cells of the wave's block(s), then the far cells of their + faces
   __shared__ T  xb[5][64];   // flux exchange buffer (+ passes: per cell; generic passes: [slot * SF + sub-face])
   const int    c    = threadIdx.x;
   const int    base = (c / S) * S, cl = c - base;
@@ -193,13 +207,9 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
   const int    cc[3] = {cl & 3, (cl >> 2) & 3, RANK == 3 ? cl >> 4 : 0};   // compile-time indices only
   const size_t o = (size_t)e * S + cl;
 
-  T s0[5], pv[5];
+  T s0[5];
 #pragma unroll
   for (int k = 0; k < 5; k++) s0[k] = src.p[k][o];
-  if (STAGE > 1) {
-#pragma unroll
-    for (int k = 0; k < 5; k++) pv[k] = prev.p[k][o];
-  }
   const T   vol     = volumes[e];
   const int b0      = P.bf_off[e];
   const int nbf     = live ? P.bf_off[e + 1] - b0 : 0;
@@ -215,13 +225,24 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
   // loads (face list -> face record -> far cell) overlap the arithmetic
   const int slot = cl / SF, sub = cl % SF, si = sub & 3, sj = RANK == 3 ? sub >> 2 : 0;
   const FaceLane<T> pre0 = load_face_lane<T, S>(P, src, b0, nbf, slot, si, sj);
-  const PlusLane<T> px = load_plus_lane<T, S, RANK>(P, src, e, 0, live && cc[0] == 3, cc[1], cc[2]);
-  const PlusLane<T> py = load_plus_lane<T, S, RANK>(P, src, e, 1, live && cc[1] == 3, cc[0], cc[2]);
-  const PlusLane<T> pz = load_plus_lane<T, S, RANK>(P, src, e, 2, RANK == 3 && live && cc[2] == 3, cc[0], cc[1]);
+  const PlusFace<T> fx = plus_face<T, RANK>(P, e, 0, live), fy = plus_face<T, RANK>(P, e, 1, live),
+                    fz = RANK == 3 ? plus_face<T, RANK>(P, e, 2, live) : PlusFace<T>{false, false, false, 0, 0, 0, T(0)};
+  // lane cl < PF fetches far cell `cl % SF` of the block's +(cl / SF) face
+  const int  pd = cl / SF, psub = cl % SF;
+  const bool p_on = cl < PF && (pd == 0 ? fx.on : (pd == 1 ? fy.on : fz.on));
+  T          pfar[5];
+  load_plus_far<T, S>(src, p_on, pd == 0 ? fx.right : (pd == 1 ? fy.right : fz.right), pd == 0 ? fx.wall : (pd == 1 ? fy.wall : fz.wall),
+                      pd == 0 ? fx.lblock : (pd == 1 ? fy.lblock : fz.lblock), pd == 0 ? fx.rblock : (pd == 1 ? fy.rblock : fz.rblock),
+                      pd == 0 ? fx.code : (pd == 1 ? fy.code : fz.code), psub & 3, RANK == 3 ? psub >> 2 : 0, pfar);
 
   const CellData<T, KIND> mine = cell_from_state<T, KIND>(s0);
 #pragma unroll
   for (int w = 0; w < NW; w++) pe[w][c] = mine.v[w];
+  if (cl < PF) {
+    const CellData<T, KIND> far = cell_from_state<T, KIND>(pfar);
+#pragma unroll
+    for (int w = 0; w < NW; w++) pe[w][64 + (c / S) * PF + cl] = far.v[w];
+  }
   __syncthreads();
 
   T acc[5] = {T(0), T(0), T(0), T(0), T(0)};
@@ -229,36 +250,26 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
   // ---- + faces: inner (kernels.inl:364-533, 2D :554-660) and, on the block surface, the +d coarse face -
 #pragma unroll
   for (int d = 0; d < RANK; d++) {
-    const int          str = d == 0 ? 1 : (d == 1 ? 4 : 16);
-    const PlusLane<T>& pl  = d == 0 ? px : (d == 1 ? py : pz);
-    const bool         inner = cc[d] < 3;
-    // operand selection first, ONE flux evaluation for all 64 lanes afterwards (no divergent flux code)
-    CellData<T, KIND> other = mine;
-    if (inner) {
-#pragma unroll
-      for (int w = 0; w < NW; w++) other.v[w] = pe[w][c + str];
-    } else if (pl.on && !pl.wall) {
-      other = cell_from_state<T, KIND>(pl.sf);
-    }
-    const bool flip = !inner && pl.right;           // stored orientation: left = far block, normal -e_d
+    const int           str = d == 0 ? 1 : (d == 1 ? 4 : 16);
+    const PlusFace<T>& pl  = d == 0 ? fx : (d == 1 ? fy : fz);
+    const bool          inner = cc[d] < 3;
+    // the other cell: next lane's, or (block surface) the far cell with this lane's tangential coordinates
+    const int tsub = d == 0 ? cc[1] + 4 * cc[2] : (d == 1 ? cc[0] + 4 * cc[2] : cc[0] + 4 * cc[1]);
+    // (a wall mirrors this cell: kernels.inl:913-1107 / compute_boundary_fluxes)
     const bool wall = !inner && pl.wall;
-    const T    ar   = inner ? surface : pl.area / T(SF);
-    CellData<T, KIND> L, R;
+    const int  oidx = inner ? c + str : (wall ? c : 64 + (c / S) * PF + d * SF + tsub);
+    CellData<T, KIND> other;
 #pragma unroll
-    for (int w = 0; w < NW; w++) {
-      L.v[w] = flip ? other.v[w] : mine.v[w];
-      R.v[w] = flip ? mine.v[w] : other.v[w];
-    }
+    for (int w = 0; w < NW; w++) other.v[w] = pe[w][oidx];
+    const T    ar   = inner ? surface : pl.area / T(SF);
     T g[5] = {T(0), T(0), T(0), T(0), T(0)};
-    if (inner || pl.on) cell_flux<T, KIND>(L, R, wall, d, !flip, ar, g);
+    if (inner || pl.on) cell_flux<T, KIND>(mine, other, wall, d, true, ar, g);   // left = this cell, normal +e_d
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 5; k++) xb[k][c] = g[k];
     __syncthreads();
-    // own + face: leaves the cell, except where the cell is the RIGHT side of the stored face
-    const T sgn = flip ? T(1) : T(-1);
 #pragma unroll
-    for (int k = 0; k < 5; k++) acc[k] += sgn * g[k];
+    for (int k = 0; k < 5; k++) acc[k] -= g[k];
     if (cc[d] > 0) {
 #pragma unroll
       for (int k = 0; k < 5; k++) acc[k] += xb[k][c - str];
@@ -274,13 +285,19 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
 #pragma unroll
       for (int w = 0; w < NW; w++) here.v[w] = pe[w][base + fl.myflat];
       there = fl.wall ? here : cell_from_state<T, KIND>(fl.sf);
+      // geometric orientation: the low-side cell is the left one (walls: this cell, outward normal)
+      const bool low = fl.wall || (fl.right != (fl.positive != 0));
       CellData<T, KIND> L, R;
 #pragma unroll
       for (int w = 0; w < NW; w++) {
-        L.v[w] = fl.right ? there.v[w] : here.v[w];
-        R.v[w] = fl.right ? here.v[w] : there.v[w];
+        L.v[w] = low ? here.v[w] : there.v[w];
+        R.v[w] = low ? there.v[w] : here.v[w];
       }
-      cell_flux<T, KIND>(L, R, fl.wall, fl.axis, fl.positive, fl.area / T(SF), g);
+      cell_flux<T, KIND>(L, R, fl.wall, fl.axis, fl.wall ? fl.positive != 0 : true, fl.area / T(SF), g);
+      // stored with the sign it has for this block's cell: leaves the left cell, enters the right one
+      const T sgn = low ? T(-1) : T(1);
+#pragma unroll
+      for (int k = 0; k < 5; k++) g[k] *= sgn;
     }
     __syncthreads();
 #pragma unroll
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
           if (ca == (fc.positive ? 3 : 0)) {
             const int q = q0 + ci + 4 * cj;
 #pragma unroll
-            for (int k = 0; k < 5; k++) acc[k] -= xb[k][q];
+            for (int k = 0; k < 5; k++) acc[k] += xb[k][q];
           }
         } else if (ca == fc.off(fc.axis)) {
           const int di = ci - fc.off(fc.ta()), dj = RANK == 3 ? cj - fc.off(fc.tb()) : 0;
@@ -323,7 +340,14 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
   }
 
   // ---- RK stage (ssp_runge_kutta.inl:101-221): per-subcell volume = volumes[e] / Subgrid::size --------
+  // (the previous step's state is only needed here: fetched late, it does not occupy registers during the
+  //  flux passes -- fp64 stays at 128 VGPRs = 4 waves per SIMD; other waves cover the latency)
   if (live) {
+    T pv[5];
+    if (STAGE > 1) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) pv[k] = prev.p[k][o];
+    }
     const T scale = dt / (vol / T(S));
 #pragma unroll
     for (int k = 0; k < 5; k++) {
