@@ -7,15 +7,24 @@
 // t8code-free provider of include/t8gpu_host.h). It exposes the part of MeshManager's interface the hot
 // path uses (mesh_manager.h:253-421): get_connectivity_information(), get_num_local_{elements,faces,
 // boundary_faces}(), get_num_ghost_elements(), get_{own,all}_variable(s), get_own_volume().
-// The t8code-bound MeshManager (constructor from a forest, adapt, partition, VTK) is NOT part of this
+// plus the read-back / VTK members (mesh_manager.inl:516-623): get_host_scalar_variable,
+// get_host_vector_variable, save_variables_to_vtk -- the device half in csrc/hip/kernels_readback.hip, the
+// file written by t8gpu_host_write_vtu where the reference calls t8_forest_write_vtk_ext.
+// The t8code-bound MeshManager (constructor from a forest, adapt, partition) is NOT part of this
 // round; it needs t8code, which this build does not have.
 #ifndef T8GPU_HIP_MESH_MESH_MANAGER_H
 #define T8GPU_HIP_MESH_MESH_MANAGER_H
 
 #include <t8gpu/memory/memory_manager.h>
 
+#include <t8gpu_hip.h>
+#include <t8gpu_host.h>
+
 #include <array>
 #include <cstdint>
+#include <memory>
+#include <string>
+#include <type_traits>
 #include <vector>
 
 #if !__has_include(<t8.h>)
@@ -93,7 +102,15 @@ namespace t8gpu {
     std::vector<double>  face_normals;    // [dim * (F + B)]
     std::vector<double>  face_surfaces;   // [F + B]
     std::vector<double>  volumes;         // [N + G]
+    // only needed by save_variables_to_vtk: geometry of the owned leaves on the unit domain
+    int                  mesh_dim = 2;
+    int64_t              first_global_element = 0;
+    std::vector<double>  centres;         // [N][3]
+    std::vector<int32_t> levels;          // [N]
   };
+
+  /// T8_VTK_SCALAR / T8_VTK_VECTOR of t8code's t8_vtk_data_field_t: values per cell
+  enum : int { T8GPU_VTK_SCALAR = 1, T8GPU_VTK_VECTOR = 3 };
 
   template<typename VariableType, typename StepType, size_t dim>
   class SyntheticMeshManager : public MemoryManager<VariableType, StepType> {
@@ -105,7 +122,8 @@ namespace t8gpu {
     explicit SyntheticMeshManager(HostMeshArrays const& m, sc_MPI_Comm comm = sc_MPI_COMM_WORLD)
         : MemoryManager<VariableType, StepType>(static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements, comm),
           m_num_local_elements{m.num_local_elements}, m_num_ghost_elements{m.num_ghost_elements},
-          m_num_local_faces{m.num_local_faces}, m_num_local_boundary_faces{m.num_local_boundary_faces} {
+          m_num_local_faces{m.num_local_faces}, m_num_local_boundary_faces{m.num_local_boundary_faces}, m_rank{m.rank},
+          m_mesh_dim{m.mesh_dim}, m_first_global{m.first_global_element}, m_centres{m.centres}, m_levels{m.levels} {
       const size_t tot = static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements;
       std::vector<int>         ranks(tot, m.rank);
       std::vector<t8_locidx_t> indices(tot);
@@ -123,6 +141,7 @@ namespace t8gpu {
       (void)hipFree(m_face_neighbors);
       (void)hipFree(m_face_normals);
       (void)hipFree(m_face_surfaces);
+      (void)hipFree(m_staging);
     }
     SyntheticMeshManager(SyntheticMeshManager const&)            = delete;
     SyntheticMeshManager& operator=(SyntheticMeshManager const&) = delete;
@@ -135,7 +154,81 @@ namespace t8gpu {
     [[nodiscard]] t8_locidx_t get_num_local_faces() const { return m_num_local_faces; }
     [[nodiscard]] t8_locidx_t get_num_local_boundary_faces() const { return m_num_local_boundary_faces; }
 
+    /// Named host array of doubles ready for the writer (mesh_manager.h: HostVariableInfo).
+    struct HostVariableInfo {
+      int                       m_type;  // T8GPU_VTK_SCALAR | T8GPU_VTK_VECTOR
+      std::unique_ptr<double[]> m_data;
+      std::string               m_name;
+    };
+
+    /// mesh_manager.inl:516-545: one variable of one step, cast to double (on the device), on the host.
+    [[nodiscard]] HostVariableInfo get_host_scalar_variable(step_index_type step, variable_index_type variable,
+                                                            std::string const& name) const {
+      const size_t n = static_cast<size_t>(m_num_local_elements);
+      double*      d = staging(n);
+      if constexpr (std::is_same_v<float_type, double>)
+        T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_host_scalar_variable_f64(n, this->get_own_variable(step, variable), d, nullptr)));
+      else
+        T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_host_scalar_variable_f32(n, this->get_own_variable(step, variable), d, nullptr)));
+      return {T8GPU_VTK_SCALAR, fetch(d, n), name};
+    }
+    /// mesh_manager.inl:547-586: three variables as interleaved xyz doubles.
+    [[nodiscard]] HostVariableInfo get_host_vector_variable(step_index_type step, std::array<variable_index_type, 3> variables,
+                                                            std::string const& name) const {
+      const size_t      n = static_cast<size_t>(m_num_local_elements);
+      double*           d = staging(3 * n);
+      float_type const* v[3];
+      for (int k = 0; k < 3; k++) v[k] = this->get_own_variable(step, variables[k]);
+      if constexpr (std::is_same_v<float_type, double>)
+        T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_host_vector_variable_f64(n, v[0], v[1], v[2], d, nullptr)));
+      else
+        T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_host_vector_variable_f32(n, v[0], v[1], v[2], d, nullptr)));
+      return {T8GPU_VTK_VECTOR, fetch(d, 3 * n), name};
+    }
+    /// mesh_manager.inl:588-623: this rank's piece `<prefix>.vtu` (`<prefix>_RRRR.vtu` in a multi-rank run).
+    void save_variables_to_vtk(std::vector<HostVariableInfo> host_variables, std::string const& prefix, int num_ranks = 1,
+                               bool ascii = false) const {
+      std::vector<char const*>   names;
+      std::vector<int32_t>       comps;
+      std::vector<double const*> data;
+      for (auto const& h : host_variables) {
+        names.push_back(h.m_name.c_str());
+        comps.push_back(h.m_type);
+        data.push_back(h.m_data.get());
+      }
+      char suffix[16] = "";
+      if (num_ranks > 1) std::snprintf(suffix, sizeof suffix, "_%04d", m_rank);
+      const std::string path = prefix + suffix + ".vtu";
+      const int rc = t8gpu_host_write_vtu(path.c_str(), m_mesh_dim, m_num_local_elements, m_centres.data(), m_levels.data(), 1, m_rank,
+                                          m_first_global, static_cast<int>(names.size()), names.data(), comps.data(), data.data(), ascii);
+      if (rc != 0) {
+        std::fprintf(stderr, "t8gpu: writing %s failed (code %d)\n", path.c_str(), rc);
+        std::abort();
+      }
+    }
+
    private:
+    int                  m_rank = 0, m_mesh_dim = 2;
+    int64_t              m_first_global = 0;
+    std::vector<double>  m_centres;
+    std::vector<int32_t> m_levels;
+    mutable double*      m_staging       = nullptr;
+    mutable size_t       m_staging_count = 0;
+
+    double* staging(size_t n) const {
+      if (n > m_staging_count) {
+        (void)hipFree(m_staging);
+        T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_staging, sizeof(double) * n));
+        m_staging_count = n;
+      }
+      return m_staging;
+    }
+    static std::unique_ptr<double[]> fetch(double const* d, size_t n) {
+      std::unique_ptr<double[]> h = std::make_unique<double[]>(n);
+      T8GPU_CUDA_CHECK_ERROR(hipMemcpy(h.get(), d, sizeof(double) * n, hipMemcpyDeviceToHost));
+      return h;
+    }
+
     t8_locidx_t  m_num_local_elements, m_num_ghost_elements, m_num_local_faces, m_num_local_boundary_faces;
     int*         m_ranks          = nullptr;
     t8_locidx_t* m_indices        = nullptr;

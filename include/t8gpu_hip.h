@@ -296,6 +296,20 @@ int t8gpu_hip_subgrid_adapt_variables_and_volume_f64(int rank, int num_new_eleme
                                                      T8gpuVars_f64 old_variables, T8gpuVars_f64 new_variables,
                                                      const double* volume_old, double* volume_new, void* stream);
 
+/* ---- read-back for the VTK writers ---------------------------------------------------------
+ * column_major_to_z_order<Subgrid><<<>>>: subgrid_mesh_manager.inl:1008-1049 -- cell (i,j,k) of every block to
+ * the z-order position it has once the block is refined uniformly twice (how the reference hands Subgrid
+ * data to t8_forest_write_vtk_ext). from != to; both [num_elements * 4^rank]. */
+int t8gpu_hip_column_major_to_z_order_f32(int rank, int num_elements, const float* from, float* to, void* stream);
+int t8gpu_hip_column_major_to_z_order_f64(int rank, int num_elements, const double* from, double* to, void* stream);
+/* get_host_scalar_variable / get_host_vector_variable (mesh_manager.inl:516-586, subgrid_mesh_manager.inl:
+ * 1140-1183): the device-side half -- cast to double, vectors interleaved xyz -- so that the host needs one
+ * copy of `out` (device memory, n resp. 3 n doubles). */
+int t8gpu_hip_host_scalar_variable_f32(size_t n, const float* variable, double* out, void* stream);
+int t8gpu_hip_host_scalar_variable_f64(size_t n, const double* variable, double* out, void* stream);
+int t8gpu_hip_host_vector_variable_f32(size_t n, const float* v0, const float* v1, const float* v2, double* out, void* stream);
+int t8gpu_hip_host_vector_variable_f64(size_t n, const double* v0, const double* v1, const double* v2, double* out, void* stream);
+
 /* ---- diagnostics -----------------------------------------------------------------------------------------
  * Element-wise evaluation of the fast-tier scalar helpers (reciprocal / division / sqrt / log without the
  * IEEE special-case handling, and the logarithmic mean built on them: kernels.cu:24-36) so that their

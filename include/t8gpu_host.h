@@ -76,6 +76,20 @@ void t8gpu_plan_subgrid_order(const void* plan, int32_t* block_order);
 /* bf_off[N+1], bf_ent[n_entries], face_rec[(F+B)*4], plus[N*rank] (the +side face of each block, or -1) */
 void t8gpu_plan_subgrid_arrays(const void* plan, int32_t* bf_off, int32_t* bf_ent, int32_t* face_rec, int32_t* plus);
 
+/* ---- VTK output (stands where t8_forest_write_vtk_ext is called: mesh_manager.inl:588-623,
+ * subgrid_mesh_manager.inl:1051-1138,1185-1206) ------------------------------------------------------------
+ * One .vtu piece: a VTK_QUAD / VTK_HEXAHEDRON per leaf with unshared corners, cell fields treeid, mpirank,
+ * level, element_id and `num_fields` user fields (components 1 = scalar, 3 = xyz vector; doubles, one value
+ * or triple per CELL). cells_per_dim = 4 writes every block as its 4^dim cells in z-order (level + 2), the
+ * layout t8gpu_hip_column_major_to_z_order produces. ascii != 0: text arrays, else appended raw binary.
+ * Returns 0, or 1 bad argument / 2 cannot open / 3 write error. */
+int t8gpu_host_write_vtu(const char* path, int dim, int64_t num_elements, const double* centre, const int32_t* level,
+                         int cells_per_dim, int mpirank, int64_t first_element_id, int num_fields, const char* const* names,
+                         const int32_t* components, const double* const* data, int ascii);
+/* The .pvtu that lists the per-rank pieces (written by rank 0). */
+int t8gpu_host_write_pvtu(const char* path, int num_pieces, const char* const* piece_files, int num_fields,
+                          const char* const* names, const int32_t* components);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,10 +43,10 @@ def _run(cmd):
 
 def build_host(force=False):
     srcs = _glob(os.path.join(CSRC, "host"), (".cpp",))
-    deps = srcs + _glob(os.path.join(CSRC, "host"), (".h", ".hpp"))
+    deps = srcs + _glob(os.path.join(CSRC, "host"), (".h", ".hpp")) + [os.path.join(ROOT, "include", "t8gpu_host.h")]
     if force or _newer(HOST_LIB, deps):
         os.makedirs(LIB, exist_ok=True)
-        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fopenmp", "-Wall", "-o", HOST_LIB] + srcs)
+        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fopenmp", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", HOST_LIB] + srcs)
     return HOST_LIB
 
 

@@ -90,6 +90,16 @@ struct Solver {
   }
   ~Solver() { (void)hipFree(speed); }
 
+  // the example's output step, written as the reference writes it (examples/compressible_euler/solver.cu:177-186)
+  void save_conserved_variables_to_vtk(std::string prefix) const {
+    std::array<VariableList, 3> momentum = {Rho_v1, Rho_v2, Rho_v3};
+    std::vector<SyntheticMeshManager<VariableList, StepList, dim>::HostVariableInfo> variables;
+    variables.push_back(mesh.get_host_scalar_variable(next, Rho, "density"));
+    variables.push_back(mesh.get_host_scalar_variable(next, Rho_e, "energy"));
+    variables.push_back(mesh.get_host_vector_variable(next, momentum, "momentum"));
+    mesh.save_variables_to_vtk(std::move(variables), prefix);
+  }
+
   // A: the reference's iterate(), launch for launch (solver.cu:75-175)
   void iterate_user_kernels(float_type delta_t) {
     std::swap(next, prev);
@@ -169,7 +179,12 @@ int main(int argc, char** argv) {
   m.face_surfaces.resize(cnt[2] + cnt[3]);
   m.volumes.resize(cnt[0] + cnt[1]);
   t8gpu_synth_part_connectivity(part, m.face_neighbors.data(), m.face_normals.data(), m.face_surfaces.data(), nullptr, nullptr);
-  t8gpu_synth_part_elements(part, nullptr, m.volumes.data(), nullptr);
+  std::vector<int32_t> lev(cnt[0] + cnt[1]);
+  std::vector<double>  cen(3 * (cnt[0] + cnt[1]));
+  t8gpu_synth_part_elements(part, lev.data(), m.volumes.data(), cen.data());
+  m.mesh_dim = mdim;
+  m.levels.assign(lev.begin(), lev.begin() + cnt[0]);
+  m.centres.assign(cen.begin(), cen.begin() + 3 * cnt[0]);
   std::vector<double> ic(5 * (cnt[0] + cnt[1]));
   t8gpu_synth_part_kh_ic(part, 1, ic.data(), cnt[0] + cnt[1]);
   const float_type delta_t = static_cast<float_type>(0.1 * std::pow(0.5, t8gpu_synth_mesh_finest_level(mesh)));
@@ -194,6 +209,8 @@ int main(int argc, char** argv) {
     std::fwrite(v.data(), sizeof(float_type), v.size(), f);
   }
   std::fclose(f);
+  // the example's output step (examples/compressible_euler/solver.cu:231-262): density + momentum to VTK
+  if (argc > 8) c.save_conserved_variables_to_vtk(argv[8]);
   t8gpu_synth_part_destroy(part);
   t8gpu_synth_mesh_destroy(mesh);
   return 0;

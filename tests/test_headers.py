@@ -49,7 +49,8 @@ def test_reference_style_solver_matches_the_oracle(ft, tol, args, tmp_path):
     out = str(tmp_path / "out.bin")
     steps = 3
     dim, base, lmax, band, periodic = args
-    subprocess.run([exe, str(dim), str(base), str(lmax), str(band), str(periodic), str(steps), out], check=True, timeout=300)
+    vtk_prefix = str(tmp_path / "kh")
+    subprocess.run([exe, str(dim), str(base), str(lmax), str(band), str(periodic), str(steps), out, vtk_prefix], check=True, timeout=300)
     raw = open(out, "rb").read()
     n, fsz, nsteps = np.frombuffer(raw[:12], np.int32)
     npdt = np.float32 if ft == "float" else np.float64
@@ -65,6 +66,13 @@ def test_reference_style_solver_matches_the_oracle(ft, tol, args, tmp_path):
     want = o.current()[:, :n]
     for name, got in zip(("user kernels on the accessor API", "C-ABI compat kernels", "fused step driver"), res):
         assert rel_err(got, want) < tol * 5, name
+    # save_conserved_variables_to_vtk of the fused solver: the file holds exactly its state
+    from _vtu import read_vtu
+    v = read_vtu(vtk_prefix + ".vtu")
+    assert v["n_cells"] == n
+    assert np.array_equal(v["arrays"]["density"], res[2][0].astype(np.float64))
+    assert np.array_equal(v["arrays"]["energy"], res[2][4].astype(np.float64))
+    assert np.array_equal(v["arrays"]["momentum"], res[2][1:4].T.astype(np.float64))
 
 
 @pytest.mark.gpu
