@@ -16,7 +16,9 @@ class T8gpuPlainPlan(C.Structure):
 
 
 class PlainPlan:
-    def __init__(self, part, dtype, tmax=None, fcap=None, compressed=True):
+    def __init__(self, part, dtype, tmax=None, fcap=None, compressed=True, dictionary=True):
+        """compressed=False: generic kernel (CSR lists, full geometry). dictionary=False: pipelined kernel
+        with per-face geometry rows even where the mesh has few distinct ones (what curved meshes get anyway)."""
         import os
         tmax = int(os.environ.get("T8GPU_TMAX", 256)) if tmax is None else tmax     # tuning knobs of the tiling
         fcap = int(os.environ.get("T8GPU_FCAP", 512)) if fcap is None else fcap
@@ -39,7 +41,7 @@ class PlainPlan:
         if compressed:
             extra = {"ell": self.host.ell.view(np.int16)}
             c.ell_width = self.host.ell_width
-            if self.host.geo_table.shape[0] > 0:
+            if dictionary and self.host.geo_table.shape[0] > 0:
                 extra["geo_idx"] = self.host.geo_idx.view(np.int16)
                 extra["geo_table"] = self.host.geo_table.astype(npf)
                 c.n_geo = self.host.geo_table.shape[0]

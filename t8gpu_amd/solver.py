@@ -46,7 +46,7 @@ class PlainSolver:
     mode = "fused": tile kernels (flux + RK in one pass, no flux planes in HBM)."""
 
     def __init__(self, part, dtype=torch.float64, flux_kind=hip.KEPES, mode="compat", capacity=None, state=None,
-                 device=None):
+                 device=None, plan_options=None):
         if not torch.cuda.is_available():
             raise hip.T8gpuHipError("PlainSolver needs a GPU: the hot path has no CPU implementation")
         hip.lib()
@@ -67,7 +67,7 @@ class PlainSolver:
         self.plan = None
         if mode == "fused":
             from . import fused
-            self.plan = fused.PlainPlan(part, dtype)
+            self.plan = fused.PlainPlan(part, dtype, **(plan_options or {}))
         elif mode != "compat":
             raise ValueError(mode)
 
