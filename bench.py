@@ -30,9 +30,13 @@ WORKLOADS = {
     "c2": dict(kind="plain", dim=2, base=6, lmax=11, band=0.0596, dtype="f64", desc="2D KH AMR levels 6-11 (~1.03 M elements)"),
     "c3": dict(kind="subgrid", dim=3, base=5, lmax=6, band=0.17, dtype="f32", desc="3D Subgrid<4,4,4> AMR levels 5-6"),
     "c4": dict(kind="plain", dim=2, base=7, lmax=12, band=0.1472, dtype="f64", desc="2D KH AMR levels 7-12 (~9.93 M elements)"),
-    # BASELINE config 5 needs a real t8code mixed tet/hex cmesh; this is its geometry-synthetic stand-in (hex only,
-    # no repartition): it exercises the 3D plain-element path (phi = 3, 6-24 faces per element) at that size.
+    # BASELINE config 5 needs a real t8code mixed-element cmesh; these are its geometry-synthetic stand-ins (no
+    # repartition inside the timed region): c5 = 3D hex AMR (phi = 3, 6-24 faces per element, Cartesian normals),
+    # c5p = conforming prisms + hexahedra on a curved shell sector (5 / 6 faces, a different oblique normal on every
+    # face: the mesh class of the reference's own example, examples/compressible_euler/main.cu:20-24).
     "c5": dict(kind="plain", dim=3, base=6, lmax=8, band=0.05, dtype="f64", desc="3D hex AMR levels 6-8 (~3.93 M elements), geometry-synthetic"),
+    "c5p": dict(kind="plain", dim=3, prism=(128, 128, 160), dtype="f64",
+                desc="3D prisms + hexahedra on a curved shell, 128x128x160 cells half split (~3.93 M elements), geometry-synthetic"),
 }
 
 
@@ -104,13 +108,18 @@ def main():
             mode = "compat"
 
     t0 = time.time()
-    mesh = SynthMesh(w["dim"], w["base"], w["lmax"], band=w["band"])
-    part = mesh.partition(rank, world, subgrid=(w["kind"] == "subgrid"))
+    if "prism" in w:
+        from t8gpu_amd.unstructured import PrismHexMesh
+        mesh = PrismHexMesh(w["prism"], split=0.5)
+        part = mesh.partition(rank, world)
+    else:
+        mesh = SynthMesh(w["dim"], w["base"], w["lmax"], band=w["band"])
+        part = mesh.partition(rank, world, subgrid=(w["kind"] == "subgrid"))
     n_global = mesh.num_elements
     cells = part.cells_per_element
     if w["kind"] == "plain":
         solver = PlainSolver(part, tdtype, flux_kind=kindf, mode=mode)
-        delta_t = 0.1 * 2.0 ** -mesh.finest_level
+        delta_t = 0.1 * float(mesh.volumes.min()) ** (1 / 3) if "prism" in w else 0.1 * 2.0 ** -mesh.finest_level
     else:
         solver = SubgridSolver(part, tdtype, flux_kind=kindf, mode=mode)
         delta_t = 0.1 * 2.0 ** -(mesh.finest_level + 2)

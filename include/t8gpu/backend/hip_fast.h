@@ -83,7 +83,7 @@ namespace t8gpu::hip {
                                         m.num_local_boundary_faces, ndim, m.face_neighbors.data(), m.face_normals.data(),
                                         m.face_surfaces.data(), tmax, fcap);
       if (!h) T8GPU_ABORT("t8gpu_plan_plain_create failed");
-      int64_t sz[12];
+      int64_t sz[16];
       t8gpu_plan_plain_sizes(h, sz);
       const size_t nt = sz[0], nhalo = sz[1], nfaces = sz[2], ncsr = sz[3], N = sz[8], w = sz[10], ngeo = sz[11];
       std::vector<int32_t>  elem_off(nt + 1), halo_off(nt + 1), face_off(nt + 1), halo_ids(nhalo), face_orig(nfaces),
@@ -111,7 +111,7 @@ namespace t8gpu::hip {
       m_plan.ntiles = static_cast<int32_t>(nt); m_plan.n_interior_tiles = static_cast<int32_t>(sz[7]);
       m_plan.max_elems = static_cast<int32_t>(sz[4]); m_plan.max_halo = static_cast<int32_t>(sz[5]);
       m_plan.max_faces = static_cast<int32_t>(sz[6]); m_plan.ell_width = static_cast<int32_t>(w);
-      m_plan.n_geo = static_cast<int32_t>(ngeo); m_plan.reserved = 0;
+      m_plan.n_geo = static_cast<int32_t>(ngeo); m_plan.max_slots = static_cast<int32_t>(sz[12]);
       T8GPU_HIP_CHECK_ABI(t8gpu_hip_plain_stepper_create(&m_plan, nullptr, &m_stepper));
     }
     ~PlainFusedPlan() {

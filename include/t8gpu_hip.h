@@ -132,11 +132,13 @@ typedef struct T8gpuPlainPlan {
   const int32_t*  tile_order; /* [ntiles] interior tiles first, then tiles reading ghost slots    */
   int32_t ntiles, n_interior_tiles, max_elems, max_halo, max_faces, ell_width;
   /* optional compressed forms (NULL = absent); with them and tiles of <= 256 elements, <= 512 own+halo
-   * elements and <= 512 faces the software-pipelined kernel variant is used */
+   * elements and <= 1024 faces the software-pipelined kernel variant is used (two passes of 256 faces up
+   * to 512 faces per tile, up to four above) */
   const uint16_t* ell;        /* [N][ell_width] copy of the CSR lists, 0xFFFF-padded, 16-byte rows      */
   const uint16_t* geo_idx;    /* per tile face: row of geo_table                                      */
   const void*     geo_table;  /* float_type [n_geo][12]: distinct {nx,ny,nz,area, t1x,t1y,t1z,0, t2x,t2y,t2z,0} */
-  int32_t n_geo, reserved;
+  int32_t n_geo;
+  int32_t max_slots;          /* max over tiles of own + halo elements (0: unknown, max_elems + max_halo is used) */
 } T8gpuPlainPlan;
 
 /* tile_begin/tile_count select a range of tile_order (0, ntiles = everything; [0, n_interior) can run

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_plain_fused(T8gpuPlainPlan P, int tile_
   extern __shared__ double lds_raw[];
   T* const      lds = reinterpret_cast<T*>(lds_raw);
   constexpr int NW  = KIND == 0 ? kPrimWords : 5;  // words per element kept in LDS
-  const int     LE  = P.max_elems + P.max_halo;    // element slots per LDS plane
+  const int     LE  = P.max_slots > 0 ? P.max_slots : P.max_elems + P.max_halo;    // element slots per LDS plane
   const int     LF  = P.max_faces;
   T* const      pe  = lds;                         // [NW][LE]
   T* const      ff  = lds + (size_t)NW * LE;       // [5][LF]
@@ -198,7 +198,10 @@ T8_DEV void load_prim(const T* pe, int LE, int i, Prim<T>& q) {
   q.beta = pe[5 * LE + i]; q.lrho = pe[6 * LE + i]; q.lbeta = pe[7 * LE + i]; q.v0 = pe[8 * LE + i];
 }
 
-template <class T, int KIND, int STAGE, bool DICT>
+// MAXP = 2: at most 512 faces per tile, both passes' face records loaded in the prologue (2D meshes).
+// MAXP = 4: up to 1024 faces per tile (3D meshes: a 256-element tile has ~3 faces per element plus its
+// surface); the record of pass p + 1 is fetched at the top of pass p, so two are live at any time.
+template <class T, int KIND, int STAGE, bool DICT, int MAXP>
 __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int tile_begin, FVars<T> prev, FVars<T> src,
                                                        FVars<T> out, const T* __restrict__ vol, T dt,
                                                        T* __restrict__ speed) {
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
   using V4 = typename vec4<T>::type;
   T* const      lds = reinterpret_cast<T*>(lds_raw);
   constexpr int NW  = KIND == 0 ? kPrimWords : 5;
-  const int     LE  = P.max_elems + P.max_halo;
+  const int     LE  = P.max_slots > 0 ? P.max_slots : P.max_elems + P.max_halo;
   T* const      pe  = lds;
   T* const      ff  = lds + (size_t)NW * LE;  // [5][256]: one pass of 256 faces at a time
 
@@ -226,25 +229,31 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
   for (int k = 0; k < 5; k++) s0[k] = src.p[k][slot0];
 #pragma unroll
   for (int k = 0; k < 5; k++) s1[k] = src.p[k][slot1];
-  const int      fb = tid + 256;
-  const bool     va = tid < nf, vb = fb < nf;
-  const uint32_t lra = P.face_lr[f0 + (va ? tid : 0)];
-  const uint32_t lrb = P.face_lr[f0 + (vb ? fb : 0)];
-  V4             gma = {}, gmb = {};
-  int            gia = 0, gib = 0;
-  if (DICT) {  // only the 2-byte row index travels with the face; the (cache-resident) row is read in phase 2
-    gia = 3 * P.geo_idx[f0 + (va ? tid : 0)];
-    gib = 3 * P.geo_idx[f0 + (vb ? fb : 0)];
-  } else {
-    const V4* __restrict__ geo = reinterpret_cast<const V4*>(P.face_geo) + f0;
-    gma = geo[va ? tid : 0];
-    gmb = geo[vb ? fb : 0];
-  }
-  int oa = -1, ob = -1;
-  if (speed && KIND == 0) {
-    oa = P.face_orig[f0 + (va ? tid : 0)];
-    ob = P.face_orig[f0 + (vb ? fb : 0)];
-  }
+  // one pass's worth of the lane's face: packed slots, geometry (row index or the row itself), original id
+  struct FaceIn {
+    bool     valid;
+    uint32_t lr;
+    V4       gm;
+    int      gi, orig;
+  };
+  auto load_face = [&](int pass) {
+    FaceIn f;
+    const int i = tid + 256 * pass;
+    f.valid = i < nf;
+    const int j = f0 + (f.valid ? i : 0);
+    f.lr = P.face_lr[j];
+    f.gm = V4{};
+    f.gi = 0;
+    if (DICT)  // only the 2-byte row index travels with the face; the (cache-resident) row is read in phase 2
+      f.gi = 3 * P.geo_idx[j];
+    else
+      f.gm = reinterpret_cast<const V4*>(P.face_geo)[j];
+    f.orig = (speed && KIND == 0) ? P.face_orig[j] : -1;
+    return f;
+  };
+  FaceIn fin[MAXP + 1];
+  fin[0] = load_face(0);
+  fin[1] = load_face(1);
   const int e = e0 + (own ? tid : 0);
   T         pv[5] = {T(0), T(0), T(0), T(0), T(0)}, volume = T(1);   // fetched behind the last flux pass (register budget)
   const uint4* __restrict__ ellrow = reinterpret_cast<const uint4*>(P.ell + (size_t)e * P.ell_width);
@@ -272,21 +281,21 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
   // ---- phases 2 + 3, one pass of 256 faces at a time (halves the LDS flux buffer -> 4 workgroups/CU) ---
   T acc[5] = {T(0), T(0), T(0), T(0), T(0)};
 #pragma unroll
-  for (int it = 0; it < 2; it++) {
-    const bool     valid = it == 0 ? va : vb;
-    const uint32_t lr    = it == 0 ? lra : lrb;
-    const int      orig  = it == 0 ? oa : ob;
-    if (it == 1 && nf <= 256) break;
-    if (valid) {
-      const V4 gm = DICT ? reinterpret_cast<const V4*>(P.geo_table)[it == 0 ? gia : gib] : (it == 0 ? gma : gmb);
-      const int  l = lr & 0xFFFFu, r16 = lr >> 16;
+  for (int it = 0; it < MAXP; it++) {
+    if (it > 0 && nf <= 256 * it) break;
+    if (MAXP > 2 && it >= 1 && it + 1 < MAXP) fin[it + 1] = load_face(it + 1);   // next pass's record flies during this pass
+    const FaceIn& fi   = fin[it];
+    const bool    last = it == MAXP - 1 || nf <= 256 * (it + 1);
+    if (fi.valid) {
+      const V4 gm = DICT ? reinterpret_cast<const V4*>(P.geo_table)[fi.gi] : fi.gm;
+      const int  l = fi.lr & 0xFFFFu, r16 = fi.lr >> 16;
       const bool wall = r16 == 0xFFFFu;
       const int  r = wall ? l : r16;
       const T    n[3] = {gm.x, gm.y, gm.z};
       T          t1[3], t2[3], g[5], spd = T(0);
       if (DICT) {  // frame precomputed per distinct normal (table rows are L1/L2 resident)
         const V4* __restrict__ tab = reinterpret_cast<const V4*>(P.geo_table);
-        const V4 b1 = tab[(it == 0 ? gia : gib) + 1], b2 = tab[(it == 0 ? gia : gib) + 2];
+        const V4 b1 = tab[fi.gi + 1], b2 = tab[fi.gi + 2];
         t1[0] = b1.x; t1[1] = b1.y; t1[2] = b1.z;
         t2[0] = b2.x; t2[1] = b2.y; t2[2] = b2.z;
       } else {
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
         load_prim<T>(pe, LE, l, L);
         load_prim<T>(pe, LE, r, R);
         kepes_prim<T>(L, R, wall, n, t1, t2, gm.w, g, spd);
-        if (orig >= 0) speed[orig] = spd;
+        if (fi.orig >= 0) speed[fi.orig] = spd;
       } else {
         T sl[5], sr[5];
 #pragma unroll
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
 #pragma unroll
       for (int k = 0; k < 5; k++) ff[k * 256 + tid] = g[k];
     }
-    if (it == 1 || nf <= 256) {  // last pass: start the RK stage's loads; they fly during the barrier + gather
+    if (MAXP == 2 && last) {  // last pass: start the RK stage's loads; they fly during the barrier + gather
       if (STAGE > 1) {
 #pragma unroll
         for (int k = 0; k < 5; k++) pv[k] = prev.p[k][e];
@@ -323,9 +332,16 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
       ell_accumulate<T>(ell0, it, ff, acc, done);
       for (int c = 1; c < P.ell_width / 8 && !done; c++) ell_accumulate<T>(ellrow[c], it, ff, acc, done);
     }
-    if (it == 0 && nf > 256) __syncthreads();   // the buffer is rewritten by the second pass
+    if (!last) __syncthreads();   // the buffer is rewritten by the next pass
   }
 
+  if (MAXP > 2) {  // (the last pass is not known at compile time here: fetched after the loop, other workgroups cover it)
+    if (STAGE > 1) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) pv[k] = prev.p[k][e];
+    }
+    volume = vol[e];
+  }
   // ---- RK stage (ssp_runge_kutta.inl:30-99) ---------------------------------------------------------
   if (own) {
     const T scale = dt / volume;
@@ -361,9 +377,11 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
   const int   nw = kind == 0 ? kPrimWords : 5;
   hipStream_t s  = static_cast<hipStream_t>(stream);
   const dim3  grid(tile_count), block(256);
+  const int   slots = plan->max_slots > 0 ? plan->max_slots : plan->max_elems + plan->max_halo;
   const bool  pipelined = plan->ell && plan->ell_width >= 8 && plan->ell_width % 8 == 0 && plan->max_elems <= 256 &&
-                         plan->max_elems + plan->max_halo <= 512 && plan->max_faces <= 512;
-  const size_t lds = sizeof(T) * ((size_t)nw * (plan->max_elems + plan->max_halo) + (size_t)5 * (pipelined ? 256 : plan->max_faces));
+                         slots <= 512 && plan->max_faces <= 1024;
+  const bool  four = plan->max_faces > 512;
+  const size_t lds = sizeof(T) * ((size_t)nw * slots + (size_t)5 * (pipelined ? 256 : plan->max_faces));
   if (lds > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
   const bool  dict = pipelined && plan->geo_idx && plan->geo_table && plan->n_geo > 0;
 #define T8_LAUNCH(KERNEL)                                                                                    \
@@ -378,10 +396,14 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
   } while (0)
 #define T8_FUSED(K, S)                                              \
   do {                                                              \
-    if (dict)                                                       \
-      T8_LAUNCH((k_plain_fused_p<T, K, S, true>));                  \
+    if (dict && !four)                                              \
+      T8_LAUNCH((k_plain_fused_p<T, K, S, true, 2>));               \
+    else if (dict)                                                  \
+      T8_LAUNCH((k_plain_fused_p<T, K, S, true, 4>));               \
+    else if (pipelined && !four)                                    \
+      T8_LAUNCH((k_plain_fused_p<T, K, S, false, 2>));              \
     else if (pipelined)                                             \
-      T8_LAUNCH((k_plain_fused_p<T, K, S, false>));                 \
+      T8_LAUNCH((k_plain_fused_p<T, K, S, false, 4>));              \
     else                                                            \
       T8_LAUNCH((k_plain_fused<T, K, S>));                          \
   } while (0)

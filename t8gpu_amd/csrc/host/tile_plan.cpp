@@ -22,7 +22,7 @@ namespace {
 
 struct TilePlan {
   int32_t N = 0, G = 0, F = 0, B = 0, ndim = 3, tmax = 256, fcap = 512;
-  int32_t max_halo = 0, max_faces = 0, max_elems = 0, n_interior = 0;
+  int32_t max_halo = 0, max_faces = 0, max_elems = 0, n_interior = 0, max_slots = 0;
   std::vector<int32_t>  elem_off, halo_off, face_off;  // [ntiles + 1]
   std::vector<int32_t>  halo_ids;                      // slots
   std::vector<uint32_t> face_lr;                       // l | r << 16 (tile-local; r = 0xFFFF: wall mirror)
@@ -65,20 +65,32 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
     return fn[2 * static_cast<size_t>(f) + which];
   };
 
-  // greedy tiling: grow the element range while elements <= tmax and distinct faces <= fcap
+  // greedy tiling: grow the element range while elements <= tmax, distinct faces <= fcap and own + halo
+  // elements <= lecap (the kernel's LDS window). The halo count is tracked incrementally: an element that
+  // joins the tile stops being halo, its neighbours outside the range become halo.
   P.elem_off.assign(1, 0);
   std::vector<int32_t> seen(static_cast<size_t>(F) + B, -1);
   {
+    std::vector<int32_t> hstamp(static_cast<size_t>(N) + P.G, -1);
     int32_t e = 0, tile = 0;
     while (e < N) {
-      int32_t nf = 0, start = e;
+      int32_t nf = 0, nh = 0, start = e;
       while (e < N && e - start < P.tmax) {
-        int32_t add = 0;
-        for (int32_t j = deg[e]; j < deg[e + 1]; j++)
+        int32_t add = 0, dh = hstamp[e] == tile ? -1 : 0;
+        for (int32_t j = deg[e]; j < deg[e + 1]; j++) {
           if (seen[ef[j]] != tile) add++;
-        if (e > start && nf + add > P.fcap) break;
+          for (int w = 0; w < 2; w++) {
+            const int32_t o = side(ef[j], w);
+            if (o >= 0 && (o < start || o > e) && hstamp[o] != tile) {
+              hstamp[o] = tile;   // (stamped even if e is rejected below: the tile ends there, the stamp with it)
+              dh++;
+            }
+          }
+        }
+        if (e > start && (nf + add > P.fcap || (e - start + 1) + nh + dh > P.lecap)) break;
         for (int32_t j = deg[e]; j < deg[e + 1]; j++) seen[ef[j]] = tile;
         nf += add;
+        nh += dh;
         e++;
       }
       P.elem_off.push_back(e);
@@ -175,6 +187,7 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
     P.max_halo  = std::max<int32_t>(P.max_halo, static_cast<int32_t>(halo.size()));
     P.max_faces = std::max<int32_t>(P.max_faces, static_cast<int32_t>(tf.size()));
     P.max_elems = std::max<int32_t>(P.max_elems, ne);
+    P.max_slots = std::max<int32_t>(P.max_slots, ne + static_cast<int32_t>(halo.size()));
   }
   P.tile_order.clear();
   for (int32_t t = 0; t < ntiles; t++)
@@ -250,7 +263,7 @@ void* t8gpu_plan_plain_create(int32_t N, int32_t G, int32_t F, int32_t B, int32_
 }
 void t8gpu_plan_plain_destroy(void* h) { delete static_cast<TilePlan*>(h); }
 
-// sizes[12] = {ntiles, n_halo, n_faces, n_csr, max_elems, max_halo, max_faces, n_interior_tiles, N, F,
+// sizes[16] = {ntiles, n_halo, n_faces, n_csr, max_elems, max_halo, max_faces, n_interior_tiles, N, F,
 //              ell_width, n_geo (0: no dictionary)}
 void t8gpu_plan_plain_sizes(const void* h, int64_t* sizes) {
   const TilePlan* P = static_cast<const TilePlan*>(h);
@@ -266,6 +279,8 @@ void t8gpu_plan_plain_sizes(const void* h, int64_t* sizes) {
   sizes[9] = P->F;
   sizes[10] = P->ell_width;
   sizes[11] = static_cast<int64_t>(P->geo_table.size() / 12);
+  sizes[12] = P->max_slots;
+  sizes[13] = sizes[14] = sizes[15] = 0;
 }
 
 void t8gpu_plan_plain_compressed(const void* h, uint16_t* ell, uint16_t* geo_idx, double* geo_table) {

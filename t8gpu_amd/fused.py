@@ -12,7 +12,7 @@ class T8gpuPlainPlan(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in HostPlainPlan.FIELDS] + [
         ("ntiles", C.c_int32), ("n_interior_tiles", C.c_int32), ("max_elems", C.c_int32), ("max_halo", C.c_int32),
         ("max_faces", C.c_int32), ("ell_width", C.c_int32), ("ell", C.c_void_p), ("geo_idx", C.c_void_p),
-        ("geo_table", C.c_void_p), ("n_geo", C.c_int32), ("reserved", C.c_int32)]
+        ("geo_table", C.c_void_p), ("n_geo", C.c_int32), ("max_slots", C.c_int32)]
 
 
 class PlainPlan:
@@ -21,6 +21,9 @@ class PlainPlan:
         with per-face geometry rows even where the mesh has few distinct ones (what curved meshes get anyway)."""
         import os
         tmax = int(os.environ.get("T8GPU_TMAX", 256)) if tmax is None else tmax     # tuning knobs of the tiling
+        # 512 faces = two passes of 256. Larger tiles (the kernel takes up to 1024 faces in four passes) were
+        # measured on 3D meshes, where 512 cuts tiles at ~130-150 elements: 768 / 1024 are 1-8 % SLOWER (LDS per
+        # workgroup grows, 3 instead of 4 workgroups per CU), so 512 stays the default for every mesh.
         fcap = int(os.environ.get("T8GPU_FCAP", 512)) if fcap is None else fcap
         self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap)
         self.dtype = dtype
@@ -51,6 +54,7 @@ class PlainPlan:
                 setattr(c, name, t.data_ptr())
         c.ntiles, c.n_interior_tiles = self.host.ntiles, self.host.n_interior
         c.max_elems, c.max_halo, c.max_faces = self.host.max_elems, self.host.max_halo, self.host.max_faces
+        c.max_slots = self.host.max_slots
         self.c = c
 
     def stage(self, solver, stage, src, dst, dt, stream, tile_begin=0, tile_count=None):

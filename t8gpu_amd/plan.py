@@ -39,7 +39,7 @@ class HostPlainPlan:
         if not h:
             raise ValueError("tile plan exceeds the packed index format (use smaller tmax / fcap)")
         try:
-            sz = np.zeros(12, np.int64)
+            sz = np.zeros(16, np.int64)
             lib.t8gpu_plan_plain_sizes(h, p(sz))
             (self.ntiles, n_halo, n_faces, n_csr, self.max_elems, self.max_halo, self.max_faces,
              self.n_interior) = (int(x) for x in sz[:8])
@@ -55,7 +55,7 @@ class HostPlainPlan:
             self.csr_ent = np.zeros(n_csr, np.uint16)
             self.tile_order = np.zeros(self.ntiles, np.int32)
             lib.t8gpu_plan_plain_arrays(h, *(p(getattr(self, f)) for f in self.FIELDS))
-            self.ell_width, n_geo = int(sz[10]), int(sz[11])
+            self.ell_width, n_geo, self.max_slots = int(sz[10]), int(sz[11]), int(sz[12])
             self.ell = np.zeros((N, self.ell_width), np.uint16)
             self.geo_idx = np.zeros(n_faces if n_geo else 0, np.uint16)
             self.geo_table = np.zeros((n_geo, 12), np.float64)

@@ -39,7 +39,7 @@ def test_fused_iterate_vs_oracle(dtype, kind, mesh_args):
 
 
 @pytest.mark.parametrize("tmax,fcap,compressed", [(256, 512, False), (64, 100, True), (17, 40, True), (256, 10 ** 6, True),
-                                                  (200, 300, False)])
+                                                  (200, 300, False), (256, 700, True), (256, 1024, True)])
 def test_fused_is_independent_of_the_tiling(tmax, fcap, compressed):
     """Pipelined (ELL + geometry dictionary) and generic kernel variants, any tiling: bitwise equal."""
     from t8gpu_amd import fused

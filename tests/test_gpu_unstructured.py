@@ -13,7 +13,8 @@ from t8gpu_amd.unstructured import PrismHexMesh, shell_map, wavy_map
 
 pytestmark = pytest.mark.gpu
 DTYPES = [torch.float64, torch.float32]
-VARIANTS = {"dictionary": {}, "per-face geometry": dict(dictionary=False), "generic": dict(compressed=False)}
+VARIANTS = {"dictionary": {}, "per-face geometry": dict(dictionary=False), "generic": dict(compressed=False),
+            "four passes": dict(fcap=1024), "four passes, per-face geometry": dict(fcap=1024, dictionary=False)}
 
 
 def time_step(part):
