@@ -180,3 +180,92 @@ def adapt_subgrid(solver, threshold=0.02, min_level=1, max_level=6, family_membe
              hip.ptr(new.volumes), hip.stream_ptr())
     torch.cuda.synchronize()
     return new, marks, adapt_data
+
+
+class PartitionedSubgridAdapt:
+    """adapt() + partition() for an SFC-partitioned Subgrid run (SubgridMeshManager::adapt followed by
+    SubgridMeshManager::partition, t8gpu/mesh/subgrid_mesh_manager.inl:428-558, 1217-1369), one rank per GPU.
+
+    Same scheme as PartitionedAdapt: the forest operations are replicated, each rank transfers its own blocks
+    on the device (block-wise injection / mean, subgrid_mesh_manager.inl:246-425) and ships contiguous runs of
+    adapted blocks -- 5 x 4^rank values + one volume per block, one message per destination -- to their
+    owners in the new equal split. A run of blocks is contiguous in every variable plane, so a message is
+    six slices; no gather kernel is needed."""
+
+    def __init__(self, solver, all_criteria, threshold=0.02, min_level=1, max_level=6, family_members_averaged=4):
+        from .solver import SubgridSolver
+        part = solver.part
+        self.solver, self.rank, self.world = solver, part.rank, part.nranks
+        mesh, S = part.mesh, solver.S
+        self.S = S
+        old_off = mesh.partition_offsets(self.world)
+        marks = mesh.marks_from_criteria(all_criteria, threshold, min_level, max_level, family_members_averaged)
+        self.marks = mesh.unmark_split_families(marks, old_off[1:-1])
+        self.new_mesh, adapt_data = mesh.adapt(self.marks)
+        n_new = self.new_mesh.num_elements
+        self.have_off = np.searchsorted(adapt_data[:-1], old_off, side="left").astype(np.int64)
+        self.have_off[-1] = n_new
+        self.new_off = self.new_mesh.partition_offsets(self.world)
+        a, b = int(self.have_off[self.rank]), int(self.have_off[self.rank + 1])
+        self.n_have = b - a
+        dtype, dev = solver.dtype, solver.planes.device
+        self.tmp = torch.zeros((5, max(1, self.n_have) * S), dtype=dtype, device=dev)
+        self.tmp_vol = torch.zeros(max(1, self.n_have), dtype=dtype, device=dev)
+        if self.n_have:
+            ad_local = torch.from_numpy((adapt_data[a:b + 1] - old_off[self.rank]).astype(np.int32)).to(dev)
+            hip.call("t8gpu_hip_subgrid_adapt_variables_and_volume", dtype, solver.rank, self.n_have, hip.ptr(ad_local),
+                     solver.get_own_variables(solver.next), hip.vars_of(self.tmp), hip.ptr(solver.volumes), hip.ptr(self.tmp_vol),
+                     hip.stream_ptr())
+        self.new_part = self.new_mesh.partition(self.rank, self.world, subgrid=True)
+        tot = self.new_part.N + self.new_part.G
+        self.new_solver = SubgridSolver(self.new_part, dtype, flux_kind=solver.kind, mode=solver.mode, state=np.zeros((5, tot * S)))
+        self.new_solver.next, self.new_solver.prev = solver.next, solver.prev
+        self.sends, self.recvs = [], []
+        lo_r, hi_r = int(self.new_off[self.rank]), int(self.new_off[self.rank + 1])
+        for q in range(self.world):
+            s0, s1 = max(a, int(self.new_off[q])), min(b, int(self.new_off[q + 1]))
+            if s1 > s0:
+                self.sends.append((q, s0 - a, s1 - s0))                  # (peer, first block in tmp, count)
+            r0, r1 = max(int(self.have_off[q]), lo_r), min(int(self.have_off[q + 1]), hi_r)
+            if r1 > r0:
+                self.recvs.append((q, r0 - lo_r, r1 - r0))               # (peer, first block in the new planes, count)
+        w = 5 * S + 1
+        self.sendbufs, self.recvbufs = {}, {}
+        for q, first, n in self.sends:
+            if q != self.rank:
+                buf = torch.empty(w * n, dtype=dtype, device=dev)
+                buf[: 5 * S * n].view(5, n * S).copy_(self.tmp[:, first * S:(first + n) * S])
+                buf[5 * S * n:].copy_(self.tmp_vol[first:first + n])
+                self.sendbufs[q] = buf
+        for q, _, n in self.recvs:
+            if q != self.rank:
+                self.recvbufs[q] = torch.empty(w * n, dtype=dtype, device=dev)
+
+    transport = PartitionedAdapt.transport
+
+    def finish(self):
+        new, S = self.new_solver, self.S
+        dst = new.planes[5 * new.next:5 * new.next + 5]
+        for q, first, n in self.recvs:
+            if q == self.rank:
+                src_first = [f for p, f, m in self.sends if p == self.rank][0]
+                dst[:, first * S:(first + n) * S] = self.tmp[:, src_first * S:(src_first + n) * S]
+                new.volumes[first:first + n] = self.tmp_vol[src_first:src_first + n]
+            else:
+                buf = self.recvbufs[q]
+                dst[:, first * S:(first + n) * S] = buf[: 5 * S * n].view(5, n * S)
+                new.volumes[first:first + n] = buf[5 * S * n:]
+        torch.cuda.synchronize()
+        return new
+
+
+def adapt_subgrid_partitioned(solver, dist, **kw):
+    """Collective: every rank calls it with its own SubgridSolver; returns the rank's new solver."""
+    crit = subgrid_refinement_criteria(solver).double()
+    world = solver.part.nranks
+    off = solver.part.mesh.partition_offsets(world)
+    chunks = [torch.empty(int(off[r + 1] - off[r]), dtype=torch.float64, device=crit.device) for r in range(world)]
+    dist.all_gather(chunks, crit)
+    pa = PartitionedSubgridAdapt(solver, torch.cat(chunks).cpu().numpy(), **kw)
+    pa.transport(dist)
+    return pa.finish()

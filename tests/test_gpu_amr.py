@@ -210,3 +210,64 @@ def test_subgrid_adaptive_run_stays_conservative():
             g.iterate(dt)
     assert len(set(sizes)) > 1 and bool(torch.isfinite(g.state()).all())
     assert abs(mass(g) - m0) < 1e-12 * abs(m0)
+
+
+@pytest.mark.parametrize("world,dim", [(2, 2), (3, 3)])
+def test_partitioned_subgrid_adapt_and_repartition_equals_single_rank(world, dim):
+    """Subgrid blocks: k ranks on one GPU (loopback transport) against the single-rank adapt with the same marks;
+    the repartitioned run then advances and stays bitwise equal to the single-rank run on the adapted mesh."""
+    from t8gpu_amd.halo import HaloExchange
+    from t8gpu_amd.solver import SubgridSolver
+    from test_gpu_halo import loopback
+    mesh = SynthMesh(dim, 2, 3, band=0.1)
+    whole = mesh.partition(subgrid=True)
+    S = 4 ** dim
+    st = whole.kh_initial_state().copy()
+    rough = np.arange(whole.N * S) < (whole.N // 5) * S                  # a rough patch at the start of the curve:
+    st[0, rough] *= 1 + 0.3 * np.random.default_rng(3).random(int(rough.sum()))   # refinement there only => blocks move
+    ref = SubgridSolver(whole, torch.float64, mode="fused", state=st)
+    parts = [mesh.partition(r, world, subgrid=True) for r in range(world)]
+    solvers = []
+    for p in parts:
+        gidx = np.concatenate([p.first_global + np.arange(p.N), p.ghost_global])
+        cells = (gidx[:, None] * S + np.arange(S)[None, :]).reshape(-1)
+        solvers.append(SubgridSolver(p, torch.float64, mode="fused", state=st[:, cells]))
+    kw = dict(threshold=0.02, min_level=2, max_level=4)
+    all_crit = np.concatenate([amr.subgrid_refinement_criteria(s).double().cpu().numpy() for s in solvers])
+    assert np.array_equal(all_crit, amr.subgrid_refinement_criteria(ref).double().cpu().numpy())
+    pas = [amr.PartitionedSubgridAdapt(s, all_crit, **kw) for s in solvers]
+    by_rank = {p.rank: p for p in pas}
+    for p in pas:
+        for q, _, n in p.sends:
+            if q != p.rank:
+                by_rank[q].recvbufs[p.rank].copy_(p.sendbufs[q])
+    news = [p.finish() for p in pas]
+    new_mesh, ad = mesh.adapt(pas[0].marks)
+    npart = new_mesh.partition(subgrid=True)
+    assert new_mesh.num_elements != mesh.num_elements
+    want = SubgridSolver(npart, torch.float64, mode="fused", state=np.zeros((5, npart.N * S)))
+    hip.call("t8gpu_hip_subgrid_adapt_variables_and_volume", torch.float64, dim, npart.N, hip.ptr(torch.from_numpy(ad).cuda()),
+             ref.get_own_variables(ref.next), want.get_own_variables(want.next), hip.ptr(ref.volumes), hip.ptr(want.volumes),
+             hip.stream_ptr())
+    torch.cuda.synchronize()
+    assert sum(n.N for n in news) == npart.N and max(n.N for n in news) - min(n.N for n in news) <= 1
+    assert torch.equal(torch.cat([n.state() for n in news], dim=1), want.state())
+    assert torch.equal(torch.cat([n.volumes[: n.N] for n in news]), want.volumes[: npart.N])
+    assert any(len(p.sends) > 1 for p in pas)
+    # advance both: ghosts of the new partition arrive through the exchange
+    halos = [HaloExchange(n.part, torch.float64, dist=None, overlap=False) for n in news]
+    dt = 0.1 * 2.0 ** -(new_mesh.finest_level + 2)
+    for _ in range(2):
+        want.iterate(dt)
+        for s in news:
+            s.begin_step()
+        for k in range(3):
+            for s, h in zip(news, halos):
+                h._pack(s.step_planes(s.stage_steps(k)[0]))
+            loopback(halos)
+            for s, h in zip(news, halos):
+                h._unpack(s.step_planes(s.stage_steps(k)[0]))
+            for s in news:
+                s.run_stage(k, dt, split=True)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([n.state() for n in news], dim=1), want.state())
