@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""One-GPU estimate of what the halo machinery costs a rank of the 8-way strong-scaled c4 run.
+
+Takes rank 3's share of the c4 mesh split 8 ways (1.24 M elements, ~3 k ghosts) and times the native C++
+stepper (a) without any exchange and (b) with the full per-stage sequence -- event, pack kernel, RCCL
+grouped send/recv, unpack kernel, event, interior tiles || exchange, ghost-reading tiles -- where every
+peer is mapped onto this rank itself (RCCL self send/recv, message sizes made symmetric). The payload does
+not cross xGMI, so (b) - (a) is the launch / synchronisation overhead of the overlap scheme, not link time;
+the ghost VALUES are meaningless here and the result of (b) is not checked.
+usage: halo_overhead.py [world=8] [rank=3] [steps=200]"""
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from t8gpu_amd import native  # noqa: E402
+from t8gpu_amd.solver import PlainSolver  # noqa: E402
+from t8gpu_amd.synth import SynthMesh  # noqa: E402
+
+
+def main():
+    world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    rank = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+    mesh = SynthMesh(2, 7, 12, band=0.1472)
+    part = mesh.partition(rank, world)
+    dt = 0.1 * 2.0 ** -mesh.finest_level
+    print(f"rank {rank}/{world}: N={part.N} G={part.G} peers={part.peers.tolist()}", flush=True)
+
+    def timed(solver):
+        for _ in range(20):
+            solver.iterate(dt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            solver.iterate(dt)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    a = PlainSolver(part, torch.float64, mode="fused")
+    a.use_native_stepper()
+    ta = timed(a)
+    print(f"(a) no exchange            : {ta:.4f} ms/step  ({a.plan.host.ntiles} tiles, {a.plan.host.n_interior} interior)", flush=True)
+
+    # symmetric self-exchange: message j carries min(send_j, recv_j) elements both ways
+    m = np.minimum(np.diff(part.send_off), np.diff(part.recv_off))
+    fake = types.SimpleNamespace(N=part.N, G=int(m.sum()), cells_per_element=1, peers=np.zeros(len(m), np.int32),
+                                 send_off=np.concatenate([[0], np.cumsum(m)]).astype(np.int32),
+                                 recv_off=np.concatenate([[0], np.cumsum(m)]).astype(np.int32),
+                                 send_idx=np.concatenate([part.send_idx[part.send_off[j]: part.send_off[j] + m[j]] for j in range(len(m))]).astype(np.int32))
+    comm = native.NativeComm(0, 1, lambda b, src: b)
+    halo = native.NativeHalo(fake, torch.float64, comm)
+    # the exchange alone: latency of one (pack, grouped send/recv, unpack) sequence, and back-to-back rate
+    planes = a.step_planes(a.next)
+    for _ in range(10):
+        halo.exchange(planes)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(100):
+        halo.exchange(planes)
+        torch.cuda.synchronize()
+    lat = (time.perf_counter() - t0) / 100 * 1e6
+    t0 = time.perf_counter()
+    for _ in range(300):
+        halo.exchange(planes)
+    torch.cuda.synchronize()
+    rate = (time.perf_counter() - t0) / 300 * 1e6
+    print(f"exchange alone: {lat:.1f} us with a sync after each, {rate:.1f} us back to back", flush=True)
+    b = PlainSolver(part, torch.float64, mode="fused")
+    b.use_native_stepper(halo)
+    tb = timed(b)
+    if native.stream_wait(torch.cuda.current_stream(), 30.0) != 0:
+        comm.abort()
+        sys.exit("exchange did not drain")
+    print(f"(b) self-exchange per stage: {tb:.4f} ms/step  ({len(m)} messages of {m.tolist()} elements)", flush=True)
+    print(f"overhead of the overlap scheme: {tb - ta:+.4f} ms/step = {(tb - ta) / 3 * 1e3:+.1f} us/stage; "
+          f"8-way ideal would be {1.0:.2f}x of (a), this is {tb / ta:.3f}x", flush=True)
+    one = 1.40   # ms/step of the whole mesh on one GPU (bench.py c4)
+    print(f"projected strong-scaling speedup at {world} ranks if every rank behaves like this one: "
+          f"{one / tb:.2f}x (no exchange: {one / ta:.2f}x)", flush=True)
+    comm.destroy()
+
+
+if __name__ == "__main__":
+    main()

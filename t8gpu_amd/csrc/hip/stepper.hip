@@ -36,7 +36,8 @@ struct Stepper {
   T8gpuHalo      halo{};
   std::vector<int32_t> peers, send_off, recv_off;
   hipStream_t    comm_stream = nullptr;
-  hipEvent_t     ev_state = nullptr, ev_ghost = nullptr;
+  hipEvent_t     ev_state = nullptr, ev_ghost = nullptr;   // step entry / last boundary launch
+  hipEvent_t     ev_interior = nullptr;                  // last interior launch
   bool           timing = false;
   std::vector<hipEvent_t> pool;   // start/stop pairs of the stage-kernel launches
   size_t         used = 0;
@@ -107,29 +108,40 @@ int iterate(Stepper* S, int kind, T* planes, size_t stride, int prev, int next, 
     const V sv = step_vars<V>(planes, stride, src[k]);
     const V ov = step_vars<V>(planes, stride, dst[k]);
     const bool comm = S->has_halo && S->halo.n_peers > 0;
-    if (comm) {
+    auto launch = [&](int b, int n, hipStream_t on) -> int {
+      T8_TRY(tick(S, on));
+      if constexpr (sizeof(T) == 4) {
+        T8_TRY(t8gpu_hip_plain_fused_stage_f32(kind, k + 1, &S->plan, b, n, pv, sv, ov, vol, dt, speed, on));
+      } else {
+        T8_TRY(t8gpu_hip_plain_fused_stage_f64(kind, k + 1, &S->plan, b, n, pv, sv, ov, vol, dt, speed, on));
+      }
+      return tick(S, on);
+    };
+    if (!comm) {
+      T8_TRY(launch(0, nt, s));
+      continue;
+    }
+    // Two chained pipelines, one cross-stream dependency each way per stage, both usually satisfied by the
+    // time they are reached (measured on one rank of the 8-way c4 split):
+    //   comm stream: pack -> RCCL -> unpack -> [interior tiles of the previous stage done] -> ghost-reading tiles
+    //   caller's s : [ghost-reading tiles of the previous stage done] -> interior tiles
+    // pack only reads elements next to a cut face; those belong to ghost-reading tiles, i.e. to the comm
+    // stream's own previous launch, so the exchange of stage k starts the moment the boundary of stage k-1 is
+    // done, beside that stage's interior tiles. The ghost-reading tiles fill the CUs the interior launch's
+    // tail leaves idle instead of waiting behind it.
+    if (k == 0) {  // step entry: the comm stream must see everything the caller queued on s
       T8_HIP_TRY(hipEventRecord(S->ev_state, s));
       T8_HIP_TRY(hipStreamWaitEvent(S->comm_stream, S->ev_state, 0));
-      T8_TRY((exchange<T, V>(S->halo, S->peers.data(), S->send_off.data(), S->recv_off.data(), sv, S->comm_stream)));
-      T8_HIP_TRY(hipEventRecord(S->ev_ghost, S->comm_stream));
-    }
-    auto launch = [&](int b, int n) -> int {
-      T8_TRY(tick(S, s));
-      if constexpr (sizeof(T) == 4) {
-        T8_TRY(t8gpu_hip_plain_fused_stage_f32(kind, k + 1, &S->plan, b, n, pv, sv, ov, vol, dt, speed, s));
-      } else {
-        T8_TRY(t8gpu_hip_plain_fused_stage_f64(kind, k + 1, &S->plan, b, n, pv, sv, ov, vol, dt, speed, s));
-      }
-      return tick(S, s);
-    };
-    if (!comm || ni == 0 || ni == nt) {
-      if (comm) T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_ghost, 0));
-      T8_TRY(launch(0, nt));
     } else {
-      T8_TRY(launch(0, ni));
-      T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_ghost, 0));
-      T8_TRY(launch(ni, nt - ni));
+      T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_ghost, 0));   // halo elements owned by ghost-reading tiles of stage k-1
     }
+    T8_TRY((exchange<T, V>(S->halo, S->peers.data(), S->send_off.data(), S->recv_off.data(), sv, S->comm_stream)));
+    if (k > 0) T8_HIP_TRY(hipStreamWaitEvent(S->comm_stream, S->ev_interior, 0));   // halo elements owned by interior tiles
+    if (nt > ni) T8_TRY(launch(ni, nt - ni, S->comm_stream));
+    T8_HIP_TRY(hipEventRecord(S->ev_ghost, S->comm_stream));
+    if (ni > 0) T8_TRY(launch(0, ni, s));
+    T8_HIP_TRY(hipEventRecord(S->ev_interior, s));
+    if (k == 2) T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_ghost, 0));   // step exit: everything is ordered on s again
   }
   return 0;
 }
@@ -192,9 +204,13 @@ int t8gpu_hip_plain_stepper_create(const T8gpuPlainPlan* plan, const T8gpuHalo* 
     S->peers.assign(halo->peers, halo->peers + halo->n_peers);
     S->send_off.assign(halo->send_off, halo->send_off + halo->n_peers + 1);
     S->recv_off.assign(halo->recv_off, halo->recv_off + halo->n_peers + 1);
+    // Normal priority on purpose: a high-priority comm stream was measured (rocprofv3 kernel trace, one rank
+    // of the 8-way c4 split) to make everything slower -- tile kernels 49 -> 90-150 us, the 5 us pack / unpack
+    // kernels up to 90 us, 50 us gaps -- the queue preempts the running tile waves instead of waiting for a slot.
     hipError_t e = hipStreamCreateWithFlags(&S->comm_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_state, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_ghost, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_interior, hipEventDisableTiming);
     if (e != hipSuccess) {
       delete S;
       return static_cast<int>(e);
@@ -210,6 +226,7 @@ int t8gpu_hip_plain_stepper_destroy(void* h) {
   for (hipEvent_t e : S->pool) (void)hipEventDestroy(e);
   if (S->ev_state) (void)hipEventDestroy(S->ev_state);
   if (S->ev_ghost) (void)hipEventDestroy(S->ev_ghost);
+  if (S->ev_interior) (void)hipEventDestroy(S->ev_interior);
   if (S->comm_stream) (void)hipStreamDestroy(S->comm_stream);
   delete S;
   return 0;

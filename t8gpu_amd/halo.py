@@ -96,9 +96,18 @@ class HaloExchange:
         self.recvbuf.copy_(recv_h)
 
     # -- one exchange, split so that compute can run between start() and finish() ----------------
-    def start(self, planes5):
-        """planes5: the [5, stride] view of the step whose ghost slots must be refreshed."""
+    @property
+    def overlapped(self):
+        """True when start() runs on a second stream (so work can be queued behind the unpack there)."""
+        return bool(self.peers) and self.comm_stream is not None
+
+    def start(self, planes5, then=None):
+        """planes5: the [5, stride] view of the step whose ghost slots must be refreshed. `then` (optional) is
+        called right behind the unpack with the comm stream current: the ghost-reading tiles go there, so
+        that they start as soon as the ghosts are in, beside the interior tiles on the main stream."""
         if not self.peers:
+            if then is not None:
+                then()
             return
         if self.comm_stream is not None:
             self.ev_state.record()                       # everything that produced planes5 is on the main stream
@@ -107,11 +116,15 @@ class HaloExchange:
                 self._pack(planes5)
                 self._transport()
                 self._unpack(planes5)
+                if then is not None:
+                    then()
                 self.ev_ghost.record()
         else:
             self._pack(planes5)
             self._transport()
             self._unpack(planes5)
+            if then is not None:
+                then()
 
     def finish(self):
         if self.peers and self.comm_stream is not None:

@@ -142,6 +142,13 @@ class PlainSolver:
         the fused kernels run the interior tiles first and the ghost-reading tiles after finish()."""
         s = hip.stream_ptr(stream)
         src, dst = self.stage_steps(k)
+        ni, nt = (self.plan.host.n_interior, self.plan.host.ntiles) if self.mode == "fused" else (0, 0)
+        if halo is not None and halo.overlapped and 0 < ni < nt:
+            # boundary pipeline on the comm stream: ghosts, then the tiles that read them; interior tiles beside it
+            halo.start(self.step_planes(src), then=lambda: self.plan.stage(self, k + 1, src, dst, delta_t, hip.stream_ptr(), ni, nt - ni))
+            self.plan.stage(self, k + 1, src, dst, delta_t, s, 0, ni)
+            halo.finish()
+            return
         if halo is not None:
             halo.start(self.step_planes(src))
         if self.mode == "compat":
@@ -246,6 +253,13 @@ class SubgridSolver:
         blocks that touch no ghost block first and the others after the ghosts have arrived."""
         s = hip.stream_ptr(stream)
         src, dst = self.stage_steps(k)
+        ni, nt = (self.plan.host.n_interior, self.N) if self.mode == "fused" else (0, 0)
+        if halo is not None and halo.overlapped and 0 < ni < nt:
+            # boundary pipeline on the comm stream: ghost blocks, then the blocks that read them; the rest beside it
+            halo.start(self.step_planes(src), then=lambda: self.plan.stage(self, k + 1, src, dst, delta_t, hip.stream_ptr(), ni, nt - ni))
+            self.plan.stage(self, k + 1, src, dst, delta_t, s, 0, ni)
+            halo.finish()
+            return
         if halo is not None:
             halo.start(self.step_planes(src))
         if self.mode == "compat":

@@ -130,3 +130,47 @@ def test_k_way_subgrid_partition_on_one_gpu_equals_single_rank(world, mode, dim)
     assert rel_err(full, ref.state().cpu().numpy()) < 1e-13
     if mode == "fused":
         assert np.array_equal(full, ref.state().cpu().numpy())      # same sums in the same order on every rank
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_native_stepper_with_rccl_self_exchange_on_a_symmetric_problem(dtype):
+    """The C++ step driver with its RCCL exchange and two-stream pipeline, with REAL data dependencies, on one
+    GPU: the mesh and the state are invariant under y -> y + 1/2, which maps the lower half of the Morton
+    curve (rank 0 of 2) onto the upper half (rank 1) in order. What rank 1 would send to rank 0 is then
+    exactly what rank 0 sends to rank 1, so rank 0 can exchange with ITSELF through a one-rank RCCL
+    communicator and must reproduce the single-rank run on its half. (Not bitwise: the single-rank run
+    lists the faces at y = 1/2 and at the periodic seam with opposite orientations, so it is symmetric only up
+    to rounding; a ghost that is one stage stale would be off by O(dt) ~ 1e-4, far above the tolerance.)"""
+    import types
+    from t8gpu_amd import fused, native
+    mesh = SynthMesh(2, 5, 8, band=0.05)
+    whole, half = mesh.partition(), mesh.partition(0, 2)
+    assert half.N * 2 == whole.N and half.peers.tolist() == [1]
+    assert np.array_equal(np.diff(half.send_off), np.diff(half.recv_off))
+    x, y = whole.centres[:, 0], whole.centres[:, 1]
+    rho = 1.5 + 0.4 * np.sin(4 * np.pi * y) * np.cos(2 * np.pi * x)
+    v1, v2 = 0.3 * np.cos(4 * np.pi * y), 0.2 * np.sin(2 * np.pi * x) * np.sin(4 * np.pi * y)
+    st = np.stack([rho, rho * v1, rho * v2, 0 * rho, 2.5 / 0.4 + 0.5 * rho * (v1 * v1 + v2 * v2)])
+    n2 = whole.N // 2
+    assert np.allclose(st[:, :n2], st[:, n2:], atol=1e-14)               # the symmetry the test relies on
+    st[:, n2:] = st[:, :n2]                                               # ... made exact
+    ref = PlainSolver(whole, dtype, mode="fused", state=st)
+    gidx = np.concatenate([np.arange(half.N), half.ghost_global])
+    local = st[:, gidx].copy()
+    local[:, half.N:] = np.nan                                            # ghosts must arrive through RCCL
+    g = PlainSolver(half, dtype, mode="fused", state=local, plan_options=dict(tmax=64, fcap=160))
+    assert 0 < g.plan.host.n_interior < g.plan.host.ntiles
+    comm = native.NativeComm(0, 1, lambda b, src: b)
+    fake = types.SimpleNamespace(N=half.N, G=half.G, cells_per_element=1, peers=np.zeros(1, np.int32), send_off=half.send_off,
+                                 recv_off=half.recv_off, send_idx=half.send_idx)
+    g.use_native_stepper(native.NativeHalo(fake, dtype, comm))
+    dt = 0.1 * 2.0 ** -mesh.finest_level
+    for _ in range(6):
+        ref.iterate(dt)
+        g.iterate(dt)
+    assert native.stream_wait(torch.cuda.current_stream(), 30.0) == 0
+    want, got = ref.state().cpu().numpy(), g.state().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_err(got, want[:, : half.N]) < (1e-12 if dtype == torch.float64 else 1e-5)
+    g.stepper = None
+    comm.destroy()
