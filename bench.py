@@ -150,9 +150,13 @@ def main():
 
     def run(nsteps, timed):
         if stepper is not None:
+            # the native driver takes all steps of a region in ONE call: the exchange stream and the compute stream
+            # then meet at the entry and the exit of the region only (csrc/hip/stepper.hip)
             stepper.timing(timed)
+            solver.iterate_steps(nsteps, delta_t)
+            return
         for _ in range(nsteps):
-            solver.kernel_timer = timers if (timed and stepper is None) else None
+            solver.kernel_timer = timers if timed else None
             solver.iterate(delta_t, halo=halo)
 
     def fence():
@@ -161,13 +165,21 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # untimed pre-warm (clocks, caches, lazy RCCL channels) before the W warm-up steps of the contract
-    prewarm = 0
+    # untimed pre-warm (clocks, caches, lazy RCCL channels) before the W warm-up steps of the contract. Every rank
+    # must run the SAME number of steps (each step exchanges halos), so the count comes from an all-reduced timing
+    # of a first batch, never from a rank's own clock.
+    fence()
     tp = time.perf_counter()
-    while time.perf_counter() - tp < args.prewarm_seconds:
-        run(10, False)
-        prewarm += 10
-        torch.cuda.synchronize()
+    run(10, False)
+    fence()
+    t10 = time.perf_counter() - tp
+    if dist is not None:
+        tt = torch.tensor([t10], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t10 = float(tt.item())
+    more = int(min(max(args.prewarm_seconds - t10, 0.0) / max(t10, 1e-6) * 10, 20000))
+    run(more, False)
+    prewarm = 10 + more
     run(args.warmup, False)
     fence()
     t1 = time.perf_counter()

@@ -112,6 +112,7 @@ namespace t8gpu::hip {
       m_plan.max_elems = static_cast<int32_t>(sz[4]); m_plan.max_halo = static_cast<int32_t>(sz[5]);
       m_plan.max_faces = static_cast<int32_t>(sz[6]); m_plan.ell_width = static_cast<int32_t>(w);
       m_plan.n_geo = static_cast<int32_t>(ngeo); m_plan.max_slots = static_cast<int32_t>(sz[12]);
+      m_plan.n_deep_tiles = static_cast<int32_t>(sz[13]); m_plan.reserved = 0;
       T8GPU_HIP_CHECK_ABI(t8gpu_hip_plain_stepper_create(&m_plan, nullptr, &m_stepper));
     }
     ~PlainFusedPlan() {

@@ -129,7 +129,8 @@ typedef struct T8gpuPlainPlan {
   const int32_t*  face_orig;  /* original face index if this tile reports the speed, else -1      */
   const int32_t*  csr_off;    /* [N+1] into csr_ent                                               */
   const uint16_t* csr_ent;    /* tile-local face | 0x8000 when the element is the face's right side */
-  const int32_t*  tile_order; /* [ntiles] interior tiles first, then tiles reading ghost slots    */
+  const int32_t*  tile_order; /* [ntiles] deep-interior tiles, then interior tiles that read an element
+                               * owned by a ghost-reading tile, then the tiles reading ghost slots */
   int32_t ntiles, n_interior_tiles, max_elems, max_halo, max_faces, ell_width;
   /* optional compressed forms (NULL = absent); with them and tiles of <= 256 elements, <= 512 own+halo
    * elements and <= 1024 faces the software-pipelined kernel variant is used (two passes of 256 faces up
@@ -139,6 +140,8 @@ typedef struct T8gpuPlainPlan {
   const void*     geo_table;  /* float_type [n_geo][12]: distinct {nx,ny,nz,area, t1x,t1y,t1z,0, t2x,t2y,t2z,0} */
   int32_t n_geo;
   int32_t max_slots;          /* max over tiles of own + halo elements (0: unknown, max_elems + max_halo is used) */
+  int32_t n_deep_tiles;       /* leading tiles of tile_order that read nothing a ghost-reading tile owns (0: unknown) */
+  int32_t reserved;
 } T8gpuPlainPlan;
 
 /* tile_begin/tile_count select a range of tile_order (0, ntiles = everything; [0, n_interior) can run
@@ -198,14 +201,23 @@ int t8gpu_hip_halo_exchange_f64(const T8gpuHalo* halo, T8gpuVars_f64 state, void
 
 /* CompressibleEulerSolver::iterate (solver.cu:75-175) as one call: `planes` is the MemoryManager
  * allocation (26 planes of `stride`, plane = step*5+var, volume = plane 25; memory_manager.h:460), prev /
- * next the step ids AFTER the caller's std::swap (solver.cu:76). Enqueues 3 x [exchange on an internal
- * second stream || interior tiles, then ghost-reading tiles] on `stream` and returns; no host sync. */
+ * next the step ids AFTER the caller's std::swap (solver.cu:76). Enqueues, per stage, the exchange and the
+ * ghost-reading tiles on an internal second stream beside the interior tiles on `stream` (the dependency
+ * scheme is described in csrc/hip/stepper.hip) and returns; no host sync. Work queued on `stream` before
+ * the call is seen by it, work queued after the call sees its result.
+ * iterate_steps: n_steps consecutive steps in one call, prev / next given for the FIRST step and swapped
+ * from step to step (after an odd n_steps the caller's roles are swapped once more); the two streams then
+ * meet only at the entry and the exit of the call instead of once per step. */
 int t8gpu_hip_plain_stepper_create(const T8gpuPlainPlan* plan, const T8gpuHalo* halo_or_null, void** stepper);
 int t8gpu_hip_plain_stepper_destroy(void* stepper);
 int t8gpu_hip_plain_stepper_iterate_f32(void* stepper, int flux_kind, float* planes, size_t stride, int prev, int next,
                                         float delta_t, float* speed_estimates, void* stream);
 int t8gpu_hip_plain_stepper_iterate_f64(void* stepper, int flux_kind, double* planes, size_t stride, int prev, int next,
                                         double delta_t, double* speed_estimates, void* stream);
+int t8gpu_hip_plain_stepper_iterate_steps_f32(void* stepper, int flux_kind, float* planes, size_t stride, int prev, int next,
+                                              float delta_t, float* speed_estimates, int n_steps, void* stream);
+int t8gpu_hip_plain_stepper_iterate_steps_f64(void* stepper, int flux_kind, double* planes, size_t stride, int prev, int next,
+                                              double delta_t, double* speed_estimates, int n_steps, void* stream);
 /* optional HIP-event timing of the stage kernels (for roofline accounting) */
 int t8gpu_hip_plain_stepper_timing(void* stepper, int enable);
 int t8gpu_hip_plain_stepper_elapsed(void* stepper, double* total_ms, int* launches);

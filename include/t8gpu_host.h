@@ -55,7 +55,7 @@ int   t8gpu_synth_mesh_adapt_data(const void* old_mesh, const void* new_mesh, in
 void* t8gpu_plan_plain_create(int32_t N, int32_t G, int32_t F, int32_t B, int32_t ndim, const int32_t* face_neighbors,
                               const double* normals, const double* areas, int32_t tmax, int32_t fcap);
 void  t8gpu_plan_plain_destroy(void* plan);
-/* sizes[16] (entries 13-15 reserved, written as 0; 12 = max over tiles of own + halo elements) = {ntiles, n_halo, n_faces, n_csr, max_elems, max_halo, max_faces, n_interior_tiles, N, F,
+/* sizes[16] (12 = max over tiles of own + halo elements, 13 = number of deep-interior tiles, 14-15 reserved = 0) = {ntiles, n_halo, n_faces, n_csr, max_elems, max_halo, max_faces, n_interior_tiles, N, F,
  *              ell_width, n_geo} */
 void t8gpu_plan_plain_sizes(const void* plan, int64_t* sizes);
 void t8gpu_plan_plain_arrays(const void* plan, int32_t* elem_off, int32_t* halo_off, int32_t* face_off,

@@ -30,13 +30,16 @@ def main():
     dt = 0.1 * 2.0 ** -mesh.finest_level
     print(f"rank {rank}/{world}: N={part.N} G={part.G} peers={part.peers.tolist()}", flush=True)
 
-    def timed(solver):
+    def timed(solver, many=False):
         for _ in range(20):
             solver.iterate(dt)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            solver.iterate(dt)
+        if many:
+            solver.iterate_steps(steps, dt)
+        else:
+            for _ in range(steps):
+                solver.iterate(dt)
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps * 1e3
 
@@ -75,7 +78,11 @@ def main():
     if native.stream_wait(torch.cuda.current_stream(), 30.0) != 0:
         comm.abort()
         sys.exit("exchange did not drain")
-    print(f"(b) self-exchange per stage: {tb:.4f} ms/step  ({len(m)} messages of {m.tolist()} elements)", flush=True)
+    print(f"(b) self-exchange per stage: {tb:.4f} ms/step  ({len(m)} messages of {m.tolist()} elements; "
+          f"{b.plan.host.n_deep} deep / {b.plan.host.n_interior - b.plan.host.n_deep} near-boundary / "
+          f"{b.plan.host.ntiles - b.plan.host.n_interior} ghost-reading tiles)", flush=True)
+    tc = timed(b, many=True)
+    print(f"(c) same, all steps in one call: {tc:.4f} ms/step -> {1.40 / tc:.2f}x projected", flush=True)
     print(f"overhead of the overlap scheme: {tb - ta:+.4f} ms/step = {(tb - ta) / 3 * 1e3:+.1f} us/stage; "
           f"8-way ideal would be {1.0:.2f}x of (a), this is {tb / ta:.3f}x", flush=True)
     one = 1.40   # ms/step of the whole mesh on one GPU (bench.py c4)

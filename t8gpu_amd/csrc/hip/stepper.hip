@@ -98,17 +98,29 @@ int tick(Stepper* S, hipStream_t s) {
   return 0;
 }
 
+// n_steps SSP-RK3 steps; (prev, next) are the roles of the FIRST step, they swap from step to step
+// (solver.cu:76). Multi-rank pipeline, per stage g (tile classes of tile_plan.cpp: C = deep interior,
+// B = interior tiles that read an element owned by an A tile, A = tiles that read ghost slots):
+//   caller's stream s : C_g ...................... -> [A_(g-1) done] -> B_g
+//   comm stream       : pack_g -> RCCL_g -> unpack_g -> [B_(g-1) done] -> A_g
+// C_g reads only what B/C tiles of stage g-1 wrote (same stream, no wait); pack_g reads only elements next
+// to a cut face, which A tiles own (same stream, no wait); A_g reads ghosts, A- and B-owned elements. So the
+// long launch (C) never waits on the other stream, and the two cross-stream dependencies per stage are
+// normally satisfied long before they are reached. Stages two apart are ordered transitively, which is what
+// the reuse of the four step buffers needs. The streams meet only at the entry and at the exit of the call.
 template <class T, class V>
-int iterate(Stepper* S, int kind, T* planes, size_t stride, int prev, int next, T dt, T* speed, hipStream_t s) {
-  const int   src[3] = {prev, 1, 2}, dst[3] = {1, 2, next};  // Step1 = 1, Step2 = 2 (solver.h:24-31)
-  const T*    vol = planes + 25 * stride;
-  const int   ni = S->plan.n_interior_tiles, nt = S->plan.ntiles;
-  const V     pv = step_vars<V>(planes, stride, prev);
-  for (int k = 0; k < 3; k++) {
-    const V sv = step_vars<V>(planes, stride, src[k]);
-    const V ov = step_vars<V>(planes, stride, dst[k]);
-    const bool comm = S->has_halo && S->halo.n_peers > 0;
+int iterate(Stepper* S, int kind, T* planes, size_t stride, int prev, int next, T dt, T* speed, int n_steps, hipStream_t s) {
+  const T*   vol = planes + 25 * stride;
+  const int  nt = S->plan.ntiles, ni = S->plan.n_interior_tiles;
+  const int  nd = (S->plan.n_deep_tiles > 0 && S->plan.n_deep_tiles <= ni) ? S->plan.n_deep_tiles : 0;
+  const bool comm = S->has_halo && S->halo.n_peers > 0;
+  for (int g = 0; g < 3 * n_steps; g++) {
+    const int k  = g % 3;
+    const int pr = (g / 3) % 2 == 0 ? prev : next, nx = (g / 3) % 2 == 0 ? next : prev;
+    const int src = k == 0 ? pr : k, dst = k == 2 ? nx : k + 1;   // Step1 = 1, Step2 = 2 (solver.h:24-31)
+    const V   pv = step_vars<V>(planes, stride, pr), sv = step_vars<V>(planes, stride, src), ov = step_vars<V>(planes, stride, dst);
     auto launch = [&](int b, int n, hipStream_t on) -> int {
+      if (n <= 0) return 0;
       T8_TRY(tick(S, on));
       if constexpr (sizeof(T) == 4) {
         T8_TRY(t8gpu_hip_plain_fused_stage_f32(kind, k + 1, &S->plan, b, n, pv, sv, ov, vol, dt, speed, on));
@@ -121,28 +133,21 @@ int iterate(Stepper* S, int kind, T* planes, size_t stride, int prev, int next, 
       T8_TRY(launch(0, nt, s));
       continue;
     }
-    // Two chained pipelines, one cross-stream dependency each way per stage, both usually satisfied by the
-    // time they are reached (measured on one rank of the 8-way c4 split):
-    //   comm stream: pack -> RCCL -> unpack -> [interior tiles of the previous stage done] -> ghost-reading tiles
-    //   caller's s : [ghost-reading tiles of the previous stage done] -> interior tiles
-    // pack only reads elements next to a cut face; those belong to ghost-reading tiles, i.e. to the comm
-    // stream's own previous launch, so the exchange of stage k starts the moment the boundary of stage k-1 is
-    // done, beside that stage's interior tiles. The ghost-reading tiles fill the CUs the interior launch's
-    // tail leaves idle instead of waiting behind it.
-    if (k == 0) {  // step entry: the comm stream must see everything the caller queued on s
+    if (g == 0) {  // entry: the comm stream must see everything the caller queued on s
       T8_HIP_TRY(hipEventRecord(S->ev_state, s));
       T8_HIP_TRY(hipStreamWaitEvent(S->comm_stream, S->ev_state, 0));
-    } else {
-      T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_ghost, 0));   // halo elements owned by ghost-reading tiles of stage k-1
     }
+    // (every hipStreamWaitEvent below is issued before the event is re-recorded for this stage)
+    T8_TRY(launch(0, nd, s));                                                        // C_g
+    if (g > 0) T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_ghost, 0));                    // A_(g-1)
     T8_TRY((exchange<T, V>(S->halo, S->peers.data(), S->send_off.data(), S->recv_off.data(), sv, S->comm_stream)));
-    if (k > 0) T8_HIP_TRY(hipStreamWaitEvent(S->comm_stream, S->ev_interior, 0));   // halo elements owned by interior tiles
-    if (nt > ni) T8_TRY(launch(ni, nt - ni, S->comm_stream));
+    if (g > 0) T8_HIP_TRY(hipStreamWaitEvent(S->comm_stream, S->ev_interior, 0));   // B_(g-1)
+    T8_TRY(launch(ni, nt - ni, S->comm_stream));                                     // A_g
     T8_HIP_TRY(hipEventRecord(S->ev_ghost, S->comm_stream));
-    if (ni > 0) T8_TRY(launch(0, ni, s));
+    T8_TRY(launch(nd, ni - nd, s));                                                  // B_g
     T8_HIP_TRY(hipEventRecord(S->ev_interior, s));
-    if (k == 2) T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_ghost, 0));   // step exit: everything is ordered on s again
   }
+  if (comm && n_steps > 0) T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_ghost, 0));        // exit: everything is ordered on s again
   return 0;
 }
 
@@ -234,14 +239,22 @@ int t8gpu_hip_plain_stepper_destroy(void* h) {
 
 int t8gpu_hip_plain_stepper_iterate_f32(void* h, int flux_kind, float* planes, size_t stride, int prev, int next,
                                         float delta_t, float* speed, void* stream) {
-  if (!h || prev < 0 || prev > 3 || next < 0 || next > 3) return static_cast<int>(hipErrorInvalidValue);
-  return iterate<float, T8gpuVars_f32>(static_cast<Stepper*>(h), flux_kind, planes, stride, prev, next, delta_t, speed,
-                                       static_cast<hipStream_t>(stream));
+  return t8gpu_hip_plain_stepper_iterate_steps_f32(h, flux_kind, planes, stride, prev, next, delta_t, speed, 1, stream);
 }
 int t8gpu_hip_plain_stepper_iterate_f64(void* h, int flux_kind, double* planes, size_t stride, int prev, int next,
                                         double delta_t, double* speed, void* stream) {
-  if (!h || prev < 0 || prev > 3 || next < 0 || next > 3) return static_cast<int>(hipErrorInvalidValue);
-  return iterate<double, T8gpuVars_f64>(static_cast<Stepper*>(h), flux_kind, planes, stride, prev, next, delta_t, speed,
+  return t8gpu_hip_plain_stepper_iterate_steps_f64(h, flux_kind, planes, stride, prev, next, delta_t, speed, 1, stream);
+}
+int t8gpu_hip_plain_stepper_iterate_steps_f32(void* h, int flux_kind, float* planes, size_t stride, int prev, int next,
+                                              float delta_t, float* speed, int n_steps, void* stream) {
+  if (!h || prev < 0 || prev > 3 || next < 0 || next > 3 || prev == next || n_steps < 0) return static_cast<int>(hipErrorInvalidValue);
+  return iterate<float, T8gpuVars_f32>(static_cast<Stepper*>(h), flux_kind, planes, stride, prev, next, delta_t, speed, n_steps,
+                                       static_cast<hipStream_t>(stream));
+}
+int t8gpu_hip_plain_stepper_iterate_steps_f64(void* h, int flux_kind, double* planes, size_t stride, int prev, int next,
+                                              double delta_t, double* speed, int n_steps, void* stream) {
+  if (!h || prev < 0 || prev > 3 || next < 0 || next > 3 || prev == next || n_steps < 0) return static_cast<int>(hipErrorInvalidValue);
+  return iterate<double, T8gpuVars_f64>(static_cast<Stepper*>(h), flux_kind, planes, stride, prev, next, delta_t, speed, n_steps,
                                         static_cast<hipStream_t>(stream));
 }
 

@@ -22,7 +22,7 @@ namespace {
 
 struct TilePlan {
   int32_t N = 0, G = 0, F = 0, B = 0, ndim = 3, tmax = 256, fcap = 512;
-  int32_t max_halo = 0, max_faces = 0, max_elems = 0, n_interior = 0, max_slots = 0;
+  int32_t max_halo = 0, max_faces = 0, max_elems = 0, n_interior = 0, max_slots = 0, n_deep = 0;
   std::vector<int32_t>  elem_off, halo_off, face_off;  // [ntiles + 1]
   std::vector<int32_t>  halo_ids;                      // slots
   std::vector<uint32_t> face_lr;                       // l | r << 16 (tile-local; r = 0xFFFF: wall mirror)
@@ -189,9 +189,26 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
     P.max_elems = std::max<int32_t>(P.max_elems, ne);
     P.max_slots = std::max<int32_t>(P.max_slots, ne + static_cast<int32_t>(halo.size()));
   }
+  // Three classes for the multi-rank step driver: A = tiles that read ghost slots; B = other tiles that read
+  // an element owned by an A tile; C = the rest (deep interior). tile_order = C, B, A. A tile of class C
+  // depends only on B/C tiles of the previous stage, one of class A only on A/B tiles and the ghosts.
+  std::vector<uint8_t> near_boundary(ntiles, 0);
+  {
+    std::vector<int32_t> owner(static_cast<size_t>(N));
+    for (int32_t t = 0; t < ntiles; t++)
+      for (int32_t e = P.elem_off[t]; e < P.elem_off[t + 1]; e++) owner[e] = t;
+    for (int32_t t = 0; t < ntiles; t++) {
+      if (reads_ghost[t]) continue;
+      for (int32_t j = P.halo_off[t]; j < P.halo_off[t + 1] && !near_boundary[t]; j++)
+        if (reads_ghost[owner[P.halo_ids[j]]]) near_boundary[t] = 1;   // (no ghost ids here: the tile reads none)
+    }
+  }
   P.tile_order.clear();
   for (int32_t t = 0; t < ntiles; t++)
-    if (!reads_ghost[t]) P.tile_order.push_back(t);
+    if (!reads_ghost[t] && !near_boundary[t]) P.tile_order.push_back(t);
+  P.n_deep = static_cast<int32_t>(P.tile_order.size());
+  for (int32_t t = 0; t < ntiles; t++)
+    if (!reads_ghost[t] && near_boundary[t]) P.tile_order.push_back(t);
   P.n_interior = static_cast<int32_t>(P.tile_order.size());
   for (int32_t t = 0; t < ntiles; t++)
     if (reads_ghost[t]) P.tile_order.push_back(t);
@@ -280,7 +297,8 @@ void t8gpu_plan_plain_sizes(const void* h, int64_t* sizes) {
   sizes[10] = P->ell_width;
   sizes[11] = static_cast<int64_t>(P->geo_table.size() / 12);
   sizes[12] = P->max_slots;
-  sizes[13] = sizes[14] = sizes[15] = 0;
+  sizes[13] = P->n_deep;
+  sizes[14] = sizes[15] = 0;
 }
 
 void t8gpu_plan_plain_compressed(const void* h, uint16_t* ell, uint16_t* geo_idx, double* geo_table) {

@@ -12,7 +12,8 @@ class T8gpuPlainPlan(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in HostPlainPlan.FIELDS] + [
         ("ntiles", C.c_int32), ("n_interior_tiles", C.c_int32), ("max_elems", C.c_int32), ("max_halo", C.c_int32),
         ("max_faces", C.c_int32), ("ell_width", C.c_int32), ("ell", C.c_void_p), ("geo_idx", C.c_void_p),
-        ("geo_table", C.c_void_p), ("n_geo", C.c_int32), ("max_slots", C.c_int32)]
+        ("geo_table", C.c_void_p), ("n_geo", C.c_int32), ("max_slots", C.c_int32), ("n_deep_tiles", C.c_int32),
+        ("reserved", C.c_int32)]
 
 
 class PlainPlan:
@@ -54,7 +55,7 @@ class PlainPlan:
                 setattr(c, name, t.data_ptr())
         c.ntiles, c.n_interior_tiles = self.host.ntiles, self.host.n_interior
         c.max_elems, c.max_halo, c.max_faces = self.host.max_elems, self.host.max_halo, self.host.max_faces
-        c.max_slots = self.host.max_slots
+        c.max_slots, c.n_deep_tiles = self.host.max_slots, self.host.n_deep
         self.c = c
 
     def stage(self, solver, stage, src, dst, dt, stream, tile_begin=0, tile_count=None):

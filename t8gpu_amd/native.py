@@ -86,6 +86,12 @@ class NativeStepper:
                  C.c_size_t(solver.stride), solver.prev, solver.next, hip.fscalar(solver.dtype, delta_t),
                  hip.ptr(solver.speed), hip.stream_ptr(stream))
 
+    def iterate_steps(self, solver, delta_t, n_steps, prev, next, stream=None):
+        """n_steps steps in one call; prev / next are the roles of the first step."""
+        hip.call("t8gpu_hip_plain_stepper_iterate_steps", solver.dtype, self.handle, solver.kind, hip.ptr(solver.planes),
+                 C.c_size_t(solver.stride), prev, next, hip.fscalar(solver.dtype, delta_t), hip.ptr(solver.speed),
+                 C.c_int(n_steps), hip.stream_ptr(stream))
+
     def timing(self, enable):
         hip.check(hip.lib().t8gpu_hip_plain_stepper_timing(self.handle, int(enable)))
 

@@ -55,7 +55,7 @@ class HostPlainPlan:
             self.csr_ent = np.zeros(n_csr, np.uint16)
             self.tile_order = np.zeros(self.ntiles, np.int32)
             lib.t8gpu_plan_plain_arrays(h, *(p(getattr(self, f)) for f in self.FIELDS))
-            self.ell_width, n_geo, self.max_slots = int(sz[10]), int(sz[11]), int(sz[12])
+            self.ell_width, n_geo, self.max_slots, self.n_deep = int(sz[10]), int(sz[11]), int(sz[12]), int(sz[13])
             self.ell = np.zeros((N, self.ell_width), np.uint16)
             self.geo_idx = np.zeros(n_faces if n_geo else 0, np.uint16)
             self.geo_table = np.zeros((n_geo, 12), np.float64)

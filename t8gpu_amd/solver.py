@@ -174,6 +174,21 @@ class PlainSolver:
         self.stepper = native.NativeStepper(self.plan, native_halo)
         return self.stepper
 
+    def iterate_steps(self, n_steps, delta_t, stream=None, halo=None):
+        """n_steps steps with a fixed delta_t. With the native stepper this is ONE call: the exchange stream and
+        the compute stream then meet only at its entry and exit (see csrc/hip/stepper.hip)."""
+        if n_steps <= 0:
+            return
+        if getattr(self, "stepper", None) is None:
+            for _ in range(n_steps):
+                self.iterate(delta_t, stream, halo)
+            return
+        self.begin_step()
+        first_prev, first_next = self.prev, self.next
+        for _ in range(n_steps - 1):
+            self.begin_step()
+        self.stepper.iterate_steps(self, delta_t, n_steps, first_prev, first_next, stream)
+
     def iterate(self, delta_t, stream=None, halo=None):
         """One SSP-RK3 step (CompressibleEulerSolver::iterate). `halo` (a halo.HaloExchange) refreshes
         the ghost slots of each stage's source state while the interior tiles are already running."""

@@ -106,6 +106,26 @@ def test_native_stepper_equals_python_driven_iterate(dtype):
     assert n == 12 and ms > 0
 
 
+@pytest.mark.parametrize("n", [1, 2, 5])
+def test_native_stepper_many_steps_in_one_call(n):
+    mesh = SynthMesh(2, 3, 6, band=0.06)
+    part = mesh.partition()
+    st = perturbed_state(part, 9)
+    a = PlainSolver(part, torch.float64, mode="fused", state=st)
+    b = PlainSolver(part, torch.float64, mode="fused", state=st)
+    b.use_native_stepper()
+    dt = 0.1 * 2.0 ** -6
+    for _ in range(n):
+        a.iterate(dt)
+    b.iterate_steps(n, dt)
+    torch.cuda.synchronize()
+    assert (a.next, a.prev) == (b.next, b.prev)
+    assert torch.equal(a.state(), b.state())
+    b.iterate(dt)                                              # and the roles it leaves behind are the right ones
+    a.iterate(dt)
+    assert torch.equal(a.state(), b.state())
+
+
 def test_native_comm_single_rank_and_stream_wait():
     from t8gpu_amd import native
     comm = native.NativeComm(0, 1, lambda b, src: b)           # nranks = 1: bootstrap + init only
