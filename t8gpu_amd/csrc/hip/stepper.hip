@@ -35,9 +35,11 @@ struct Stepper {
   bool           has_halo = false;
   T8gpuHalo      halo{};
   std::vector<int32_t> peers, send_off, recv_off;
-  hipStream_t    comm_stream = nullptr;
+  hipStream_t    comm_stream = nullptr;   // pack, RCCL, unpack, class A tiles
+  hipStream_t    near_stream = nullptr;   // class B tiles
   hipEvent_t     ev_state = nullptr, ev_ghost = nullptr;   // step entry / last boundary launch
-  hipEvent_t     ev_interior = nullptr;                  // last interior launch
+  hipEvent_t     ev_interior = nullptr;                  // last class B launch
+  hipEvent_t     ev_deep = nullptr;                      // last class C launch
   bool           timing = false;
   std::vector<hipEvent_t> pool;   // start/stop pairs of the stage-kernel launches
   size_t         used = 0;
@@ -101,13 +103,16 @@ int tick(Stepper* S, hipStream_t s) {
 // n_steps SSP-RK3 steps; (prev, next) are the roles of the FIRST step, they swap from step to step
 // (solver.cu:76). Multi-rank pipeline, per stage g (tile classes of tile_plan.cpp: C = deep interior,
 // B = interior tiles that read an element owned by an A tile, A = tiles that read ghost slots):
-//   caller's stream s : C_g ...................... -> [A_(g-1) done] -> B_g
-//   comm stream       : pack_g -> RCCL_g -> unpack_g -> [B_(g-1) done] -> A_g
-// C_g reads only what B/C tiles of stage g-1 wrote (same stream, no wait); pack_g reads only elements next
-// to a cut face, which A tiles own (same stream, no wait); A_g reads ghosts, A- and B-owned elements. So the
-// long launch (C) never waits on the other stream, and the two cross-stream dependencies per stage are
-// normally satisfied long before they are reached. Stages two apart are ordered transitively, which is what
-// the reuse of the four step buffers needs. The streams meet only at the entry and at the exit of the call.
+//   caller's stream s : [B_(g-1)] -> C_g
+//   near stream       : [C_(g-1), A_(g-1)] -> B_g
+//   comm stream       : pack_g -> RCCL_g -> unpack_g -> [B_(g-1)] -> A_g
+// C_g reads only what B/C tiles of stage g-1 wrote; pack_g reads only elements next to a cut face, which A
+// tiles own (same stream, no wait); A_g reads ghosts, A- and B-owned elements; B_g reads all three classes
+// of stage g-1 but nothing of stage g, so it runs beside C_g instead of behind it. The long launch (C) and
+// the exchange chain therefore never wait for each other, and every bracketed dependency is normally
+// satisfied long before it is reached. Stages two apart are ordered transitively (C_g > B_(g-1) > all of
+// g-2, and so on), which is what the reuse of the four step buffers needs. The streams meet only at the
+// entry and at the exit of the call.
 template <class T, class V>
 int iterate(Stepper* S, int kind, T* planes, size_t stride, int prev, int next, T dt, T* speed, int n_steps, hipStream_t s) {
   const T*   vol = planes + 25 * stride;
@@ -133,21 +138,30 @@ int iterate(Stepper* S, int kind, T* planes, size_t stride, int prev, int next, 
       T8_TRY(launch(0, nt, s));
       continue;
     }
-    if (g == 0) {  // entry: the comm stream must see everything the caller queued on s
+    if (g == 0) {  // entry: the other streams must see everything the caller queued on s
       T8_HIP_TRY(hipEventRecord(S->ev_state, s));
       T8_HIP_TRY(hipStreamWaitEvent(S->comm_stream, S->ev_state, 0));
+      T8_HIP_TRY(hipStreamWaitEvent(S->near_stream, S->ev_state, 0));
     }
-    // (every hipStreamWaitEvent below is issued before the event is re-recorded for this stage)
-    T8_TRY(launch(0, nd, s));                                                        // C_g
-    if (g > 0) T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_ghost, 0));                    // A_(g-1)
+    // every wait on an event of stage g-1 is issued before that event is re-recorded for stage g
+    if (g > 0) {
+      T8_HIP_TRY(hipStreamWaitEvent(S->near_stream, S->ev_deep, 0));       // B_g <- C_(g-1)
+      T8_HIP_TRY(hipStreamWaitEvent(S->near_stream, S->ev_ghost, 0));      // B_g <- A_(g-1)
+      T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_interior, 0));                // C_g <- B_(g-1)
+    }
+    T8_TRY(launch(0, nd, s));                                              // C_g
+    T8_HIP_TRY(hipEventRecord(S->ev_deep, s));
     T8_TRY((exchange<T, V>(S->halo, S->peers.data(), S->send_off.data(), S->recv_off.data(), sv, S->comm_stream)));
-    if (g > 0) T8_HIP_TRY(hipStreamWaitEvent(S->comm_stream, S->ev_interior, 0));   // B_(g-1)
-    T8_TRY(launch(ni, nt - ni, S->comm_stream));                                     // A_g
+    if (g > 0) T8_HIP_TRY(hipStreamWaitEvent(S->comm_stream, S->ev_interior, 0));   // A_g <- B_(g-1)
+    T8_TRY(launch(ni, nt - ni, S->comm_stream));                           // A_g
     T8_HIP_TRY(hipEventRecord(S->ev_ghost, S->comm_stream));
-    T8_TRY(launch(nd, ni - nd, s));                                                  // B_g
-    T8_HIP_TRY(hipEventRecord(S->ev_interior, s));
+    T8_TRY(launch(nd, ni - nd, S->near_stream));                           // B_g
+    T8_HIP_TRY(hipEventRecord(S->ev_interior, S->near_stream));
   }
-  if (comm && n_steps > 0) T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_ghost, 0));        // exit: everything is ordered on s again
+  if (comm && n_steps > 0) {  // exit: everything is ordered on s again
+    T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_ghost, 0));
+    T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_interior, 0));
+  }
   return 0;
 }
 
@@ -216,6 +230,8 @@ int t8gpu_hip_plain_stepper_create(const T8gpuPlainPlan* plan, const T8gpuHalo* 
     if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_state, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_ghost, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_interior, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_deep, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&S->near_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
       delete S;
       return static_cast<int>(e);
@@ -232,7 +248,9 @@ int t8gpu_hip_plain_stepper_destroy(void* h) {
   if (S->ev_state) (void)hipEventDestroy(S->ev_state);
   if (S->ev_ghost) (void)hipEventDestroy(S->ev_ghost);
   if (S->ev_interior) (void)hipEventDestroy(S->ev_interior);
+  if (S->ev_deep) (void)hipEventDestroy(S->ev_deep);
   if (S->comm_stream) (void)hipStreamDestroy(S->comm_stream);
+  if (S->near_stream) (void)hipStreamDestroy(S->near_stream);
   delete S;
   return 0;
 }
