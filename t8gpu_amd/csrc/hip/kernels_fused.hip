@@ -12,8 +12,6 @@
 // so each XCD gets one contiguous run of tiles and neighbouring tiles' halos hit the same L2.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "flux_math.hpp"
 #include "t8gpu_hip.h"
 
@@ -383,8 +381,7 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
   const bool  pipelined = plan->ell && plan->ell_width >= 8 && plan->ell_width % 8 == 0 && plan->max_elems <= 256 &&
                          slots <= 512 && plan->max_faces <= 1024;
   const bool  four = plan->max_faces > 512;
-  static const size_t lds_pad = std::getenv("T8GPU_LDS_PAD_BYTES") ? std::strtoul(std::getenv("T8GPU_LDS_PAD_BYTES"), nullptr, 10) : 0;   // EXPERIMENT
-  const size_t lds = lds_pad + sizeof(T) * ((size_t)nw * slots + (size_t)5 * (pipelined ? 256 : plan->max_faces));
+  const size_t lds = sizeof(T) * ((size_t)nw * slots + (size_t)5 * (pipelined ? 256 : plan->max_faces));
   if (lds > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
   const bool  dict = pipelined && plan->geo_idx && plan->geo_table && plan->n_geo > 0;
 #define T8_LAUNCH(KERNEL)                                                                                    \
