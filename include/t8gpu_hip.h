@@ -229,13 +229,12 @@ int t8gpu_hip_plain_stepper_elapsed(void* stepper, double* total_ms, int* launch
  * share it) and applies the RK stage; the Fluxes planes are neither read nor written. The plan is the
  * per-block face list built by t8gpu_plan_subgrid_create() (csrc/host/subgrid_plan.cpp). */
 typedef struct T8gpuSubgridPlan {
-  const int32_t* plus;          /* [num_elements][rank] face on the block's +x/+y/+z side that is folded into the
-                                   inner passes (bit 31: block is the RIGHT side), -1 = none             */
-  const int32_t* bf_off;        /* [num_elements+1] into bf_ent                                         */
-  const int32_t* bf_ent;        /* remaining faces (bit 31: the block is the face's RIGHT side); walls first */
-  const int32_t* face_rec;      /* [F+B][4] = left slot, right slot (-1 wall), code, 0 (16-byte aligned) */
-  const void*    face_surfaces; /* float_type [F+B], the reference's face_surfaces array                 */
-  const int32_t* block_order;   /* [num_elements] blocks that touch no ghost block first, then the others  */
+  /* joined records, t8gpu_plan_subgrid_records(): one dependent load level between a wavefront's position
+   * and all of its far-cell loads */
+  const int32_t* block_rec;     /* [num_elements][16], blocks that touch no ghost block first: {block, n generic
+                                   faces, first bf_rec entry, 0, 3 x {other block, code, area (2 words)}} (64-byte rows) */
+  const int32_t* bf_rec;        /* [n_entries][4] generic faces in the same order: {other block (-1 wall), code
+                                   (bit 12: the block is the face's RIGHT side), area (2 words)}; walls first */
   int32_t num_elements, rank, max_faces_per_block, n_interior_blocks;
 } T8gpuSubgridPlan;
 

@@ -76,6 +76,11 @@ void t8gpu_plan_subgrid_order(const void* plan, int32_t* block_order);
 /* bf_off[N+1], bf_ent[n_entries], face_rec[(F+B)*4], plus[N*rank] (the +side face of each block, or -1) */
 void t8gpu_plan_subgrid_arrays(const void* plan, int32_t* bf_off, int32_t* bf_ent, int32_t* face_rec, int32_t* plus);
 
+/* The joined per-block records the fused Subgrid kernels read (layout: csrc/host/subgrid_plan.cpp):
+ * block_rec[N][16] in block_order position order, bf_rec[n_entries][4]; areas = face_surfaces[F + B] (doubles),
+ * float_size = 4 or 8 selects how the areas are stored in the records. */
+void t8gpu_plan_subgrid_records(const void* plan, const double* areas, int float_size, int32_t* block_rec, int32_t* bf_rec);
+
 /* ---- VTK output (stands where t8_forest_write_vtk_ext is called: mesh_manager.inl:588-623,
  * subgrid_mesh_manager.inl:1051-1138,1185-1206) ------------------------------------------------------------
  * One .vtu piece: a VTK_QUAD / VTK_HEXAHEDRON per leaf with unshared corners, cell fields treeid, mpirank,

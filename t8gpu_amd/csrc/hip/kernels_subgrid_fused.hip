@@ -44,7 +44,8 @@ T8_DEV int sg_xcd_position(int b, int nb) {
 // would be placed in scratch memory.
 struct FaceCode {
   int axis, positive, hanging, code;
-  T8_DEV int off(int a) const { return (code >> (4 + 2 * a)) & 3; }   // anchor inside the right block
+  T8_DEV int  off(int a) const { return (code >> (4 + 2 * a)) & 3; }   // anchor inside the right block
+  T8_DEV bool right() const { return (code >> 12) & 1; }               // joined records: this block is the face's RIGHT side
   T8_DEV int ta() const { return axis == 0 ? 1 : 0; }                  // tangential axes (i, j) of the sub-face grid
   T8_DEV int tb() const { return axis == 2 ? 1 : 2; }
 };
@@ -111,8 +112,11 @@ struct FaceLane {
   T    area, sf[5];
 };
 
+T8_DEV float  area_of(int lo, int, float) { return __int_as_float(lo); }
+T8_DEV double area_of(int lo, int hi, double) { return __hiloint2double(hi, lo); }
+
 template <class T, int S>
-T8_DEV FaceLane<T> load_face_lane(const T8gpuSubgridPlan& P, const SVars<T>& src, int b0, int nbf, int idx, int si, int sj) {
+T8_DEV FaceLane<T> load_face_lane(const T8gpuSubgridPlan& P, const SVars<T>& src, int first, int nbf, int idx, int si, int sj) {
   FaceLane<T> L;
   L.active = idx < nbf;
   L.right = L.wall = false;
@@ -121,19 +125,17 @@ T8_DEV FaceLane<T> load_face_lane(const T8gpuSubgridPlan& P, const SVars<T>& src
 #pragma unroll
   for (int k = 0; k < 5; k++) L.sf[k] = T(1);
   if (L.active) {
-    const int  ent = P.bf_ent[b0 + idx];
-    const int  fid = ent & 0x7FFFFFFF;
-    const int4 rec = reinterpret_cast<const int4*>(P.face_rec)[fid];
-    L.right        = ent < 0;
-    L.wall         = rec.y < 0;
-    L.area         = reinterpret_cast<const T*>(P.face_surfaces)[fid];
-    const FaceCode fc = decode(rec.z);
+    const int4     rec = reinterpret_cast<const int4*>(P.bf_rec)[first + idx];   // {other block, code, area}
+    const FaceCode fc  = decode(rec.y);
+    L.right = fc.right();
+    L.wall  = rec.x == -1;
+    L.area  = area_of(rec.z, rec.w, T(0));
     const int lflat = left_cell(fc, si, sj), rflat = right_cell(fc, si, sj);
     L.myflat   = L.right ? rflat : lflat;
     L.axis     = fc.axis;
     L.positive = fc.positive;
     if (!L.wall) {
-      const size_t far = (size_t)(L.right ? rec.x : rec.y) * S + (L.right ? lflat : rflat);
+      const size_t far = (size_t)rec.x * S + (L.right ? lflat : rflat);
 #pragma unroll
       for (int k = 0; k < 5; k++) L.sf[k] = src.p[k][far];
     }
@@ -149,23 +151,19 @@ struct PlusFace {
   int  lblock, rblock, code;
   T    area;
 };
-template <class T, int RANK>
-T8_DEV PlusFace<T> plus_face(const T8gpuSubgridPlan& P, int e, int d, bool live) {
+template <class T>
+T8_DEV PlusFace<T> plus_face(int4 w, bool live) {   // w = the four words of the block record for this face
   PlusFace<T> f;
   f.on = f.right = f.wall = false;
   f.lblock = f.rblock = f.code = 0;
   f.area = T(0);
-  const int ent = P.plus[(size_t)e * RANK + d];
-  if (live && ent != -1) {
-    const int  fid = ent & 0x7FFFFFFF;
-    const int4 rec = reinterpret_cast<const int4*>(P.face_rec)[fid];
+  if (live && w.x != -2) {
     f.on     = true;
-    f.right  = ent < 0;
-    f.wall   = rec.y < 0;
-    f.lblock = rec.x;
-    f.rblock = rec.y;
-    f.code   = rec.z;
-    f.area   = reinterpret_cast<const T*>(P.face_surfaces)[fid];
+    f.code   = w.y;
+    f.right  = (w.y >> 12) & 1;
+    f.wall   = w.x == -1;
+    f.lblock = f.rblock = w.x;   // the block on the far side, whichever side that is
+    f.area   = area_of(w.z, w.w, T(0));
   }
   return f;
 }
@@ -203,7 +201,11 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
   // per-block loads (volume, face lists, face records) stay scalar loads and their branches scalar branches
   const int    pos  = RANK == 3 ? sg_xcd_position(blockIdx.x, gridDim.x) : sg_xcd_position(blockIdx.x, gridDim.x) * BPW + c / S;
   const bool   live = pos < block_count;
-  const int    e    = P.block_order[block_begin + (live ? pos : 0)];
+  // ONE dependent level: the block's joined record (64 bytes; four scalar loads for RANK 3) names the block, its
+  // generic face list and the far block, code and area of its three + faces
+  const int4* __restrict__ brec = reinterpret_cast<const int4*>(P.block_rec) + 4 * (size_t)(block_begin + (live ? pos : 0));
+  const int4   r0 = brec[0];
+  const int    e  = r0.x;
   const int    cc[3] = {cl & 3, (cl >> 2) & 3, RANK == 3 ? cl >> 4 : 0};   // compile-time indices only
   const size_t o = (size_t)e * S + cl;
 
@@ -211,8 +213,8 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
 #pragma unroll
   for (int k = 0; k < 5; k++) s0[k] = src.p[k][o];
   const T   vol     = volumes[e];
-  const int b0      = P.bf_off[e];
-  const int nbf     = live ? P.bf_off[e + 1] - b0 : 0;
+  const int b0      = r0.z;
+  const int nbf     = live ? r0.y : 0;
   const T   edge    = (RANK == 3 ? t8_cbrt(vol) : t8_sqrt(vol)) / T(4);
   const T   surface = RANK == 3 ? edge * edge : edge;
   int       npass   = nbf;  // generic passes run until the busiest block of the wave is done
@@ -225,8 +227,8 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
   // loads (face list -> face record -> far cell) overlap the arithmetic
   const int slot = cl / SF, sub = cl % SF, si = sub & 3, sj = RANK == 3 ? sub >> 2 : 0;
   const FaceLane<T> pre0 = load_face_lane<T, S>(P, src, b0, nbf, slot, si, sj);
-  const PlusFace<T> fx = plus_face<T, RANK>(P, e, 0, live), fy = plus_face<T, RANK>(P, e, 1, live),
-                    fz = RANK == 3 ? plus_face<T, RANK>(P, e, 2, live) : PlusFace<T>{false, false, false, 0, 0, 0, T(0)};
+  const PlusFace<T> fx = plus_face<T>(brec[1], live), fy = plus_face<T>(brec[2], live),
+                    fz = RANK == 3 ? plus_face<T>(brec[3], live) : PlusFace<T>{false, false, false, 0, 0, 0, T(0)};
   // lane cl < PF fetches far cell `cl % SF` of the block's +(cl / SF) face
   const int  pd = cl / SF, psub = cl % SF;
   const bool p_on = cl < PF && (pd == 0 ? fx.on : (pd == 1 ? fy.on : fz.on));
@@ -306,10 +308,8 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
     // every cell collects the sub-face fluxes that end on it, slot by slot (list order)
     for (int s = 0; s < 4; s++) {
       if (p0 + s < nbf) {
-        const int  ent   = P.bf_ent[b0 + p0 + s];
-        const int  fid   = ent & 0x7FFFFFFF;
-        const bool right = ent < 0;
-        const FaceCode fc = decode(reinterpret_cast<const int4*>(P.face_rec)[fid].z);
+        const FaceCode fc    = decode(P.bf_rec[4 * (size_t)(b0 + p0 + s) + 1]);
+        const bool     right = fc.right();
         const int  ca = cell_coord(cl, fc.axis), ci = cell_coord(cl, fc.ta()), cj = RANK == 3 ? cell_coord(cl, fc.tb()) : 0;
         const int  q0 = base + SF * s;
         if (!right) {

@@ -146,4 +146,49 @@ void t8gpu_plan_subgrid_arrays(const void* h, int32_t* bf_off, int32_t* bf_ent, 
   if (face_rec && !P->face_rec.empty()) std::memcpy(face_rec, P->face_rec.data(), P->face_rec.size() * sizeof(int32_t));
 }
 
+
+// What the kernel reads, joined per block so that a wavefront needs ONE dependent level (its record) before it
+// can issue every far-cell load, instead of block_order -> face list -> face record -> far cell:
+//   block_rec[N][16] in block_order position order:
+//     {block, n generic faces, first entry in bf_rec, 0,  then for d = 0..2 the +d face: other, code, area (2 words)}
+//   bf_rec[n_entries][4], the generic faces of the blocks in the same position order: other, code, area (2 words)
+// other = the block on the far side (left block if this block is the face's right side and vice versa), -1 = wall,
+// -2 (+ faces only) = not foldable (finer neighbours: those faces are in the generic list); code = the face code of
+// face_rec | 1 << 12 when this block is the face's RIGHT side; area = face_surfaces[f] as float (word 0) or double.
+void t8gpu_plan_subgrid_records(const void* h, const double* areas, int float_size, int32_t* block_rec, int32_t* bf_rec) {
+  const SubgridPlan* P = static_cast<const SubgridPlan*>(h);
+  auto put = [&](int32_t* dst, int32_t ent) {
+    const int32_t  f     = ent & 0x7FFFFFFF;
+    const bool     right = ent < 0;
+    const int32_t* rec   = &P->face_rec[4 * static_cast<size_t>(f)];
+    dst[0] = right ? rec[0] : rec[1];
+    dst[1] = rec[2] | (right ? 1 << 12 : 0);
+    dst[2] = dst[3] = 0;
+    if (float_size == 4) {
+      const float a = static_cast<float>(areas[f]);
+      std::memcpy(&dst[2], &a, 4);
+    } else {
+      std::memcpy(&dst[2], &areas[f], 8);
+    }
+  };
+  int32_t first = 0;
+  for (int32_t pos = 0; pos < P->N; pos++) {
+    const int32_t e   = P->block_order[pos];
+    int32_t*      rec = block_rec + 16 * static_cast<size_t>(pos);
+    std::memset(rec, 0, 64);
+    rec[0] = e;
+    rec[1] = P->bf_off[e + 1] - P->bf_off[e];
+    rec[2] = first;
+    for (int d = 0; d < 3; d++) {
+      int32_t* pd = rec + 4 + 4 * d;
+      pd[0] = -2;
+      if (d < P->rank) {
+        const int32_t ent = P->plus[static_cast<size_t>(e) * P->rank + d];
+        if (ent != -1) put(pd, ent);
+      }
+    }
+    for (int32_t j = P->bf_off[e]; j < P->bf_off[e + 1]; j++) put(bf_rec + 4 * static_cast<size_t>(first++), P->bf_ent[j]);
+  }
+}
+
 }  // extern "C"

@@ -69,28 +69,20 @@ class PlainPlan:
 
 
 class T8gpuSubgridPlan(C.Structure):
-    _fields_ = [("plus", C.c_void_p), ("bf_off", C.c_void_p), ("bf_ent", C.c_void_p), ("face_rec", C.c_void_p),
-                ("face_surfaces", C.c_void_p), ("block_order", C.c_void_p),
+    _fields_ = [("block_rec", C.c_void_p), ("bf_rec", C.c_void_p),
                 ("num_elements", C.c_int32), ("rank", C.c_int32), ("max_faces_per_block", C.c_int32),
                 ("n_interior_blocks", C.c_int32)]
 
 
 class SubgridPlan:
-    """Device copy of the per-block face lists for the fused Subgrid<4,4> / Subgrid<4,4,4> kernels."""
+    """Device copy of the joined per-block face records for the fused Subgrid<4,4> / Subgrid<4,4,4> kernels."""
 
     def __init__(self, part, dtype):
         from .plan import HostSubgridPlan
         self.host = HostSubgridPlan(part)
         self.dtype = dtype
-        npf = np.float32 if dtype == torch.float32 else np.float64
-        self._keep = {
-            "plus": torch.from_numpy(self.host.plus if self.host.plus.size else np.full((1, part.mesh.dim), -1, np.int32)).cuda(),
-            "bf_off": torch.from_numpy(self.host.bf_off).cuda(),
-            "bf_ent": torch.from_numpy(self.host.bf_ent if self.host.bf_ent.size else np.zeros(1, np.int32)).cuda(),
-            "face_rec": torch.from_numpy(self.host.face_rec if self.host.face_rec.size else np.zeros((1, 4), np.int32)).cuda(),
-            "face_surfaces": torch.from_numpy(np.ascontiguousarray(part.areas if part.areas.size else np.zeros(1), npf)).cuda(),
-            "block_order": torch.from_numpy(self.host.block_order if self.host.block_order.size else np.zeros(1, np.int32)).cuda(),
-        }
+        block_rec, bf_rec = self.host.records(part.areas, 4 if dtype == torch.float32 else 8)
+        self._keep = {"block_rec": torch.from_numpy(block_rec).cuda(), "bf_rec": torch.from_numpy(bf_rec).cuda()}
         c = T8gpuSubgridPlan()
         for k, t in self._keep.items():
             setattr(c, k, t.data_ptr())

@@ -87,17 +87,31 @@ class HostSubgridPlan:
         h = lib.t8gpu_plan_subgrid_create(part.N, part.F, part.B, rank, p(fn), p(part.level_diff), p(part.nb_offset), p(nr))
         if not h:
             raise ValueError("subgrid plan needs axis-aligned unit normals (as the reference's subgrid kernels do)")
-        try:
-            sz = np.zeros(4, np.int64)
-            lib.t8gpu_plan_subgrid_sizes(h, p(sz))
-            self.N, self.rank, self.max_bf, self.n_interior = part.N, rank, int(sz[1]), int(sz[3])
-            lib.t8gpu_plan_subgrid_order.argtypes = [C.c_void_p, C.c_void_p]
-            self.block_order = np.zeros(part.N, np.int32)
-            lib.t8gpu_plan_subgrid_order(h, p(self.block_order))
-            self.bf_off = np.zeros(part.N + 1, np.int32)
-            self.bf_ent = np.zeros(int(sz[0]), np.int32)
-            self.face_rec = np.zeros((int(sz[2]), 4), np.int32)
-            self.plus = np.zeros((part.N, rank), np.int32)
-            lib.t8gpu_plan_subgrid_arrays(h, p(self.bf_off), p(self.bf_ent), p(self.face_rec), p(self.plus))
-        finally:
-            lib.t8gpu_plan_subgrid_destroy(h)
+        self._h = h
+        sz = np.zeros(4, np.int64)
+        lib.t8gpu_plan_subgrid_sizes(h, p(sz))
+        self.N, self.rank, self.max_bf, self.n_interior = part.N, rank, int(sz[1]), int(sz[3])
+        self.n_entries = int(sz[0])
+        lib.t8gpu_plan_subgrid_order.argtypes = [C.c_void_p, C.c_void_p]
+        self.block_order = np.zeros(part.N, np.int32)
+        lib.t8gpu_plan_subgrid_order(h, p(self.block_order))
+        self.bf_off = np.zeros(part.N + 1, np.int32)
+        self.bf_ent = np.zeros(int(sz[0]), np.int32)
+        self.face_rec = np.zeros((int(sz[2]), 4), np.int32)
+        self.plus = np.zeros((part.N, rank), np.int32)
+        lib.t8gpu_plan_subgrid_arrays(h, p(self.bf_off), p(self.bf_ent), p(self.face_rec), p(self.plus))
+
+    def records(self, areas, float_size):
+        """The joined records the kernels read: block_rec [N, 16], bf_rec [n_entries, 4] (int32 words)."""
+        lib = _synth.lib()
+        lib.t8gpu_plan_subgrid_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        ar = np.ascontiguousarray(areas, np.float64)
+        block_rec = np.zeros((max(1, self.N), 16), np.int32)
+        bf_rec = np.zeros((max(1, self.n_entries), 4), np.int32)
+        lib.t8gpu_plan_subgrid_records(self._h, _synth._p(ar), int(float_size), _synth._p(block_rec), _synth._p(bf_rec))
+        return block_rec, bf_rec
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _synth.lib().t8gpu_plan_subgrid_destroy(self._h)
+            self._h = None
