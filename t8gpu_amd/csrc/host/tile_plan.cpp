@@ -13,9 +13,13 @@
 //
 // Host-only: covered by the CPU test-suite through a numpy interpreter of the plan.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <unordered_set>
 #include <vector>
 
 namespace {
@@ -41,6 +45,14 @@ struct TilePlan {
 
 void build(TilePlan& P, const int32_t* fn, const double* normals, const double* areas) {
   const int32_t N = P.N, F = P.F, B = P.B;
+  const bool verbose = std::getenv("T8GPU_PLAN_VERBOSE") != nullptr;
+  auto       tprev   = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!verbose) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[tile_plan] %-28s %.2f s\n", what, std::chrono::duration<double>(now - tprev).count());
+    tprev = now;
+  };
   // faces of each owned element, in original face order (interior faces first, then walls)
   std::vector<int32_t> deg(static_cast<size_t>(N) + 1, 0);
   for (int32_t f = 0; f < F; f++) {
@@ -65,6 +77,7 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
     return fn[2 * static_cast<size_t>(f) + which];
   };
 
+  lap("element -> faces");
   // greedy tiling: grow the element range while elements <= tmax, distinct faces <= fcap and own + halo
   // elements <= lecap (the kernel's LDS window). The halo count is tracked incrementally: an element that
   // joins the tile stops being halo, its neighbours outside the range become halo.
@@ -97,6 +110,7 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
       tile++;
     }
   }
+  lap("greedy tiling");
   // a tile must fit the kernel's LDS window: own + halo elements <= lecap; halve offenders
   {
     std::vector<int32_t> stamp(static_cast<size_t>(N) + P.G, -1);
@@ -129,24 +143,21 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
     }
     P.elem_off.swap(off);
   }
+  lap("LDS window check");
   const int32_t ntiles = static_cast<int32_t>(P.elem_off.size()) - 1;
-  P.halo_off.assign(1, 0);
-  P.face_off.assign(1, 0);
+  // Per-tile lists. Tiles are independent: pass 1 sizes them (faces = sorted distinct faces of the tile's
+  // elements, halo = sorted distinct outside elements those faces touch), a prefix sum places them, pass 2
+  // fills the arrays in place. Both passes run over the tiles in parallel.
+  P.halo_off.assign(static_cast<size_t>(ntiles) + 1, 0);
+  P.face_off.assign(static_cast<size_t>(ntiles) + 1, 0);
   P.csr_off.assign(static_cast<size_t>(N) + 1, 0);
-  std::fill(seen.begin(), seen.end(), -1);
-  std::vector<int32_t> tf, halo;
   std::vector<uint8_t> reads_ghost(ntiles, 0);
-  for (int32_t t = 0; t < ntiles; t++) {
-    const int32_t e0 = P.elem_off[t], e1 = P.elem_off[t + 1], ne = e1 - e0;
-    tf.clear();
-    halo.clear();
-    for (int32_t e = e0; e < e1; e++)
-      for (int32_t j = deg[e]; j < deg[e + 1]; j++)
-        if (seen[ef[j]] != t) {
-          seen[ef[j]] = t;
-          tf.push_back(ef[j]);
-        }
+  auto tile_lists = [&](int32_t t, std::vector<int32_t>& tf, std::vector<int32_t>& halo) {
+    const int32_t e0 = P.elem_off[t], e1 = P.elem_off[t + 1];
+    tf.assign(ef.begin() + deg[e0], ef.begin() + deg[e1]);
     std::sort(tf.begin(), tf.end());
+    tf.erase(std::unique(tf.begin(), tf.end()), tf.end());
+    halo.clear();
     for (int32_t f : tf)
       for (int w = 0; w < 2; w++) {
         const int32_t s = side(f, w);
@@ -154,41 +165,68 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
       }
     std::sort(halo.begin(), halo.end());
     halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
-    if (!halo.empty() && halo.back() >= N) reads_ghost[t] = 1;
-    auto loc = [&](int32_t s) -> uint32_t {
-      if (s >= e0 && s < e1) return static_cast<uint32_t>(s - e0);
-      return static_cast<uint32_t>(ne + (std::lower_bound(halo.begin(), halo.end(), s) - halo.begin()));
-    };
-    const size_t fbase = P.face_lr.size();
-    for (int32_t f : tf) {
-      const int32_t l = side(f, 0), r = side(f, 1);
-      const uint32_t ll = loc(l), rr = r < 0 ? 0xFFFFu : loc(r);
-      P.face_lr.push_back(ll | (rr << 16));
-      for (int k = 0; k < 3; k++) P.face_geo.push_back(k < P.ndim ? normals[static_cast<size_t>(P.ndim) * f + k] : 0.0);
-      P.face_geo.push_back(areas[f]);
-      // the tile owning the left element reports the speed estimate (left is always owned or, for a
-      // face whose left side is a ghost, the tile of the right element does)
-      const int32_t reporter = (l < N) ? l : r;
-      P.face_orig.push_back((reporter >= e0 && reporter < e1) ? f : -1);
+  };
+#pragma omp parallel
+  {
+    std::vector<int32_t> tf, halo;
+#pragma omp for schedule(static)
+    for (int32_t t = 0; t < ntiles; t++) {
+      tile_lists(t, tf, halo);
+      P.face_off[t + 1] = static_cast<int32_t>(tf.size());
+      P.halo_off[t + 1] = static_cast<int32_t>(halo.size());
+      reads_ghost[t]    = !halo.empty() && halo.back() >= N;
     }
-    for (int32_t e = e0; e < e1; e++) {
-      for (int32_t j = deg[e]; j < deg[e + 1]; j++) {
-        const int32_t  f   = ef[j];
-        const uint16_t idx = static_cast<uint16_t>(std::lower_bound(tf.begin(), tf.end(), f) - tf.begin());
-        const bool     right = side(f, 0) != e;
-        P.csr_ent.push_back(static_cast<uint16_t>(idx | (right ? 0x8000u : 0u)));
-      }
-      P.csr_off[e + 1] = static_cast<int32_t>(P.csr_ent.size());
-    }
-    (void)fbase;
-    P.halo_ids.insert(P.halo_ids.end(), halo.begin(), halo.end());
-    P.halo_off.push_back(static_cast<int32_t>(P.halo_ids.size()));
-    P.face_off.push_back(static_cast<int32_t>(P.face_lr.size()));
-    P.max_halo  = std::max<int32_t>(P.max_halo, static_cast<int32_t>(halo.size()));
-    P.max_faces = std::max<int32_t>(P.max_faces, static_cast<int32_t>(tf.size()));
-    P.max_elems = std::max<int32_t>(P.max_elems, ne);
-    P.max_slots = std::max<int32_t>(P.max_slots, ne + static_cast<int32_t>(halo.size()));
   }
+  for (int32_t t = 0; t < ntiles; t++) {
+    const int32_t ne = P.elem_off[t + 1] - P.elem_off[t], nh = P.halo_off[t + 1], nf = P.face_off[t + 1];
+    P.max_halo  = std::max(P.max_halo, nh);
+    P.max_faces = std::max(P.max_faces, nf);
+    P.max_elems = std::max(P.max_elems, ne);
+    P.max_slots = std::max(P.max_slots, ne + nh);
+    P.halo_off[t + 1] += P.halo_off[t];
+    P.face_off[t + 1] += P.face_off[t];
+  }
+  for (int32_t e = 0; e < N; e++) P.csr_off[e + 1] = deg[e + 1];   // one entry per (element, face) incidence
+  P.halo_ids.resize(P.halo_off[ntiles]);
+  P.face_lr.resize(P.face_off[ntiles]);
+  P.face_geo.resize(4 * static_cast<size_t>(P.face_off[ntiles]));
+  P.face_orig.resize(P.face_off[ntiles]);
+  P.csr_ent.resize(deg[N]);
+#pragma omp parallel
+  {
+    std::vector<int32_t> tf, halo;
+#pragma omp for schedule(static)
+    for (int32_t t = 0; t < ntiles; t++) {
+      const int32_t e0 = P.elem_off[t], e1 = P.elem_off[t + 1], ne = e1 - e0;
+      tile_lists(t, tf, halo);
+      auto loc = [&](int32_t s) -> uint32_t {
+        if (s >= e0 && s < e1) return static_cast<uint32_t>(s - e0);
+        return static_cast<uint32_t>(ne + (std::lower_bound(halo.begin(), halo.end(), s) - halo.begin()));
+      };
+      size_t q = P.face_off[t];
+      for (int32_t f : tf) {
+        const int32_t l = side(f, 0), r = side(f, 1);
+        const uint32_t ll = loc(l), rr = r < 0 ? 0xFFFFu : loc(r);
+        P.face_lr[q] = ll | (rr << 16);
+        for (int k = 0; k < 3; k++) P.face_geo[4 * q + k] = k < P.ndim ? normals[static_cast<size_t>(P.ndim) * f + k] : 0.0;
+        P.face_geo[4 * q + 3] = areas[f];
+        // the tile owning the left element reports the speed estimate (left is always owned or, for a
+        // face whose left side is a ghost, the tile of the right element does)
+        const int32_t reporter = (l < N) ? l : r;
+        P.face_orig[q] = (reporter >= e0 && reporter < e1) ? f : -1;
+        q++;
+      }
+      for (int32_t e = e0; e < e1; e++)
+        for (int32_t j = deg[e]; j < deg[e + 1]; j++) {
+          const int32_t  f   = ef[j];
+          const uint16_t idx = static_cast<uint16_t>(std::lower_bound(tf.begin(), tf.end(), f) - tf.begin());
+          const bool     right = side(f, 0) != e;
+          P.csr_ent[j] = static_cast<uint16_t>(idx | (right ? 0x8000u : 0u));
+        }
+      std::copy(halo.begin(), halo.end(), P.halo_ids.begin() + P.halo_off[t]);
+    }
+  }
+  lap("per-tile lists");
   // Three classes for the multi-rank step driver: A = tiles that read ghost slots; B = other tiles that read
   // an element owned by an A tile; C = the rest (deep interior). tile_order = C, B, A. A tile of class C
   // depends only on B/C tiles of the previous stage, one of class A only on A/B tiles and the ghosts.
@@ -213,6 +251,7 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
   for (int32_t t = 0; t < ntiles; t++)
     if (reads_ghost[t]) P.tile_order.push_back(t);
 
+  lap("tile classes");
   // fixed-width (ELL) copy of the element face lists: one aligned 16-byte load per 8 entries
   int32_t maxdeg = 0;
   for (int32_t e = 0; e < N; e++) maxdeg = std::max(maxdeg, P.csr_off[e + 1] - P.csr_off[e]);
@@ -222,6 +261,7 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
     for (int32_t c = P.csr_off[e]; c < P.csr_off[e + 1]; c++)
       P.ell[static_cast<size_t>(e) * P.ell_width + (c - P.csr_off[e])] = P.csr_ent[c];
 
+  lap("ELL rows");
   // dictionary of distinct {nx, ny, nz, area} tuples (exact bit patterns): Cartesian AMR meshes have a
   // few dozen, so a face needs a 2-byte index instead of 4 float_type values
   {
@@ -231,11 +271,27 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
       bool     operator==(const Key& o) const { return std::equal(w, w + 4, o.w); }
     };
     const size_t     nfaces = P.face_lr.size();
-    std::vector<Key> keys(nfaces);
-    for (size_t f = 0; f < nfaces; f++) std::memcpy(keys[f].w, &P.face_geo[4 * f], 32);
-    std::vector<Key> uniq(keys);
+    // distinct rows through a hash set (a sort of all n_faces 32-byte keys was a third of the planning time);
+    // the few survivors are sorted so that the table does not depend on the order of discovery
+    struct KeyHash {
+      size_t operator()(const Key& k) const {
+        uint64_t h = 0x9E3779B97F4A7C15ull;
+        for (int i = 0; i < 4; i++) h = (h ^ k.w[i]) * 0xff51afd7ed558ccdull + (h >> 29);
+        return static_cast<size_t>(h);
+      }
+    };
+    std::unordered_set<Key, KeyHash> set;
+    bool                             too_many = false;
+    for (size_t f = 0; f < nfaces && !too_many; f++) {
+      Key k;
+      std::memcpy(k.w, &P.face_geo[4 * f], 32);
+      set.insert(k);
+      too_many = set.size() > 65535;
+    }
+    std::vector<Key> uniq;
+    if (!too_many) uniq.assign(set.begin(), set.end());
     std::sort(uniq.begin(), uniq.end());
-    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    if (too_many) uniq.resize(65536);   // (only its size is looked at below)
     if (uniq.size() <= 65535) {
       // table row = {nx, ny, nz, area, t1x, t1y, t1z, 0, t2x, t2y, t2z, 0}: the face frame (the reference
       // rebuilds it per face and stage, kernels.cu:174-193) is computed once per distinct normal
@@ -254,10 +310,15 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
         row[10] = n[0] * row[5] - n[1] * row[4];
       }
       P.geo_idx.resize(nfaces);
-      for (size_t f = 0; f < nfaces; f++)
-        P.geo_idx[f] = static_cast<uint16_t>(std::lower_bound(uniq.begin(), uniq.end(), keys[f]) - uniq.begin());
+#pragma omp parallel for schedule(static)
+      for (int64_t f = 0; f < static_cast<int64_t>(nfaces); f++) {
+        Key k;
+        std::memcpy(k.w, &P.face_geo[4 * static_cast<size_t>(f)], 32);
+        P.geo_idx[f] = static_cast<uint16_t>(std::lower_bound(uniq.begin(), uniq.end(), k) - uniq.begin());
+      }
     }
   }
+  lap("geometry dictionary");
 }
 
 }  // namespace
