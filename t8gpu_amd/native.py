@@ -17,16 +17,41 @@ class NativeComm:
     """One RCCL communicator per process. `broadcast_bytes(b, src)` distributes rank 0's unique id
     (torch.distributed, MPI, ...)."""
 
-    def __init__(self, rank, nranks, broadcast_bytes):
+    def __init__(self, rank, nranks, broadcast_bytes, timeout_s=180.0):
+        """Collective. Never leaves a peer waiting: rank 0 broadcasts even when it could not make an id (an
+        empty one, on which every rank raises), and ncclCommInitRank runs in a helper thread so that a rank
+        whose peers never arrive raises after `timeout_s` instead of blocking forever."""
+        import threading
         lib = hip.lib()
-        idbuf = C.create_string_buffer(128)
-        if rank == 0:
-            hip.check(lib.t8gpu_hip_comm_unique_id(idbuf))
-        uid = broadcast_bytes(bytes(idbuf.raw), 0)
-        assert len(uid) == 128
         self.handle = C.c_void_p()
-        hip.check(lib.t8gpu_hip_comm_create(C.create_string_buffer(uid, 128), rank, nranks, C.byref(self.handle)))
         self.rank, self.nranks = rank, nranks
+        idbuf = C.create_string_buffer(128)
+        uid, err = b"", None
+        if rank == 0:
+            try:
+                hip.check(lib.t8gpu_hip_comm_unique_id(idbuf))
+                uid = bytes(idbuf.raw)
+            except Exception as exc:  # noqa: BLE001  (reported after the broadcast, which must happen)
+                err = exc
+        uid = broadcast_bytes(uid, 0)
+        if err is not None:
+            raise err
+        if not isinstance(uid, (bytes, bytearray)) or len(uid) != 128:
+            raise hip.T8gpuHipError("rank 0 could not create an RCCL unique id")
+        result = {}
+
+        def init():
+            h = C.c_void_p()
+            result["rc"] = lib.t8gpu_hip_comm_create(C.create_string_buffer(bytes(uid), 128), rank, nranks, C.byref(h))
+            result["handle"] = h
+
+        th = threading.Thread(target=init, daemon=True)
+        th.start()
+        th.join(timeout_s)
+        if th.is_alive():
+            raise hip.T8gpuHipError(f"ncclCommInitRank did not return within {timeout_s:.0f} s")
+        hip.check(result["rc"])
+        self.handle = result["handle"]
 
     def abort(self):
         if self.handle:
