@@ -152,7 +152,7 @@ def main():
         if stepper is not None:
             # the native driver takes all steps of a region in ONE call: the exchange stream and the compute stream
             # then meet at the entry and the exit of the region only (csrc/hip/stepper.hip)
-            stepper.timing(timed)
+            stepper.timing((1 if world == 1 else 8) if timed else 0)   # multi-rank: sample every 8th step (host cost)
             solver.iterate_steps(nsteps, delta_t)
             return
         for _ in range(nsteps):
@@ -204,7 +204,9 @@ def main():
     per_update, flux_stage, rk = algorithmic_bytes(w["kind"], ft, phi if w["kind"] == "plain" else 0, 3, phi)
     # dominant kernel: the fused stage kernel (flux + RK of one stage) or the face-flux kernel
     if kernel_launches:
-        avg_ms = kernel_ms / (3 * args.steps)   # one fused stage may be split into interior + ghost-reading tiles
+        stride = 8 if (stepper is not None and world > 1) else 1          # steps whose stage kernels carry events
+        steps_timed = -(-args.steps // stride)
+        avg_ms = kernel_ms / (3 * steps_timed)   # one fused stage may be split into several tile ranges
         local_cells = part.N * cells
         if mode == "fused":
             per_launch = local_cells * (flux_stage + sum(rk) / 3.0)
@@ -218,8 +220,13 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": int(per_launch), "launches_timed": kernel_launches}
-        if kernel_launches != 3 * args.steps:
-            roof["note"] = "stage kernel split into interior + ghost-reading tile ranges; avg_launch_ms is their sum per stage"
+        if achieved > HBM_PEAK_GBS * 0.98 and traffic:
+            roof["note"] = ("algorithmic bytes are those of the reference's data flow (SURVEY 8d: state gathers + flux planes + RK "
+                            "pass); the fused kernel never writes the flux planes, so it can exceed 'peak' on this measure -- the "
+                            f"HBM bytes it really moves are in 'traffic' ({traffic / (avg_ms * 1e-3) / 1e9:.0f} GB/s)")
+        if kernel_launches != 3 * steps_timed:
+            roof["note"] = ("stage kernel split into deep-interior / near-boundary / ghost-reading tile ranges; avg_launch_ms is "
+                            "their sum per stage" + (f"; events on every {stride}th step" if stride > 1 else ""))
     else:
         roof = None
 

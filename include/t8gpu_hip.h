@@ -218,7 +218,9 @@ int t8gpu_hip_plain_stepper_iterate_steps_f32(void* stepper, int flux_kind, floa
                                               float delta_t, float* speed_estimates, int n_steps, void* stream);
 int t8gpu_hip_plain_stepper_iterate_steps_f64(void* stepper, int flux_kind, double* planes, size_t stride, int prev, int next,
                                               double delta_t, double* speed_estimates, int n_steps, void* stream);
-/* optional HIP-event timing of the stage kernels (for roofline accounting) */
+/* optional HIP-event timing of the stage kernels (for roofline accounting): enable = 0 off, n > 0 = the stage
+ * kernels of every n-th step of a call are bracketed by events (n > 1 keeps the host-side cost of the
+ * events out of latency-bound multi-rank runs); elapsed() sums what has been recorded since. */
 int t8gpu_hip_plain_stepper_timing(void* stepper, int enable);
 int t8gpu_hip_plain_stepper_elapsed(void* stepper, double* total_ms, int* launches);
 

@@ -40,7 +40,8 @@ struct Stepper {
   hipEvent_t     ev_state = nullptr, ev_ghost = nullptr;   // step entry / last boundary launch
   hipEvent_t     ev_interior = nullptr;                  // last class B launch
   hipEvent_t     ev_deep = nullptr;                      // last class C launch
-  bool           timing = false;
+  int            timing = 0;        // 0 = off, n = time the stage kernels of every n-th step
+  bool           sample = false;    // the step being enqueued is one of those
   std::vector<hipEvent_t> pool;   // start/stop pairs of the stage-kernel launches
   size_t         used = 0;
 };
@@ -90,7 +91,7 @@ V step_vars(T* planes, size_t stride, int step) {
 }
 
 int tick(Stepper* S, hipStream_t s) {
-  if (!S->timing) return 0;
+  if (!S->timing || !S->sample) return 0;
   if (S->used == S->pool.size()) {
     hipEvent_t e;
     T8_HIP_TRY(hipEventCreate(&e));
@@ -121,6 +122,7 @@ int iterate(Stepper* S, int kind, T* planes, size_t stride, int prev, int next, 
   const bool comm = S->has_halo && S->halo.n_peers > 0;
   for (int g = 0; g < 3 * n_steps; g++) {
     const int k  = g % 3;
+    S->sample    = S->timing > 0 && (g / 3) % S->timing == 0;
     const int pr = (g / 3) % 2 == 0 ? prev : next, nx = (g / 3) % 2 == 0 ? next : prev;
     const int src = k == 0 ? pr : k, dst = k == 2 ? nx : k + 1;   // Step1 = 1, Step2 = 2 (solver.h:24-31)
     const V   pv = step_vars<V>(planes, stride, pr), sv = step_vars<V>(planes, stride, src), ov = step_vars<V>(planes, stride, dst);
@@ -279,7 +281,7 @@ int t8gpu_hip_plain_stepper_iterate_steps_f64(void* h, int flux_kind, double* pl
 int t8gpu_hip_plain_stepper_timing(void* h, int enable) {
   Stepper* S = static_cast<Stepper*>(h);
   if (!S) return static_cast<int>(hipErrorInvalidValue);
-  S->timing = enable != 0;
+  S->timing = enable < 0 ? 0 : enable;
   S->used   = 0;
   return 0;
 }
