@@ -204,9 +204,10 @@ def main():
     per_update, flux_stage, rk = algorithmic_bytes(w["kind"], ft, phi if w["kind"] == "plain" else 0, 3, phi)
     # dominant kernel: the fused stage kernel (flux + RK of one stage) or the face-flux kernel
     if kernel_launches:
-        stride = 8 if (stepper is not None and world > 1) else 1          # steps whose stage kernels carry events
-        steps_timed = -(-args.steps // stride)
-        avg_ms = kernel_ms / (3 * steps_timed)   # one fused stage may be split into several tile ranges
+        stride = 8 if (stepper is not None and world > 1) else 1          # (groups of) steps whose stage kernels carry events
+        stages_timed = stepper.timed_stages() if stepper is not None else 3 * args.steps
+        steps_timed = stages_timed / 3.0
+        avg_ms = kernel_ms / max(1, stages_timed)   # one fused stage may be split into several tile ranges
         local_cells = part.N * cells
         if mode == "fused":
             per_launch = local_cells * (flux_stage + sum(rk) / 3.0)
@@ -226,7 +227,7 @@ def main():
                             f"HBM bytes it really moves are in 'traffic' ({traffic / (avg_ms * 1e-3) / 1e9:.0f} GB/s)")
         if kernel_launches != 3 * steps_timed:
             roof["note"] = ("stage kernel split into deep-interior / near-boundary / ghost-reading tile ranges; avg_launch_ms is "
-                            "their sum per stage" + (f"; events on every {stride}th step" if stride > 1 else ""))
+                            "their sum per stage" + (f"; events on {stages_timed} of {3 * args.steps} stages" if stride > 1 else ""))
     else:
         roof = None
 

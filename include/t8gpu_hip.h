@@ -223,6 +223,7 @@ int t8gpu_hip_plain_stepper_iterate_steps_f64(void* stepper, int flux_kind, doub
  * events out of latency-bound multi-rank runs); elapsed() sums what has been recorded since. */
 int t8gpu_hip_plain_stepper_timing(void* stepper, int enable);
 int t8gpu_hip_plain_stepper_elapsed(void* stepper, double* total_ms, int* launches);
+int t8gpu_hip_plain_stepper_timed_stages(void* stepper); /* RK stages covered by elapsed() */
 
 /* ---- Subgrid<4,4,4> and Subgrid<4,4>, fused block kernels ("fast" tier) -----------------------------
  * One launch per RK stage replaces compute_inner_fluxes + compute_boundary_fluxes + compute_outer_fluxes

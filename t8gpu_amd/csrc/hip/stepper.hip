@@ -44,6 +44,7 @@ struct Stepper {
   bool           sample = false;    // the step being enqueued is one of those
   std::vector<hipEvent_t> pool;   // start/stop pairs of the stage-kernel launches
   size_t         used = 0;
+  int            stages_timed = 0;
 };
 
 template <class T>
@@ -123,6 +124,7 @@ int iterate(Stepper* S, int kind, T* planes, size_t stride, int prev, int next, 
   for (int g = 0; g < 3 * n_steps; g++) {
     const int k  = g % 3;
     S->sample    = S->timing > 0 && (g / 3) % S->timing == 0;
+    if (S->sample) S->stages_timed++;
     const int pr = (g / 3) % 2 == 0 ? prev : next, nx = (g / 3) % 2 == 0 ? next : prev;
     const int src = k == 0 ? pr : k, dst = k == 2 ? nx : k + 1;   // Step1 = 1, Step2 = 2 (solver.h:24-31)
     const V   pv = step_vars<V>(planes, stride, pr), sv = step_vars<V>(planes, stride, src), ov = step_vars<V>(planes, stride, dst);
@@ -282,6 +284,7 @@ int t8gpu_hip_plain_stepper_timing(void* h, int enable) {
   Stepper* S = static_cast<Stepper*>(h);
   if (!S) return static_cast<int>(hipErrorInvalidValue);
   S->timing = enable < 0 ? 0 : enable;
+  S->stages_timed = 0;
   S->used   = 0;
   return 0;
 }
@@ -299,6 +302,14 @@ int t8gpu_hip_plain_stepper_elapsed(void* h, double* total_ms, int* launches) {
   *total_ms = sum;
   *launches = static_cast<int>(S->used / 2);
   return 0;
+}
+
+
+// Number of RK stages whose kernels were bracketed by events since timing was enabled (elapsed() / this = the
+// average duration of one stage's kernels, however many tile ranges a stage is split into).
+int t8gpu_hip_plain_stepper_timed_stages(void* h) {
+  Stepper* S = static_cast<Stepper*>(h);
+  return S ? S->stages_timed : 0;
 }
 
 }  // extern "C"

@@ -120,6 +120,9 @@ class NativeStepper:
     def timing(self, enable):
         hip.check(hip.lib().t8gpu_hip_plain_stepper_timing(self.handle, int(enable)))
 
+    def timed_stages(self):
+        return int(hip.lib().t8gpu_hip_plain_stepper_timed_stages(self.handle))
+
     def elapsed(self):
         ms, n = C.c_double(), C.c_int()
         hip.check(hip.lib().t8gpu_hip_plain_stepper_elapsed(self.handle, C.byref(ms), C.byref(n)))

@@ -166,11 +166,12 @@ def test_native_stepper_with_rccl_self_exchange_on_a_symmetric_problem(dtype):
     g.use_native_stepper(native.NativeHalo(fake, dtype, comm))
     dt = 0.1 * 2.0 ** -mesh.finest_level
     assert 0 < g.plan.host.n_deep < g.plan.host.n_interior              # all three tile classes are populated
-    for _ in range(6):
+    for _ in range(6 + 13):
         ref.iterate(dt)
     g.iterate(dt)                                                         # one step per call ...
     g.iterate_steps(3, dt)                                                # ... several in one call (odd count) ...
     g.iterate_steps(2, dt)                                                # ... and an even count
+    g.iterate_steps(13, dt)                                               # a longer run in one call
     assert native.stream_wait(torch.cuda.current_stream(), 30.0) == 0
     want, got = ref.state().cpu().numpy(), g.state().cpu().numpy()
     assert np.isfinite(got).all()
