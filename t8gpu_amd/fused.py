@@ -30,9 +30,15 @@ class PlainPlan:
         self.dtype = dtype
         self._keep = {}
         c = T8gpuPlainPlan()
+        h = self.host
+        # the pipelined kernel with a geometry dictionary never reads the per-face rows (32 B per face: 700 MB at c4)
+        skip_geo = (compressed and dictionary and h.geo_table.shape[0] > 0 and h.max_elems <= 256 and h.max_slots <= 512
+                    and h.max_faces <= 1024)
         for name in HostPlainPlan.FIELDS:
             a = getattr(self.host, name)
             if name == "face_geo":
+                if skip_geo:
+                    continue
                 a = a.astype(np.float32 if dtype == torch.float32 else np.float64)
             if a.dtype == np.uint32:
                 a = a.view(np.int32)
