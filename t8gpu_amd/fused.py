@@ -24,7 +24,9 @@ class PlainPlan:
         tmax = int(os.environ.get("T8GPU_TMAX", 256)) if tmax is None else tmax     # tuning knobs of the tiling
         # 512 faces = two passes of 256. Larger tiles (the kernel takes up to 1024 faces in four passes) were
         # measured on 3D meshes, where 512 cuts tiles at ~130-150 elements: 768 / 1024 are 1-8 % SLOWER (LDS per
-        # workgroup grows, 3 instead of 4 workgroups per CU), so 512 stays the default for every mesh.
+        # workgroup grows, 3 instead of 4 workgroups per CU), and so is a 512-lane workgroup with one lane per
+        # own + halo element and two passes of 512 faces (-5 ... -7 %: fewer instructions, but 8 waves per barrier
+        # and 2 workgroups per CU), so 512 stays the default for every mesh.
         fcap = int(os.environ.get("T8GPU_FCAP", 512)) if fcap is None else fcap
         self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap)
         self.dtype = dtype
