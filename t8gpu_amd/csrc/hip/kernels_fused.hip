@@ -12,6 +12,8 @@
 // so each XCD gets one contiguous run of tiles and neighbouring tiles' halos hit the same L2.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "flux_math.hpp"
 #include "t8gpu_hip.h"
 
@@ -201,7 +203,11 @@ T8_DEV void load_prim(const T* pe, int LE, int i, Prim<T>& q) {
 // MAXP = 2: at most 512 faces per tile, both passes' face records loaded in the prologue (2D meshes).
 // MAXP = 4: up to 1024 faces per tile (3D meshes: a 256-element tile has ~3 faces per element plus its
 // surface); the record of pass p + 1 is fetched at the top of pass p, so two are live at any time.
-template <class T, int KIND, int STAGE, bool DICT, int MAXP>
+// SCATTER = true is the accumulation the project brief sketches: every face lane adds -F / +F to per-element
+// accumulators in LDS with ds_add_f32 / ds_add_f64 (no ELL rows, no gather, one barrier after the last pass).
+// Kept as a measured alternative (T8GPU_LDS_SCATTER=1): the order of the additions is not fixed, so the
+// result is no longer bitwise reproducible, and the default gather is faster.
+template <class T, int KIND, int STAGE, bool DICT, int MAXP, bool SCATTER = false>
 __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int tile_begin, FVars<T> prev, FVars<T> src,
                                                        FVars<T> out, const T* __restrict__ vol, T dt,
                                                        T* __restrict__ speed) {
@@ -260,6 +266,10 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
   const uint4 ell0 = ellrow[0];
 
   // ---- phase 1 -----------------------------------------------------------------------------------
+  if (SCATTER) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) ff[k * 256 + tid] = T(0);
+  }
   if (a0) {
     if (KIND == 0) {
       store_prim<T>(pe, LE, tid, s0);
@@ -316,8 +326,19 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
         }
         hll_face<T>(sl, sr, wall, n, t1, t2, gm.w, g);
       }
+      if (SCATTER) {
+        if (l < ne) {
 #pragma unroll
-      for (int k = 0; k < 5; k++) ff[k * 256 + tid] = g[k];
+          for (int k = 0; k < 5; k++) atomicAdd(&ff[k * 256 + l], -g[k]);
+        }
+        if (!wall && r < ne) {
+#pragma unroll
+          for (int k = 0; k < 5; k++) atomicAdd(&ff[k * 256 + r], g[k]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 5; k++) ff[k * 256 + tid] = g[k];
+      }
     }
     if (MAXP == 2 && last) {  // last pass: start the RK stage's loads; they fly during the barrier + gather
       if (STAGE > 1) {
@@ -326,6 +347,7 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
       }
       volume = vol[e];
     }
+    if (SCATTER) continue;   // the accumulators take every pass; one barrier after the loop
     __syncthreads();
     if (own) {
       bool done = false;
@@ -333,6 +355,13 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
       for (int c = 1; c < P.ell_width / 8 && !done; c++) ell_accumulate<T>(ellrow[c], it, ff, acc, done);
     }
     if (!last) __syncthreads();   // the buffer is rewritten by the next pass
+  }
+  if (SCATTER) {
+    __syncthreads();
+    if (own) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) acc[k] = ff[k * 256 + tid];
+    }
   }
 
   if (MAXP > 2) {  // (the last pass is not known at compile time here: fetched after the loop, other workgroups cover it)
@@ -381,6 +410,7 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
   const bool  pipelined = plan->ell && plan->ell_width >= 8 && plan->ell_width % 8 == 0 && plan->max_elems <= 256 &&
                          slots <= 512 && plan->max_faces <= 1024;
   const bool  four = plan->max_faces > 512;
+  static const bool scatter = std::getenv("T8GPU_LDS_SCATTER") && std::getenv("T8GPU_LDS_SCATTER")[0] == '1';   // measured alternative
   const size_t lds = sizeof(T) * ((size_t)nw * slots + (size_t)5 * (pipelined ? 256 : plan->max_faces));
   if (lds > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
   const bool  dict = pipelined && plan->geo_idx && plan->geo_table && plan->n_geo > 0;
@@ -396,7 +426,11 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
   } while (0)
 #define T8_FUSED(K, S)                                              \
   do {                                                              \
-    if (dict && !four)                                              \
+    if (scatter && dict && !four)                                   \
+      T8_LAUNCH((k_plain_fused_p<T, K, S, true, 2, true>));         \
+    else if (scatter && pipelined && !four)                         \
+      T8_LAUNCH((k_plain_fused_p<T, K, S, false, 2, true>));        \
+    else if (dict && !four)                                         \
       T8_LAUNCH((k_plain_fused_p<T, K, S, true, 2>));               \
     else if (dict)                                                  \
       T8_LAUNCH((k_plain_fused_p<T, K, S, true, 4>));               \

@@ -159,3 +159,36 @@ def test_c4_full_size_properties():
     for _ in range(3):
         b.iterate(dt)
     assert torch.equal(b.state(), first)                             # native driver == python driver, run-to-run identical
+
+
+def test_lds_scatter_add_variant_matches_the_oracle():
+    """T8GPU_LDS_SCATTER=1: the accumulation the project brief sketches (ds_add_f64 into per-element LDS
+    accumulators instead of the ELL gather). Not bitwise reproducible by construction, so it is checked against
+    the oracle within the parity tolerance, in its own process (the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "tests")
+import _oracle as O
+from _gpu import perturbed_state, rel_err
+from t8gpu_amd.solver import PlainSolver
+from t8gpu_amd.synth import SynthMesh
+mesh = SynthMesh(2, 3, 6, band=0.06, periodic=False)
+part = mesh.partition()
+st = perturbed_state(part, 21)
+g = PlainSolver(part, torch.float64, mode="fused", state=st)
+o = O.PlainCase(part, np.float64, state=st)
+dt = 0.1 * 2.0 ** -6
+m0 = g.compute_integral(0)
+for _ in range(10):
+    g.iterate(dt); o.iterate(dt)
+err = rel_err(g.state().cpu().numpy(), o.current()[:, :part.N])
+print("ERR", err, abs(g.compute_integral(0) - m0) / abs(m0))
+assert err < 1e-10
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, T8GPU_LDS_SCATTER="1"), capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode == 0 and "ERR" in res.stdout, res.stdout[-1500:] + res.stderr[-1500:]
