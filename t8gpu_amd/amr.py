@@ -112,17 +112,24 @@ class PartitionedAdapt:
                 hip.call("t8gpu_hip_gather_elements", dtype, n, first, hip.vars_of(self.tmp), hip.ptr(self.tmp[5]),
                          hip.ptr(self.sendbufs[q]), s)
 
-    def transport(self, dist):
+    def transport(self, dist, host_staged=False):
+        """host_staged: move the messages through host memory (gloo, which cannot send device buffers)."""
+        torch.cuda.synchronize()
+        rbuf = {q: (b.cpu() if host_staged else b) for q, b in self.recvbufs.items()}
+        sbuf = {q: (b.cpu() if host_staged else b) for q, b in self.sendbufs.items()}
         ops = []
         for q, _, n in self.recvs:
             if q != self.rank:
-                ops.append(dist.P2POp(dist.irecv, self.recvbufs[q], q))
+                ops.append(dist.P2POp(dist.irecv, rbuf[q], q))
         for q, _, n in self.sends:
             if q != self.rank:
-                ops.append(dist.P2POp(dist.isend, self.sendbufs[q], q))
+                ops.append(dist.P2POp(dist.isend, sbuf[q], q))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+        if host_staged:
+            for q, b in self.recvbufs.items():
+                b.copy_(rbuf[q])
 
     def finish(self):
         new, dtype = self.new_solver, self.solver.dtype
@@ -139,16 +146,25 @@ class PartitionedAdapt:
         return new
 
 
-def adapt_partitioned(solver, dist, **kw):
-    """Collective: every rank calls it with its own solver; returns the rank's new solver."""
-    crit = refinement_criteria(solver).double()
+def _gather_criteria(crit, solver, dist, host_staged):
     world = solver.part.nranks
-    sizes = [int(solver.part.mesh.partition_offsets(world)[r + 1] - solver.part.mesh.partition_offsets(world)[r]) for r in range(world)]
-    chunks = [torch.empty(n, dtype=torch.float64, device=crit.device) for n in sizes]
-    dist.all_gather(chunks, crit)
-    all_crit = torch.cat(chunks).cpu().numpy()
+    off = solver.part.mesh.partition_offsets(world)
+    crit = crit.cpu() if host_staged else crit
+    sizes = [int(off[r + 1] - off[r]) for r in range(world)]
+    width = max(sizes)                       # all_gather wants equal contributions: pad to the largest share
+    mine = torch.zeros(width, dtype=torch.float64, device=crit.device)
+    mine[: crit.numel()] = crit
+    chunks = [torch.empty(width, dtype=torch.float64, device=crit.device) for _ in range(world)]
+    dist.all_gather(chunks, mine)
+    return torch.cat([c[:n] for c, n in zip(chunks, sizes)]).cpu().numpy()
+
+
+def adapt_partitioned(solver, dist, host_staged=False, **kw):
+    """Collective: every rank calls it with its own solver; returns the rank's new solver.
+    host_staged: collectives and messages through host memory (gloo)."""
+    all_crit = _gather_criteria(refinement_criteria(solver).double(), solver, dist, host_staged)
     pa = PartitionedAdapt(solver, all_crit, **kw)
-    pa.transport(dist)
+    pa.transport(dist, host_staged)
     return pa.finish()
 
 
@@ -259,13 +275,9 @@ class PartitionedSubgridAdapt:
         return new
 
 
-def adapt_subgrid_partitioned(solver, dist, **kw):
+def adapt_subgrid_partitioned(solver, dist, host_staged=False, **kw):
     """Collective: every rank calls it with its own SubgridSolver; returns the rank's new solver."""
-    crit = subgrid_refinement_criteria(solver).double()
-    world = solver.part.nranks
-    off = solver.part.mesh.partition_offsets(world)
-    chunks = [torch.empty(int(off[r + 1] - off[r]), dtype=torch.float64, device=crit.device) for r in range(world)]
-    dist.all_gather(chunks, crit)
-    pa = PartitionedSubgridAdapt(solver, torch.cat(chunks).cpu().numpy(), **kw)
-    pa.transport(dist)
+    all_crit = _gather_criteria(subgrid_refinement_criteria(solver).double(), solver, dist, host_staged)
+    pa = PartitionedSubgridAdapt(solver, all_crit, **kw)
+    pa.transport(dist, host_staged)
     return pa.finish()

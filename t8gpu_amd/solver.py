@@ -121,7 +121,7 @@ class PlainSolver:
 
     def compute_timestep(self, cfl=0.7, max_level=None, dist=None):
         """cfl * 0.5^max_level / max speed (solver.cu:213-229); `dist` all-reduces the maximum over ranks."""
-        speed = torch.tensor([self.max_speed()], dtype=torch.float64, device="cuda")
+        speed = torch.tensor([self.max_speed()], dtype=torch.float64, device="cuda" if dist is None or dist.get_backend() == "nccl" else "cpu")
         if dist is not None:
             dist.all_reduce(speed, op=dist.ReduceOp.MAX)
         level = self.part.mesh.finest_level if max_level is None else max_level

@@ -37,3 +37,22 @@ def test_bench_multirank_rehearsal(world, workload):
     assert rec["value"] > 0 and rec["ms_per_step"] > 0
     assert rec["roofline"]["bound"] == "hbm" and 0 < rec["roofline"]["frac"] < 1.2
     assert rec["cpu_baseline"] is None            # timed on rank 0 at N = 1 only
+
+
+@pytest.mark.gpu
+def test_adaptive_example_on_three_ranks_rehearsal(tmp_path):
+    """examples/kelvin_helmholtz_amr.py with 3 ranks sharing the GPU (uneven element counts: the criteria
+    all-gather must cope), adapt + repartition cycles, CFL all-reduce, per-rank .vtu pieces and the .pvtu."""
+    env = dict(os.environ, T8GPU_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    prefix = str(tmp_path / "kh")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+           "--master-port", "29671", os.path.join(ROOT, "examples", "kelvin_helmholtz_amr.py"), "--steps", "45", "--adapt-every", "20",
+           "--min-level", "4", "--max-level", "6", "--vtk", prefix]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "conservation drift" in out.stdout and "wrote" in out.stdout
+    for r in range(3):
+        assert os.path.exists(f"{prefix}_{r:04d}.vtu")
+    assert os.path.exists(prefix + ".pvtu")
+    drift = float(out.stdout.split("conservation drift")[-1].split()[0])
+    assert drift < 1e-9
