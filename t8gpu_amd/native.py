@@ -39,8 +39,11 @@ class NativeComm:
         if not isinstance(uid, (bytes, bytearray)) or len(uid) != 128:
             raise hip.T8gpuHipError("rank 0 could not create an RCCL unique id")
         result = {}
+        import torch
+        device = torch.cuda.current_device()     # the helper thread starts on device 0: hand it this rank's GPU
 
         def init():
+            torch.cuda.set_device(device)
             h = C.c_void_p()
             result["rc"] = lib.t8gpu_hip_comm_create(C.create_string_buffer(bytes(uid), 128), rank, nranks, C.byref(h))
             result["handle"] = h
