@@ -134,14 +134,16 @@ def main():
         native_halo = None
         if world > 1 and os.environ.get("T8GPU_HALO", "native") == "native":
             native_halo = make_native_halo(part, tdtype, solver, halo, dist, rank, world)
-        if world == 1 or native_halo is not None:
+        if world == 1:
             try:
-                stepper = solver.use_native_stepper(native_halo)
-                if native_halo is not None:
-                    halo, halo_kind = None, "native rccl (C++ stepper)"
+                stepper = solver.use_native_stepper(None)
             except Exception as exc:  # noqa: BLE001  (keep the run alive on the python-driven path)
                 print(f"[bench rank {rank}] native stepper unavailable ({exc}); python-driven stages", file=sys.stderr, flush=True)
                 solver.stepper, stepper = None, None
+        elif native_halo is not None:
+            stepper = bring_up_native_stepper(solver, native_halo, delta_t, part, tdtype, dist, rank)
+            if stepper is not None:
+                halo, halo_kind = None, "native rccl (C++ stepper)"
     setup_s = time.time() - t0
 
     # HIP-event timing of the dominant kernel (events recorded on the launch stream)
@@ -310,6 +312,38 @@ def make_native_halo(part, tdtype, solver, torch_halo, dist, rank, world):
     flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     return nh if int(flag.item()) == 1 else None
+
+
+def bring_up_native_stepper(solver, native_halo, delta_t, part, tdtype, dist, rank):
+    """Every rank must end up on the SAME transport. Bring the C++ driver up, push two trial steps through its
+    pipeline under a stall guard, and let an all-reduce decide: any rank that failed or stalled sends everybody
+    back to the torch.distributed path (None is returned, the initial state is restored)."""
+    from t8gpu_amd import native
+    ok, stepper = 1, None
+    try:
+        stepper = solver.use_native_stepper(native_halo)
+        solver.iterate_steps(2, delta_t)
+        if native.stream_wait(torch.cuda.current_stream(), 60.0) != 0:
+            raise RuntimeError("the native step pipeline did not complete two trial steps within 60 s")
+        if not bool(torch.isfinite(solver.state()).all().item()):
+            raise RuntimeError("the native step pipeline produced non-finite values")
+    except Exception as exc:  # noqa: BLE001
+        print(f"[bench rank {rank}] native stepper unavailable ({exc}); python-driven stages", file=sys.stderr, flush=True)
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return stepper
+    try:
+        native_halo.comm.abort()
+    except Exception:  # noqa: BLE001
+        pass
+    solver.stepper = None
+    tot = part.N + part.G
+    solver.planes[:25].zero_()
+    solver.planes[0:5, :tot] = torch.from_numpy(part.kh_initial_state()).to(tdtype).cuda()
+    solver.next, solver.prev = 0, 3   # Step0 / Step3, as after construction (solver.h:100-101)
+    return None
 
 
 def cpu_baseline(part, w, dts, delta_t, kindf, budget_s):

@@ -178,3 +178,41 @@ def test_native_stepper_with_rccl_self_exchange_on_a_symmetric_problem(dtype):
     assert rel_err(got, want[:, : half.N]) < (1e-12 if dtype == torch.float64 else 1e-5)
     g.stepper = None
     comm.destroy()
+
+
+def test_bench_native_bring_up_agreement_logic():
+    """bench.bring_up_native_stepper with a stand-in process group: success keeps the C++ driver, a rank that
+    votes 0 (here: the all-reduce is made to return 0) sends everybody back to the initial state."""
+    import sys
+    import types
+    from t8gpu_amd import native
+    sys.path.insert(0, ".")
+    import bench
+    mesh = SynthMesh(2, 5, 8, band=0.05)
+    half = mesh.partition(0, 2)
+    comm = native.NativeComm(0, 1, lambda b, src: b)
+    fake = types.SimpleNamespace(N=half.N, G=half.G, cells_per_element=1, peers=np.zeros(1, np.int32), send_off=half.send_off,
+                                 recv_off=half.recv_off, send_idx=half.send_idx)
+    dt = 0.1 * 2.0 ** -mesh.finest_level
+
+    class Group:
+        ReduceOp = types.SimpleNamespace(MIN="min")
+
+        def __init__(self, verdict):
+            self.verdict = verdict
+
+        def get_backend(self):
+            return "nccl"
+
+        def all_reduce(self, t, op=None):
+            t.fill_(min(int(t.item()), self.verdict))
+
+    g = PlainSolver(half, torch.float64, mode="fused")
+    st = bench.bring_up_native_stepper(g, native.NativeHalo(fake, torch.float64, comm), dt, half, torch.float64, Group(1), 0)
+    assert st is not None and g.stepper is st and bool(torch.isfinite(g.state()).all())
+    g2 = PlainSolver(half, torch.float64, mode="fused")
+    ic = g2.state().clone()
+    nh = native.NativeHalo(fake, torch.float64, native.NativeComm(0, 1, lambda b, src: b))
+    st = bench.bring_up_native_stepper(g2, nh, dt, half, torch.float64, Group(0), 0)
+    assert st is None and g2.stepper is None and (g2.next, g2.prev) == (0, 3) and torch.equal(g2.state(), ic)
+    comm.destroy()
