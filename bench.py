@@ -272,12 +272,24 @@ def measured_traffic(workload, dts, flux, mode, world):
         return None, None
 
 
+def _all_agree(ok, dist):
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return int(flag.item()) == 1
+
+
 def make_native_halo(part, tdtype, solver, torch_halo, dist, rank, world):
-    """Native RCCL communicator + halo descriptor, cross-checked ONCE against the torch.distributed
-    exchange on the initial state. Any error, mismatch or a 60 s stall on any rank -> None (all ranks
-    agree through an all-reduce) and the run continues on the torch.distributed transport."""
+    """Native RCCL communicator + halo descriptor, cross-checked ONCE against the torch.distributed exchange on
+    the initial state. Two collective decisions, so that no rank ever waits for a peer that has given up:
+    (1) did every rank get its communicator, (2) did every rank's native exchange complete (60 s stall guard)
+    and reproduce the torch.distributed ghosts. Any "no" -> None on all ranks, the run continues on the
+    torch.distributed transport."""
     from t8gpu_amd import native
-    ok, nh, comm = 1, None, None
+
+    def complain(exc):
+        print(f"[bench rank {rank}] native RCCL halo unavailable ({exc}); using torch.distributed", file=sys.stderr, flush=True)
+
+    comm, nh, ok = None, None, True
     try:
         def bcast(b, src):
             box = [b]
@@ -285,10 +297,21 @@ def make_native_halo(part, tdtype, solver, torch_halo, dist, rank, world):
             return box[0]
         comm = native.NativeComm(rank, world, bcast)
         nh = native.NativeHalo(part, tdtype, comm)
-        src5 = solver.planes[0:5]
-        ghosts = slice(part.N, part.N + part.G)
-        saved = src5[:, ghosts].clone()
-        torch_halo.exchange(src5)
+    except Exception as exc:  # noqa: BLE001
+        complain(exc)
+        ok = False
+    if not _all_agree(ok, dist):
+        if comm is not None:
+            try:
+                comm.abort()
+            except Exception:  # noqa: BLE001
+                pass
+        return None
+    src5 = solver.planes[0:5]
+    ghosts = slice(part.N, part.N + part.G)
+    saved = src5[:, ghosts].clone()
+    try:
+        torch_halo.exchange(src5)                      # collective: every rank is here (decision 1)
         torch.cuda.synchronize()
         want = src5[:, ghosts].clone()
         src5[:, ghosts] = float("nan")
@@ -300,18 +323,20 @@ def make_native_halo(part, tdtype, solver, torch_halo, dist, rank, world):
         torch.cuda.synchronize()
         if part.G and not torch.equal(src5[:, ghosts], want):
             raise RuntimeError("native halo exchange disagrees with the torch.distributed exchange")
-        src5[:, ghosts] = saved
     except Exception as exc:  # noqa: BLE001
-        print(f"[bench rank {rank}] native RCCL halo unavailable ({exc}); using torch.distributed", file=sys.stderr, flush=True)
-        ok = 0
-        if comm is not None:
-            try:
-                comm.abort()
-            except Exception:  # noqa: BLE001
-                pass
-    flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    return nh if int(flag.item()) == 1 else None
+        complain(exc)
+        ok = False
+    if ok:
+        src5[:, ghosts] = saved
+    agreed = _all_agree(ok, dist)
+    if not agreed:
+        try:
+            comm.abort()
+        except Exception:  # noqa: BLE001
+            pass
+        src5[:, ghosts] = saved
+        return None
+    return nh
 
 
 def bring_up_native_stepper(solver, native_halo, delta_t, part, tdtype, dist, rank):
@@ -330,9 +355,7 @@ def bring_up_native_stepper(solver, native_halo, delta_t, part, tdtype, dist, ra
     except Exception as exc:  # noqa: BLE001
         print(f"[bench rank {rank}] native stepper unavailable ({exc}); python-driven stages", file=sys.stderr, flush=True)
         ok = 0
-    flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) == 1:
+    if _all_agree(ok == 1, dist):
         return stepper
     try:
         native_halo.comm.abort()

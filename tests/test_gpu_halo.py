@@ -216,3 +216,46 @@ def test_bench_native_bring_up_agreement_logic():
     st = bench.bring_up_native_stepper(g2, nh, dt, half, torch.float64, Group(0), 0)
     assert st is None and g2.stepper is None and (g2.next, g2.prev) == (0, 3) and torch.equal(g2.state(), ic)
     comm.destroy()
+
+
+def test_bench_make_native_halo_success_path_with_stand_ins():
+    """bench.make_native_halo end to end on one GPU: the symmetric half-domain problem, a stand-in process group
+    (one rank, self as the only peer) and a stand-in torch.distributed exchange that delivers the rank's own send
+    elements as its ghosts -- exactly what the RCCL self-exchange must then reproduce."""
+    import sys
+    import types
+    from t8gpu_amd.halo import HaloExchange
+    sys.path.insert(0, ".")
+    import bench
+    mesh = SynthMesh(2, 5, 8, band=0.05)
+    half = mesh.partition(0, 2)
+    selfpart = types.SimpleNamespace(N=half.N, G=half.G, cells_per_element=1, peers=np.zeros(1, np.int32), send_off=half.send_off,
+                                     recv_off=half.recv_off, send_idx=half.send_idx, rank=0, nranks=1, subgrid=False)
+
+    class Group:
+        ReduceOp = types.SimpleNamespace(MIN="min")
+
+        def get_backend(self):
+            return "nccl"
+
+        def all_reduce(self, t, op=None):
+            pass
+
+        def broadcast_object_list(self, box, src=0):
+            pass
+
+    class SelfExchange:
+        def __init__(self):
+            self.h = HaloExchange(selfpart, torch.float64, dist=None, overlap=False)
+
+        def exchange(self, planes5):
+            self.h._pack(planes5)
+            self.h.recvbuf.copy_(self.h.sendbuf)
+            self.h._unpack(planes5)
+
+    g = PlainSolver(half, torch.float64, mode="fused")
+    before = g.planes[0:5].clone()
+    nh = bench.make_native_halo(selfpart, torch.float64, g, SelfExchange(), Group(), 0, 1)
+    assert nh is not None
+    assert torch.equal(g.planes[0:5], before)                         # the check leaves the state as it found it
+    nh.comm.destroy()
