@@ -29,6 +29,7 @@ WORKLOADS = {
     "c1": dict(kind="plain", dim=2, base=8, lmax=8, band=0.0, dtype="f64", desc="2D KH uniform 256^2 quads"),
     "c2": dict(kind="plain", dim=2, base=6, lmax=11, band=0.0596, dtype="f64", desc="2D KH AMR levels 6-11 (~1.03 M elements)"),
     "c3": dict(kind="subgrid", dim=3, base=5, lmax=6, band=0.17, dtype="f32", desc="3D Subgrid<4,4,4> AMR levels 5-6"),
+    "c3q": dict(kind="subgrid", dim=2, base=9, lmax=10, band=0.1, dtype="f32", desc="2D Subgrid<4,4> AMR levels 9-10 (examples/subgrid/main_2d.cu)"),
     "c4": dict(kind="plain", dim=2, base=7, lmax=12, band=0.1472, dtype="f64", desc="2D KH AMR levels 7-12 (~9.93 M elements)"),
     # BASELINE config 5 needs a real t8code mixed-element cmesh; these are its geometry-synthetic stand-ins (no
     # repartition inside the timed region): c5 = 3D hex AMR (phi = 3, 6-24 faces per element, Cartesian normals),
