@@ -132,8 +132,9 @@ def test_k_way_subgrid_partition_on_one_gpu_equals_single_rank(world, mode, dim)
         assert np.array_equal(full, ref.state().cpu().numpy())      # same sums in the same order on every rank
 
 
-@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-def test_native_stepper_with_rccl_self_exchange_on_a_symmetric_problem(dtype):
+@pytest.mark.parametrize("dtype,caps", [(torch.float64, (64, 160)), (torch.float32, (64, 160)), (torch.float64, (8, 30)),
+                                        (torch.float64, (256, 512)), (torch.float64, (4000, 512))])
+def test_native_stepper_with_rccl_self_exchange_on_a_symmetric_problem(dtype, caps):
     """The C++ step driver with its RCCL exchange and two-stream pipeline, with REAL data dependencies, on one
     GPU: the mesh and the state are invariant under y -> y + 1/2, which maps the lower half of the Morton
     curve (rank 0 of 2) onto the upper half (rank 1) in order. What rank 1 would send to rank 0 is then
@@ -158,14 +159,18 @@ def test_native_stepper_with_rccl_self_exchange_on_a_symmetric_problem(dtype):
     gidx = np.concatenate([np.arange(half.N), half.ghost_global])
     local = st[:, gidx].copy()
     local[:, half.N:] = np.nan                                            # ghosts must arrive through RCCL
-    g = PlainSolver(half, dtype, mode="fused", state=local, plan_options=dict(tmax=64, fcap=160))
-    assert 0 < g.plan.host.n_interior < g.plan.host.ntiles
+    g = PlainSolver(half, dtype, mode="fused", state=local, plan_options=dict(tmax=min(caps[0], 256), fcap=caps[1]))
+    if caps[0] == 4000:                                                   # no class information: the driver must cope
+        g.plan.c.n_deep_tiles = 0
+    hp = g.plan.host
+    print("tiles C / B / A:", hp.n_deep, hp.n_interior - hp.n_deep, hp.ntiles - hp.n_interior)
     comm = native.NativeComm(0, 1, lambda b, src: b)
     fake = types.SimpleNamespace(N=half.N, G=half.G, cells_per_element=1, peers=np.zeros(1, np.int32), send_off=half.send_off,
                                  recv_off=half.recv_off, send_idx=half.send_idx)
     g.use_native_stepper(native.NativeHalo(fake, dtype, comm))
     dt = 0.1 * 2.0 ** -mesh.finest_level
-    assert 0 < g.plan.host.n_deep < g.plan.host.n_interior              # all three tile classes are populated
+    if caps == (64, 160):
+        assert 0 < hp.n_deep < hp.n_interior < hp.ntiles                  # all three tile classes are populated
     for _ in range(6 + 13):
         ref.iterate(dt)
     g.iterate(dt)                                                         # one step per call ...
