@@ -249,7 +249,7 @@ T8_DEV void from_face_frame(const T n[3], const T t1[3], const T t2[3], const T 
 // denormal or huge, so a reciprocal plus Newton steps is enough: fp32 v_rcp_f32 (1 ulp) and one
 // multiply, fp64 v_rcp_f64 + two Newton steps + one residual correction (< 1 ulp, checked in tests).
 T8_DEV float t8_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-T8_DEV double t8_rcp(double x) {
+T8_DEV double t8_rcp(double x) {   // (a bare reciprocal has no residual step behind it: two Newton steps; one leaves > 2 ulp)
   double r = __builtin_amdgcn_rcp(x);
   r        = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
   r        = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
@@ -268,7 +268,10 @@ T8_DEV double t8_sqrt_fast(double x) {
 }
 T8_DEV float  t8_div(float a, float b) { return a * t8_rcp(b); }
 T8_DEV double t8_div(double a, double b) {
-  const double r = t8_rcp(b);
+  // v_rcp_f64 (~27 bits) + ONE Newton step (~52 bits) is enough for the reciprocal here: the quotient gets its
+  // last bits from the residual correction below (pinned at < 2 ulp in tests/test_gpu_fastmath.py)
+  double r = __builtin_amdgcn_rcp(b);
+  r        = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
   const double q = a * r;
   return __builtin_fma(__builtin_fma(-b, q, a), r, q);
 }
