@@ -10,7 +10,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(_build.build_host())
+        import os
+        _lib = C.CDLL(os.environ.get("T8GPU_HOST_LIB") or _build.build_host())   # override: sanitizer builds
         _lib.t8gpu_synth_mesh_create.restype = C.c_void_p
         _lib.t8gpu_synth_mesh_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
         _lib.t8gpu_synth_mesh_destroy.argtypes = [C.c_void_p]
