@@ -150,6 +150,7 @@ def main():
     # HIP-event timing of the dominant kernel (events recorded on the launch stream)
     timers = []
     solver.kernel_timer = None
+    py_stride, py_sampled = (8 if world > 1 else 1), [0]   # python-driven stages: events on every 8th step at N > 1
 
     def run(nsteps, timed):
         if stepper is not None:
@@ -160,8 +161,10 @@ def main():
             stepper.timing((4 if world == 1 else 8) if timed else 0)
             solver.iterate_steps(nsteps, delta_t)
             return
-        for _ in range(nsteps):
-            solver.kernel_timer = timers if timed else None
+        for i in range(nsteps):
+            sampled = timed and i % py_stride == 0
+            solver.kernel_timer = timers if sampled else None
+            py_sampled[0] += 3 if sampled else 0
             solver.iterate(delta_t, halo=halo)
 
     def fence():
@@ -209,8 +212,8 @@ def main():
     per_update, flux_stage, rk = algorithmic_bytes(w["kind"], ft, phi if w["kind"] == "plain" else 0, 3, phi)
     # dominant kernel: the fused stage kernel (flux + RK of one stage) or the face-flux kernel
     if kernel_launches:
-        stride = (8 if world > 1 else 4) if stepper is not None else 1    # steps whose stage kernels carry events
-        stages_timed = stepper.timed_stages() if stepper is not None else 3 * args.steps
+        stride = (8 if world > 1 else 4) if stepper is not None else py_stride    # steps whose stage kernels carry events
+        stages_timed = stepper.timed_stages() if stepper is not None else py_sampled[0]
         steps_timed = stages_timed / 3.0
         avg_ms = kernel_ms / max(1, stages_timed)   # one fused stage may be split into several tile ranges
         local_cells = part.N * cells
