@@ -21,7 +21,12 @@ class PlainPlan:
         """compressed=False: generic kernel (CSR lists, full geometry). dictionary=False: pipelined kernel
         with per-face geometry rows even where the mesh has few distinct ones (what curved meshes get anyway)."""
         import os
-        tmax = int(os.environ.get("T8GPU_TMAX", 256)) if tmax is None else tmax     # tuning knobs of the tiling
+        # tuning knobs of the tiling. A mesh that would give fewer than 512 tiles (two per CU) gets half-size tiles:
+        # c1 (65 536 elements) runs 16 % faster on 512 tiles of 128 than on 256 tiles of 256.
+        small = part.N < 512 * 256 and tmax is None and fcap is None and "T8GPU_TMAX" not in os.environ
+        tmax = int(os.environ.get("T8GPU_TMAX", 128 if small else 256)) if tmax is None else tmax
+        if small:
+            fcap = int(os.environ.get("T8GPU_FCAP", 256))
         # 512 faces = two passes of 256. Larger tiles (the kernel takes up to 1024 faces in four passes) were
         # measured on 3D meshes, where 512 cuts tiles at ~130-150 elements: 768 / 1024 are 1-8 % SLOWER (LDS per
         # workgroup grows, 3 instead of 4 workgroups per CU), and so is a 512-lane workgroup with one lane per
