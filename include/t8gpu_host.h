@@ -81,6 +81,36 @@ void t8gpu_plan_subgrid_arrays(const void* plan, int32_t* bf_off, int32_t* bf_en
  * float_size = 4 or 8 selects how the areas are stored in the records. */
 void t8gpu_plan_subgrid_records(const void* plan, const double* areas, int float_size, int32_t* block_rec, int32_t* bf_rec);
 
+/* ---- connectivity from forest queries (the t8code-independent part) -------------------------
+ * What MeshManager::compute_connectivity_information (mesh_manager.inl:333-481) asks of t8code, as callbacks;
+ * slots [0, num_local) are the rank's elements, [num_local, num_local + num_ghost) its ghost layer, ordered by
+ * owner rank, then global index (t8code's order). csrc/host/connectivity.cpp states the listing rule. */
+typedef struct T8gpuForestQuery {
+  void*   ctx;
+  int32_t num_local, num_ghost;
+  int64_t (*global_id)(void* ctx, int32_t slot);        /* position on the space-filling curve                  */
+  int32_t (*owner_rank)(void* ctx, int32_t ghost);      /* ghost = slot - num_local                             */
+  int32_t (*level)(void* ctx, int32_t slot);
+  int32_t (*num_faces)(void* ctx, int32_t slot);
+  /* neighbours of LOCAL element e across its face f (t8_forest_leaf_face_neighbors): their slots and the face
+   * numbers on their side; returns how many (0 = domain boundary, > 1 = finer neighbours), at most max_n  */
+  int32_t (*face_neighbors)(void* ctx, int32_t e, int32_t f, int32_t max_n, int32_t* slots, int32_t* dual_faces);
+  void    (*face_normal)(void* ctx, int32_t slot, int32_t f, double normal[3]);   /* outward, unit; ghosts too   */
+  double  (*face_area)(void* ctx, int32_t slot, int32_t f);                       /* ghosts too                  */
+  double  (*volume)(void* ctx, int32_t slot);                                     /* ghosts too                  */
+} T8gpuForestQuery;
+void* t8gpu_host_connectivity_create(const T8gpuForestQuery* query);   /* NULL on a malformed query */
+void  t8gpu_host_connectivity_destroy(void* connectivity);
+/* counts[6] = {N, G, F, B, n_peers, n_send} */
+void t8gpu_host_connectivity_counts(const void* connectivity, int64_t* counts);
+/* face_neighbors[2F + B], normals[3 (F + B)], areas[F + B], volumes[N + G], peers[n_peers], recv_off[n_peers + 1],
+ * send_off[n_peers + 1], send_idx[n_send]: the inputs of t8gpu_plan_plain_create and T8gpuHalo */
+void t8gpu_host_connectivity_arrays(const void* connectivity, int32_t* face_neighbors, double* normals, double* areas,
+                                    double* volumes, int32_t* peers, int32_t* recv_off, int32_t* send_off, int32_t* send_idx);
+/* The synthetic forest behind the same callbacks (tests): destroy with t8gpu_synth_query_destroy. */
+T8gpuForestQuery* t8gpu_synth_query_create(const void* mesh, int rank, int nranks);
+void              t8gpu_synth_query_destroy(T8gpuForestQuery* query);
+
 /* ---- VTK output (stands where t8_forest_write_vtk_ext is called: mesh_manager.inl:588-623,
  * subgrid_mesh_manager.inl:1051-1138,1185-1206) ------------------------------------------------------------
  * One .vtu piece: a VTK_QUAD / VTK_HEXAHEDRON per leaf with unshared corners, cell fields treeid, mpirank,

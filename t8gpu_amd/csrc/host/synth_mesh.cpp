@@ -22,6 +22,8 @@
 #include <cstring>
 #include <vector>
 
+#include "t8gpu_host.h"
+
 namespace {
 
 struct Leaf {
@@ -600,5 +602,85 @@ int t8gpu_synth_mesh_adapt_data(const void* old_mesh, const void* new_mesh, int3
   adapt_data[nn] = static_cast<int32_t>(no);
   return 0;
 }
+
+
+// ---- the synthetic forest behind the T8gpuForestQuery callbacks (tests of csrc/host/connectivity.cpp) --------
+namespace {
+struct SynthQuery {
+  T8gpuForestQuery q;   // first member: the handle handed out is &q
+  const Mesh*      m;
+  Part             part;   // only first / N / ghost_global / ghost_owner are used (the slot numbering)
+  int64_t gid(int32_t slot) const { return slot < part.N ? part.first + slot : part.ghost_global[slot - part.N]; }
+  int32_t slot_of(int64_t g) const {
+    if (g >= part.first && g < part.first + part.N) return static_cast<int32_t>(g - part.first);
+    return part.N + static_cast<int32_t>(std::lower_bound(part.ghost_global.begin(), part.ghost_global.end(), g) - part.ghost_global.begin());
+  }
+};
+SynthQuery* SQ(void* c) { return static_cast<SynthQuery*>(c); }
+}  // namespace
+
+T8gpuForestQuery* t8gpu_synth_query_create(const void* mesh, int rank, int nranks) {
+  const Mesh* m = static_cast<const Mesh*>(mesh);
+  if (!m || rank < 0 || rank >= nranks) return nullptr;
+  SynthQuery* s = new SynthQuery;
+  s->m           = m;
+  s->part.m      = m;
+  s->part.rank   = rank;
+  s->part.nranks = nranks;
+  s->part.ndim   = 3;
+  build_part(s->part);
+  T8gpuForestQuery& q = s->q;
+  q.ctx        = s;
+  q.num_local  = s->part.N;
+  q.num_ghost  = s->part.G;
+  q.global_id  = [](void* c, int32_t slot) -> int64_t { return SQ(c)->gid(slot); };
+  q.owner_rank = [](void* c, int32_t g) -> int32_t { return SQ(c)->part.ghost_owner[g]; };
+  q.level      = [](void* c, int32_t slot) -> int32_t { return SQ(c)->m->leaves[SQ(c)->gid(slot)].level; };
+  q.num_faces  = [](void* c, int32_t) -> int32_t { return 2 * SQ(c)->m->dim; };
+  q.face_neighbors = [](void* c, int32_t e, int32_t f, int32_t max_n, int32_t* slots, int32_t* dual) -> int32_t {
+    const SynthQuery* s = SQ(c);
+    const Mesh&       M = *s->m;
+    const int64_t     ge = s->gid(e);
+    const int32_t     one = M.across(static_cast<size_t>(ge), f);
+    if (one < 0) return 0;
+    const Leaf& l = M.leaves[ge];
+    if (M.leaves[one].level <= l.level) {
+      slots[0] = s->slot_of(one);
+      dual[0]  = f ^ 1;
+      return 1;
+    }
+    // finer neighbours (2:1 balance: exactly one level finer): probe the 2^(dim-1) sub-faces
+    const uint32_t sz = 1u << (M.lmax - l.level), ext = 1u << M.lmax, half = sz / 2;
+    const int      d  = f / 2;
+    int32_t        k  = 0;
+    for (int b = 0; b < (1 << (M.dim - 1)); b++) {
+      uint32_t p[3] = {l.c[0] * sz, l.c[1] * sz, M.dim == 3 ? l.c[2] * sz : 0};
+      p[d] = (f & 1) ? (p[d] + sz) % ext : (p[d] + ext - 1) % ext;
+      int bit = 0;
+      for (int a = 0; a < M.dim; a++)
+        if (a != d) p[a] += ((b >> bit++) & 1) * half;
+      if (k >= max_n) return -1;
+      slots[k] = s->slot_of(M.owner[M.grid_index(p)]);
+      dual[k]  = f ^ 1;
+      k++;
+    }
+    return k;
+  };
+  q.face_normal = [](void*, int32_t, int32_t f, double n[3]) {
+    n[0] = n[1] = n[2] = 0.0;
+    n[f / 2] = (f & 1) ? 1.0 : -1.0;
+  };
+  q.face_area = [](void* c, int32_t slot, int32_t) -> double {
+    const double h = std::ldexp(1.0, -SQ(c)->m->leaves[SQ(c)->gid(slot)].level);
+    return SQ(c)->m->dim == 3 ? h * h : h;
+  };
+  q.volume = [](void* c, int32_t slot) -> double {
+    const double h = std::ldexp(1.0, -SQ(c)->m->leaves[SQ(c)->gid(slot)].level);
+    return SQ(c)->m->dim == 3 ? h * h * h : h * h;
+  };
+  return &s->q;
+}
+
+void t8gpu_synth_query_destroy(T8gpuForestQuery* q) { delete reinterpret_cast<SynthQuery*>(q); }
 
 }  // extern "C"
