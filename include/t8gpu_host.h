@@ -98,8 +98,13 @@ typedef struct T8gpuForestQuery {
   void    (*face_normal)(void* ctx, int32_t slot, int32_t f, double normal[3]);   /* outward, unit; ghosts too   */
   double  (*face_area)(void* ctx, int32_t slot, int32_t f);                       /* ghosts too                  */
   double  (*volume)(void* ctx, int32_t slot);                                     /* ghosts too                  */
+  int32_t (*child_id)(void* ctx, int32_t slot);   /* t8_element_child_id; only for ..._create_subgrid (may be NULL otherwise) */
 } T8gpuForestQuery;
 void* t8gpu_host_connectivity_create(const T8gpuForestQuery* query);   /* NULL on a malformed query */
+/* Subgrid meshes (subgrid_rank = 2 | 3, quad / hex forests): additionally face_level_difference[F] and
+ * face_neighbor_offset[rank * F] of subgrid_mesh_manager.inl:587-680; normals keep 3 components here. */
+void* t8gpu_host_connectivity_create_subgrid(const T8gpuForestQuery* query, int32_t subgrid_rank);
+void  t8gpu_host_connectivity_subgrid_arrays(const void* connectivity, int32_t* face_level_difference, int32_t* face_neighbor_offset);
 void  t8gpu_host_connectivity_destroy(void* connectivity);
 /* counts[6] = {N, G, F, B, n_peers, n_send} */
 void t8gpu_host_connectivity_counts(const void* connectivity, int64_t* counts);

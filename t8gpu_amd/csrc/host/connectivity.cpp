@@ -29,6 +29,8 @@ struct Conn {
   std::vector<int32_t> fn;
   std::vector<double>  normals, areas, volumes;
   std::vector<int32_t> peers, recv_off, send_off, send_idx;
+  std::vector<int32_t> level_diff, nb_offset;   // Subgrid meshes only
+  int32_t              rank = 0;
 };
 
 struct Raw {
@@ -42,7 +44,15 @@ struct Raw {
 
 extern "C" {
 
-void* t8gpu_host_connectivity_create(const T8gpuForestQuery* q) {
+void* t8gpu_host_connectivity_create(const T8gpuForestQuery* q) { return t8gpu_host_connectivity_create_subgrid(q, 0); }
+
+// subgrid_rank = 2 | 3 adds what the Subgrid kernels need per face (subgrid_mesh_manager.inl:587-680):
+// face_level_difference = level(right) - level(left) <= 0 and face_neighbor_offset = the anchor inside the right
+// (coarser-or-equal) block: on the shared face plane along the face axis, the half-block selected by the left
+// element's child id along the other axes when the right block is coarser. Needs q->child_id; quad / hex faces
+// numbered -x, +x, -y, +y, -z, +z (t8code's order for these classes).
+void* t8gpu_host_connectivity_create_subgrid(const T8gpuForestQuery* q, int32_t subgrid_rank) {
+  if ((subgrid_rank != 0 && subgrid_rank != 2 && subgrid_rank != 3) || (subgrid_rank != 0 && (!q || !q->child_id))) return nullptr;
   if (!q || q->num_local < 0 || q->num_ghost < 0 || !q->global_id || !q->level || !q->num_faces || !q->face_neighbors ||
       !q->face_normal || !q->face_area || !q->volume || (q->num_ghost > 0 && !q->owner_rank))
     return nullptr;
@@ -99,6 +109,26 @@ void* t8gpu_host_connectivity_create(const T8gpuForestQuery* q) {
     q->face_normal(q->ctx, r.gslot, r.gface, &C->normals[3 * i]);
     C->areas[i] = q->face_area(q->ctx, r.gslot, r.gface);
   }
+  if (subgrid_rank) {
+    C->rank = subgrid_rank;
+    C->level_diff.resize(faces.size());
+    C->nb_offset.assign(static_cast<size_t>(subgrid_rank) * faces.size(), 0);
+    for (size_t i = 0; i < faces.size(); i++) {
+      const Raw&    r  = faces[i];
+      const int32_t ll = q->level(q->ctx, r.l), lr = q->level(q->ctx, r.r);
+      C->level_diff[i] = lr - ll;
+      const int     ax = r.key_face / 2;
+      const int32_t child = q->child_id(q->ctx, r.l);
+      for (int d = 0; d < subgrid_rank; d++) {
+        int o = 0;
+        if (d == ax)
+          o = (r.key_face & 1) ? 0 : 3;
+        else if (lr < ll)
+          o = 2 * ((child >> d) & 1);
+        C->nb_offset[static_cast<size_t>(subgrid_rank) * i + d] = o;
+      }
+    }
+  }
   C->volumes.resize(static_cast<size_t>(N) + G);
   for (int32_t s = 0; s < N + G; s++) C->volumes[s] = q->volume(q->ctx, s);
   // halo lists
@@ -154,6 +184,14 @@ void t8gpu_host_connectivity_arrays(const void* h, int32_t* face_neighbors, doub
   cp(recv_off, C->recv_off);
   cp(send_off, C->send_off);
   cp(send_idx, C->send_idx);
+}
+
+
+/* Subgrid meshes: face_level_difference[F], face_neighbor_offset[rank * F] */
+void t8gpu_host_connectivity_subgrid_arrays(const void* h, int32_t* level_diff, int32_t* nb_offset) {
+  const Conn* C = static_cast<const Conn*>(h);
+  if (level_diff && !C->level_diff.empty()) std::memcpy(level_diff, C->level_diff.data(), C->level_diff.size() * sizeof(int32_t));
+  if (nb_offset && !C->nb_offset.empty()) std::memcpy(nb_offset, C->nb_offset.data(), C->nb_offset.size() * sizeof(int32_t));
 }
 
 }  // extern "C"

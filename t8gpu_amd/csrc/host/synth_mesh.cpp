@@ -674,6 +674,10 @@ T8gpuForestQuery* t8gpu_synth_query_create(const void* mesh, int rank, int nrank
     const double h = std::ldexp(1.0, -SQ(c)->m->leaves[SQ(c)->gid(slot)].level);
     return SQ(c)->m->dim == 3 ? h * h : h;
   };
+  q.child_id = [](void* c, int32_t slot) -> int32_t {
+    const Leaf& l = SQ(c)->m->leaves[SQ(c)->gid(slot)];
+    return static_cast<int32_t>((l.c[0] & 1u) | ((l.c[1] & 1u) << 1) | ((l.c[2] & 1u) << 2));
+  };
   q.volume = [](void* c, int32_t slot) -> double {
     const double h = std::ldexp(1.0, -SQ(c)->m->leaves[SQ(c)->gid(slot)].level);
     return SQ(c)->m->dim == 3 ? h * h * h : h * h;

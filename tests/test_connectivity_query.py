@@ -65,3 +65,42 @@ def test_malformed_queries_are_rejected():
     assert not lib.t8gpu_host_connectivity_create(None)
     zero = (C.c_byte * 128)()                       # all callbacks NULL
     assert not lib.t8gpu_host_connectivity_create(C.cast(zero, C.c_void_p))
+
+
+@pytest.mark.parametrize("dim,base,lmax,band,periodic", [(2, 2, 4, 0.1, True), (2, 3, 5, 0.05, False), (3, 1, 3, 0.15, True),
+                                                         (3, 2, 3, 0.1, False)])
+@pytest.mark.parametrize("nranks", [1, 3])
+def test_subgrid_arrays_from_the_query(dim, base, lmax, band, periodic, nranks):
+    """face_level_difference / face_neighbor_offset (subgrid_mesh_manager.inl:587-680) from the callbacks + child ids."""
+    lib = synth.lib()
+    lib.t8gpu_synth_query_create.restype = C.c_void_p
+    lib.t8gpu_synth_query_create.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.t8gpu_synth_query_destroy.argtypes = [C.c_void_p]
+    lib.t8gpu_host_connectivity_create_subgrid.restype = C.c_void_p
+    lib.t8gpu_host_connectivity_create_subgrid.argtypes = [C.c_void_p, C.c_int32]
+    lib.t8gpu_host_connectivity_destroy.argtypes = [C.c_void_p]
+    lib.t8gpu_host_connectivity_counts.argtypes = [C.c_void_p, C.c_void_p]
+    lib.t8gpu_host_connectivity_arrays.argtypes = [C.c_void_p] * 9
+    lib.t8gpu_host_connectivity_subgrid_arrays.argtypes = [C.c_void_p] * 3
+    mesh = SynthMesh(dim, base, lmax, band=band, periodic=periodic)
+    for rank in range(nranks):
+        want = mesh.partition(rank, nranks, subgrid=True)
+        q = lib.t8gpu_synth_query_create(mesh._h, rank, nranks)
+        h = lib.t8gpu_host_connectivity_create_subgrid(q, dim)
+        assert h
+        try:
+            cnt = np.zeros(6, np.int64)
+            lib.t8gpu_host_connectivity_counts(h, cnt.ctypes.data)
+            F, B = int(cnt[2]), int(cnt[3])
+            assert (F, B) == (want.F, want.B)
+            fn, nrm = np.zeros(2 * F + B, np.int32), np.zeros(3 * (F + B))
+            ld, off = np.zeros(F, np.int32), np.zeros(dim * F, np.int32)
+            lib.t8gpu_host_connectivity_arrays(h, fn.ctypes.data, nrm.ctypes.data, None, None, None, None, None, None)
+            lib.t8gpu_host_connectivity_subgrid_arrays(h, ld.ctypes.data if F else None, off.ctypes.data if F else None)
+            assert np.array_equal(fn, want.face_neighbors)
+            assert np.array_equal(nrm.reshape(-1, 3)[:, :dim].reshape(-1), want.normals)
+            assert np.array_equal(ld, want.level_diff) and np.array_equal(off, want.nb_offset)
+            assert (ld <= 0).all()
+        finally:
+            lib.t8gpu_host_connectivity_destroy(h)
+            lib.t8gpu_synth_query_destroy(q)
