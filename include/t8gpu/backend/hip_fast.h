@@ -74,6 +74,35 @@ namespace t8gpu::hip {
                    volume, delta_t, stream);
   }
 
+  /// What the halo exchange needs besides HostMeshArrays (peers ascending; offsets have n_peers + 1 entries).
+  struct HostHaloArrays {
+    std::vector<int32_t> peers, recv_off, send_off, send_idx;
+  };
+
+  /// the connectivity of one rank from forest-query callbacks (csrc/host/connectivity.cpp): the
+  /// arrays a MeshManager's compute_connectivity_information hands to this backend.
+  inline HostMeshArrays host_mesh_arrays_from_query(T8gpuForestQuery const& q, int rank = 0, HostHaloArrays* halo = nullptr) {
+    void* h = t8gpu_host_connectivity_create(&q);
+    if (!h) T8GPU_ABORT("t8gpu_host_connectivity_create failed (malformed forest query)");
+    int64_t c[6];
+    t8gpu_host_connectivity_counts(h, c);
+    HostMeshArrays m;
+    m.num_local_elements = static_cast<int32_t>(c[0]); m.num_ghost_elements = static_cast<int32_t>(c[1]);
+    m.num_local_faces = static_cast<int32_t>(c[2]); m.num_local_boundary_faces = static_cast<int32_t>(c[3]);
+    m.rank = rank;
+    m.face_neighbors.resize(2 * c[2] + c[3]);
+    m.face_normals.resize(3 * (c[2] + c[3]));
+    m.face_surfaces.resize(c[2] + c[3]);
+    m.volumes.resize(c[0] + c[1]);
+    HostHaloArrays hh;
+    hh.peers.resize(c[4]); hh.recv_off.resize(c[4] + 1); hh.send_off.resize(c[4] + 1); hh.send_idx.resize(c[5]);
+    t8gpu_host_connectivity_arrays(h, m.face_neighbors.data(), m.face_normals.data(), m.face_surfaces.data(), m.volumes.data(),
+                                   hh.peers.data(), hh.recv_off.data(), hh.send_off.data(), hh.send_idx.data());
+    t8gpu_host_connectivity_destroy(h);
+    if (halo) *halo = std::move(hh);
+    return m;
+  }
+
   /// Device copy of the tile plan (t8gpu_plan_plain_create) + the native step driver.
   template<typename ft>
   class PlainFusedPlan {

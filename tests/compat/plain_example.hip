@@ -171,14 +171,11 @@ int main(int argc, char** argv) {
   void*        part = t8gpu_synth_part_create(mesh, 0, 1, 0, 3);
   int64_t      cnt[8];
   t8gpu_synth_part_counts(part, cnt);
-  HostMeshArrays m;
-  m.num_local_elements = static_cast<int32_t>(cnt[0]); m.num_ghost_elements = static_cast<int32_t>(cnt[1]);
-  m.num_local_faces = static_cast<int32_t>(cnt[2]); m.num_local_boundary_faces = static_cast<int32_t>(cnt[3]);
-  m.face_neighbors.resize(2 * cnt[2] + cnt[3]);
-  m.face_normals.resize(3 * (cnt[2] + cnt[3]));
-  m.face_surfaces.resize(cnt[2] + cnt[3]);
-  m.volumes.resize(cnt[0] + cnt[1]);
-  t8gpu_synth_part_connectivity(part, m.face_neighbors.data(), m.face_normals.data(), m.face_surfaces.data(), nullptr, nullptr);
+  // connectivity through the forest-query adapter, the way a t8code build would get it
+  T8gpuForestQuery* query = t8gpu_synth_query_create(mesh, 0, 1);
+  HostMeshArrays    m     = t8gpu::hip::host_mesh_arrays_from_query(*query);
+  t8gpu_synth_query_destroy(query);
+  if (m.num_local_elements != cnt[0] || m.num_local_faces != cnt[2] || m.num_local_boundary_faces != cnt[3]) return 4;
   std::vector<int32_t> lev(cnt[0] + cnt[1]);
   std::vector<double>  cen(3 * (cnt[0] + cnt[1]));
   t8gpu_synth_part_elements(part, lev.data(), m.volumes.data(), cen.data());
