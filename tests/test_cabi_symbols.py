@@ -28,6 +28,15 @@ def test_library_builds_loads_and_exports_the_header():
     assert lib.t8gpu_hip_abi_version() >= 1
 
 
+def test_host_library_exports_its_header():
+    lib = ctypes.CDLL(build.build_host())
+    text = open(os.path.join(ROOT, "include", "t8gpu_host.h")).read()
+    names = set(re.findall(r"\b(t8gpu_(?:synth|plan|host)_[a-z0-9_]+)\s*\(", text))
+    assert len(names) >= 30
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
 def test_host_library_has_no_hip_dependency():
     import subprocess
     out = subprocess.check_output(["ldd", build.build_host()]).decode()
