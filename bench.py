@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default=os.environ.get("T8GPU_BENCH_MODE", "auto"), choices=["auto", "compat", "fused"])
-    ap.add_argument("--flux", default="kepes", choices=["kepes", "hll"])
+    ap.add_argument("--flux", default="kepes", choices=["kepes", "hll", "hllc"])
     ap.add_argument("--dtype", default=None, choices=[None, "f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -99,7 +99,7 @@ def main():
     dts = args.dtype or w["dtype"]
     tdtype = torch.float64 if dts == "f64" else torch.float32
     ft = 8 if dts == "f64" else 4
-    kindf = hip.KEPES if args.flux == "kepes" else hip.HLL
+    kindf = {"kepes": hip.KEPES, "hll": hip.HLL, "hllc": hip.HLLC}[args.flux]
     mode = args.mode
     if mode == "auto":
         try:

@@ -17,7 +17,8 @@
  *   - return value: 0 on success, otherwise the hipError_t (or ncclResult_t + 10000) code; the C++
  *     wrappers turn non-zero into the reference's print-and-abort (t8gpu/utils/cuda.h:7-15).
  *   - flux_kind: 0 = KEPES (the flux the reference runs), 1 = HLL (reference dead code,
- *     examples/subgrid/kernels.inl:263-332).
+ *     examples/subgrid/kernels.inl:263-332), 2 = HLLC (NOT in the reference: the project brief names it; the HLL
+ *     above with the contact wave restored, same wave-speed estimates; oracle/oracle.hpp states the formulas).
  */
 #ifndef T8GPU_HIP_H
 #define T8GPU_HIP_H
@@ -31,6 +32,7 @@ extern "C" {
 
 #define T8GPU_FLUX_KEPES 0
 #define T8GPU_FLUX_HLL 1
+#define T8GPU_FLUX_HLLC 2
 
 typedef struct T8gpuVars_f32 { float* p[5]; } T8gpuVars_f32;
 typedef struct T8gpuVars_f64 { double* p[5]; } T8gpuVars_f64;

@@ -233,12 +233,54 @@ inline void to_face_frame(const T n[3], const T t1[3], const T t2[3], const T s[
   r[4]       = s[4];
 }
 
-enum FluxKind { KEPES = 0, HLL = 1 };
+// ---------------------------------------------------------------------------
+// HLLC (Toro, Spruce & Speares 1994; Toro, "Riemann Solvers ...", 3rd ed., eqs. 10.37-10.39, 10.71-10.73).
+// NOT in the reference (its only approximate Riemann solver is the dead HLL above); the project brief
+// names it, so it is offered as a third flux with the wave-speed estimates of that HLL (Roe averages and
+// one-sided bounds, kernels.inl:296-304) and the contact restored. Checked by its defining properties
+// (consistency, exact stationary / moving contacts, upwinding) in tests/test_oracle_golden.py.
+// ---------------------------------------------------------------------------
+template <class T>
+inline void hllc_total_flux(const T uL[5], const T uR[5], T F[5]) {
+  const T zero = T(0), one = T(1), half = T(0.5);
+  const T g = T(1.4);
+  const T v1l = uL[1] / uL[0], v2l = uL[2] / uL[0], v3l = uL[3] / uL[0];
+  const T kl  = half * (v1l * v1l + v2l * v2l + v3l * v3l);
+  const T pl  = (g - one) * (uL[4] - uL[0] * kl);
+  const T Hl  = (uL[4] + pl) / uL[0];
+  const T cl  = std::sqrt((g - one) * (Hl - kl));
+  const T v1r = uR[1] / uR[0], v2r = uR[2] / uR[0], v3r = uR[3] / uR[0];
+  const T kr  = half * (v1r * v1r + v2r * v2r + v3r * v3r);
+  const T pr  = (g - one) * (uR[4] - uR[0] * kr);
+  const T Hr  = (uR[4] + pr) / uR[0];
+  const T cr  = std::sqrt((g - one) * (Hr - kr));
+  const T wl = std::sqrt(uL[0]), wr = std::sqrt(uR[0]);
+  const T ws = wl + wr;
+  const T v1 = (wl * v1l + wr * v1r) / ws, v2 = (wl * v2l + wr * v2r) / ws, v3 = (wl * v3l + wr * v3r) / ws;
+  const T H  = (wl * Hl + wr * Hr) / ws;
+  const T c  = std::sqrt((g - one) * (H - half * (v1 * v1 + v2 * v2 + v3 * v3)));
+  const T Sl = std::min(v1 - c, v1l - cl), Sr = std::max(v1 + c, v1r + cr);
+  const T ml = uL[0] * (Sl - v1l), mr = uR[0] * (Sr - v1r);           // rho_K (S_K - u_K)
+  const T Ss = ((pr - pl) + (uL[1] * (Sl - v1l) - uR[1] * (Sr - v1r))) / (ml - mr);
+  const bool left = Ss >= zero;
+  const T*   u  = left ? uL : uR;
+  const T    S  = left ? std::min(Sl, zero) : std::max(Sr, zero);     // S_K, or 0 when that side is fully upwind
+  const T    SK = left ? Sl : Sr, vn = left ? v1l : v1r, vt1 = left ? v2l : v2r, vt2 = left ? v3l : v3r;
+  const T    p = left ? pl : pr, Hk = left ? Hl : Hr, m = left ? ml : mr;
+  const T    fac = m / (SK - Ss);                                      // rho*_K
+  const T    Us[5] = {fac, fac * Ss, fac * vt1, fac * vt2, fac * (u[4] / u[0] + (Ss - vn) * (Ss + p / m))};
+  const T    Fk[5] = {u[1], u[1] * vn + p, u[1] * vt1, u[1] * vt2, u[1] * Hk};
+  for (int k = 0; k < 5; k++) F[k] = Fk[k] + S * (Us[k] - u[k]);
+}
+
+enum FluxKind { KEPES = 0, HLL = 1, HLLC = 2 };
 
 template <class T>
 inline void face_frame_flux(int kind, const T a[5], const T b[5], T F[5], T* speed) {
   if (kind == HLL) {
     hll_total_flux<T>(a, b, F);
+  } else if (kind == HLLC) {
+    hllc_total_flux<T>(a, b, F);
   } else {
     kepes_total_flux<T>(a, b, F, speed);
   }

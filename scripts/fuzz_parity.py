@@ -28,7 +28,7 @@ def main():
     while time.time() - t0 < budget and (only is None or n < only):
         kind = rng.choice(["plain2", "plain3", "prism", "sub2", "sub3"])
         dtype = torch.float64 if rng.random() < 0.5 else torch.float32
-        flux = hip.KEPES if rng.random() < 0.7 else hip.HLL
+        flux = hip.KEPES if rng.random() < 0.7 else (hip.HLL if rng.random() < 0.5 else hip.HLLC)
         periodic = bool(rng.random() < 0.5)
         band = float(rng.choice([0.0, 0.02, 0.05, 0.11, 0.3]))
         seed = int(rng.integers(1 << 30))

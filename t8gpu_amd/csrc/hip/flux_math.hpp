@@ -159,6 +159,43 @@ T8_DEV void hll_ref(const T uL[5], const T uR[5], T F[5]) {
   for (int k = 0; k < 5; k++) F[k] = ((sr * Fl[k] - sl * Fr[k]) + sr * sl * (uR[k] - uL[k])) / (sr - sl);
 }
 
+// HLLC (not in the reference; see oracle.hpp): the HLL above with the contact wave restored, same wave speeds.
+template <class T>
+T8_DEV void hllc_ref(const T uL[5], const T uR[5], T F[5]) {
+  const T zero = T(0), one = T(1), half = T(0.5);
+  const T g = T(1.4);
+  const T v1l = uL[1] / uL[0], v2l = uL[2] / uL[0], v3l = uL[3] / uL[0];
+  const T kl  = half * (v1l * v1l + v2l * v2l + v3l * v3l);
+  const T pl  = (g - one) * (uL[4] - uL[0] * kl);
+  const T Hl  = (uL[4] + pl) / uL[0];
+  const T cl  = t8_sqrt((g - one) * (Hl - kl));
+  const T v1r = uR[1] / uR[0], v2r = uR[2] / uR[0], v3r = uR[3] / uR[0];
+  const T kr  = half * (v1r * v1r + v2r * v2r + v3r * v3r);
+  const T pr  = (g - one) * (uR[4] - uR[0] * kr);
+  const T Hr  = (uR[4] + pr) / uR[0];
+  const T cr  = t8_sqrt((g - one) * (Hr - kr));
+  const T wl = t8_sqrt(uL[0]), wr = t8_sqrt(uR[0]);
+  const T ws = wl + wr;
+  const T v1 = (wl * v1l + wr * v1r) / ws, v2 = (wl * v2l + wr * v2r) / ws, v3 = (wl * v3l + wr * v3r) / ws;
+  const T H  = (wl * Hl + wr * Hr) / ws;
+  const T c  = t8_sqrt((g - one) * (H - half * (v1 * v1 + v2 * v2 + v3 * v3)));
+  const T Sl = t8_min(v1 - c, v1l - cl), Sr = t8_max(v1 + c, v1r + cr);
+  const T ml = uL[0] * (Sl - v1l), mr = uR[0] * (Sr - v1r);
+  const T Ss = ((pr - pl) + (uL[1] * (Sl - v1l) - uR[1] * (Sr - v1r))) / (ml - mr);
+  const bool left = Ss >= zero;
+  const T    S  = left ? t8_min(Sl, zero) : t8_max(Sr, zero);
+  const T    SK = left ? Sl : Sr, vn = left ? v1l : v1r, vt1 = left ? v2l : v2r, vt2 = left ? v3l : v3r;
+  const T    p = left ? pl : pr, Hk = left ? Hl : Hr, m = left ? ml : mr;
+  T          u[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) u[k] = left ? uL[k] : uR[k];
+  const T fac = m / (SK - Ss);
+  const T Us[5] = {fac, fac * Ss, fac * vt1, fac * vt2, fac * (u[4] / u[0] + (Ss - vn) * (Ss + p / m))};
+  const T Fk[5] = {u[1], u[1] * vn + p, u[1] * vt1, u[1] * vt2, u[1] * Hk};
+#pragma unroll
+  for (int k = 0; k < 5; k++) F[k] = Fk[k] + S * (Us[k] - u[k]);
+}
+
 // frame of an axis-aligned face: exactly what face_basis() returns for n = +-e_axis
 template <class T>
 T8_DEV void axis_basis(int axis, bool positive, T n[3], T t1[3], T t2[3]) {
@@ -219,6 +256,9 @@ T8_DEV void face_frame_flux_ref(const T n[3], const T t1[3], const T t2[3], cons
   to_face_frame<T>(n, t1, t2, mirror ? sL : sR, b, mirror);
   if (KIND == 1) {
     hll_ref<T>(a, b, Ff);
+    speed = T(0);
+  } else if (KIND == 2) {
+    hllc_ref<T>(a, b, Ff);
     speed = T(0);
   } else {
     kepes_ref<T>(a, b, Ff, speed);
@@ -489,13 +529,51 @@ T8_DEV void hll_fast(const T uL[5], const T uR[5], T F[5]) {
   for (int k = 0; k < 5; k++) F[k] = ((sr * Fl[k] - sl * Fr[k]) + sr * sl * (uR[k] - uL[k])) * id;
 }
 
-// face-frame HLL flux of an xyz state pair, scaled by `area`, rotated back to xyz (fast tier)
+// HLLC for the fast tier: hllc_ref with shared reciprocals and the fast division / sqrt
 template <class T>
-T8_DEV void hll_face(const T sL[5], const T sR[5], bool mirror, const T n[3], const T t1[3], const T t2[3], T area, T g[5]) {
+T8_DEV void hllc_fast(const T uL[5], const T uR[5], T F[5]) {
+  const T zero = T(0), one = T(1), half = T(0.5);
+  const T gm1 = T(1.4) - one;
+  const T irl = t8_rcp(uL[0]), irr = t8_rcp(uR[0]);
+  const T v1l = uL[1] * irl, v2l = uL[2] * irl, v3l = uL[3] * irl;
+  const T v1r = uR[1] * irr, v2r = uR[2] * irr, v3r = uR[3] * irr;
+  const T kl = half * (v1l * v1l + v2l * v2l + v3l * v3l), kr = half * (v1r * v1r + v2r * v2r + v3r * v3r);
+  const T pl = gm1 * (uL[4] - uL[0] * kl), pr = gm1 * (uR[4] - uR[0] * kr);
+  const T Hl = (uL[4] + pl) * irl, Hr = (uR[4] + pr) * irr;
+  const T cl = t8_sqrt_fast(gm1 * (Hl - kl)), cr = t8_sqrt_fast(gm1 * (Hr - kr));
+  const T wl = t8_sqrt_fast(uL[0]), wr = t8_sqrt_fast(uR[0]);
+  const T iw = t8_rcp(wl + wr);
+  const T v1 = (wl * v1l + wr * v1r) * iw, v2 = (wl * v2l + wr * v2r) * iw, v3 = (wl * v3l + wr * v3r) * iw;
+  const T H  = (wl * Hl + wr * Hr) * iw;
+  const T c  = t8_sqrt_fast(gm1 * (H - half * (v1 * v1 + v2 * v2 + v3 * v3)));
+  const T Sl = t8_min(v1 - c, v1l - cl), Sr = t8_max(v1 + c, v1r + cr);
+  const T ml = uL[0] * (Sl - v1l), mr = uR[0] * (Sr - v1r);
+  const T Ss = t8_div((pr - pl) + (uL[1] * (Sl - v1l) - uR[1] * (Sr - v1r)), ml - mr);
+  const bool left = Ss >= zero;
+  const T    S  = left ? t8_min(Sl, zero) : t8_max(Sr, zero);
+  const T    SK = left ? Sl : Sr, vn = left ? v1l : v1r, vt1 = left ? v2l : v2r, vt2 = left ? v3l : v3r;
+  const T    p = left ? pl : pr, Hk = left ? Hl : Hr, m = left ? ml : mr, ir = left ? irl : irr;
+  T          u[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) u[k] = left ? uL[k] : uR[k];
+  const T fac = t8_div(m, SK - Ss);
+  const T Us[5] = {fac, fac * Ss, fac * vt1, fac * vt2, fac * (u[4] * ir + (Ss - vn) * (Ss + t8_div(p, m)))};
+  const T Fk[5] = {u[1], u[1] * vn + p, u[1] * vt1, u[1] * vt2, u[1] * Hk};
+#pragma unroll
+  for (int k = 0; k < 5; k++) F[k] = Fk[k] + S * (Us[k] - u[k]);
+}
+
+// face-frame HLL (hllc = false) or HLLC flux of an xyz state pair, scaled by `area`, rotated back to xyz (fast tier)
+template <class T>
+T8_DEV void hll_face(const T sL[5], const T sR[5], bool mirror, const T n[3], const T t1[3], const T t2[3], T area, T g[5],
+                     bool hllc = false) {
   T a[5], b[5], Ff[5];
   to_face_frame<T>(n, t1, t2, sL, a, false);
   to_face_frame<T>(n, t1, t2, mirror ? sL : sR, b, mirror);
-  hll_fast<T>(a, b, Ff);
+  if (hllc)
+    hllc_fast<T>(a, b, Ff);
+  else
+    hll_fast<T>(a, b, Ff);
 #pragma unroll
   for (int k = 0; k < 5; k++) Ff[k] = area * Ff[k];
   from_face_frame<T>(n, t1, t2, Ff, g);

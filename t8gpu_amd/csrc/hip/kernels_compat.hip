@@ -263,13 +263,15 @@ template <class T, class V>
 int flux_faces(int kind, int F, int ndim, const int32_t* fn, const int32_t* idx, const T* normals, const T* areas,
                V st, V fl, T* speed, void* stream) {
   if (F <= 0) return 0;
-  if (ndim < 2 || ndim > 3 || (kind != 0 && kind != 1)) return static_cast<int>(hipErrorInvalidValue);
+  if (ndim < 2 || ndim > 3 || (kind < 0 || kind > 2)) return static_cast<int>(hipErrorInvalidValue);
   const dim3  grid((F + 255) / 256), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (kind == 0)
     hipLaunchKernelGGL((k_flux_faces<T, 0>), grid, block, 0, s, F, ndim, fn, idx, normals, areas, mk<T>(st), mk<T>(fl), speed);
-  else
+  else if (kind == 1)
     hipLaunchKernelGGL((k_flux_faces<T, 1>), grid, block, 0, s, F, ndim, fn, idx, normals, areas, mk<T>(st), mk<T>(fl), speed);
+  else
+    hipLaunchKernelGGL((k_flux_faces<T, 2>), grid, block, 0, s, F, ndim, fn, idx, normals, areas, mk<T>(st), mk<T>(fl), speed);
   return launch_status();
 }
 
@@ -277,13 +279,15 @@ template <class T, class V>
 int flux_boundary(int kind, int F, int B, int ndim, const int32_t* fn, const T* normals, const T* areas, V st, V fl,
                   T* speed, void* stream) {
   if (B <= 0) return 0;
-  if (ndim < 2 || ndim > 3 || (kind != 0 && kind != 1)) return static_cast<int>(hipErrorInvalidValue);
+  if (ndim < 2 || ndim > 3 || (kind < 0 || kind > 2)) return static_cast<int>(hipErrorInvalidValue);
   const dim3  grid((B + 255) / 256), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (kind == 0)
     hipLaunchKernelGGL((k_flux_boundary<T, 0>), grid, block, 0, s, F, B, ndim, fn, normals, areas, mk<T>(st), mk<T>(fl), speed);
-  else
+  else if (kind == 1)
     hipLaunchKernelGGL((k_flux_boundary<T, 1>), grid, block, 0, s, F, B, ndim, fn, normals, areas, mk<T>(st), mk<T>(fl), speed);
+  else
+    hipLaunchKernelGGL((k_flux_boundary<T, 2>), grid, block, 0, s, F, B, ndim, fn, normals, areas, mk<T>(st), mk<T>(fl), speed);
   return launch_status();
 }
 
@@ -308,15 +312,15 @@ int rk_stage(int stage, size_t ncells, V prev, V mid, V out, V fl, const T* volu
 template <class T, class V>
 int subgrid_inner(int kind, int rank, int N, V st, V fl, const T* volumes, void* stream) {
   if (N <= 0) return 0;
-  if ((rank != 2 && rank != 3) || (kind != 0 && kind != 1)) return static_cast<int>(hipErrorInvalidValue);
+  if ((rank != 2 && rank != 3) || (kind < 0 || kind > 2)) return static_cast<int>(hipErrorInvalidValue);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3  block(64);
   const dim3  grid(rank == 3 ? N : (N + 3) / 4);
 #define T8_INNER(K, R) hipLaunchKernelGGL((k_subgrid_inner<T, K, R>), grid, block, 0, s, N, mk<T>(st), mk<T>(fl), volumes)
   if (rank == 3) {
-    if (kind == 0) T8_INNER(0, 3); else T8_INNER(1, 3);
+    if (kind == 0) T8_INNER(0, 3); else if (kind == 1) T8_INNER(1, 3); else T8_INNER(2, 3);
   } else {
-    if (kind == 0) T8_INNER(0, 2); else T8_INNER(1, 2);
+    if (kind == 0) T8_INNER(0, 2); else if (kind == 1) T8_INNER(1, 2); else T8_INNER(2, 2);
   }
 #undef T8_INNER
   return launch_status();
@@ -326,7 +330,7 @@ template <class T, bool WALL, class V>
 int subgrid_faces(int kind, int rank, int F, int count, const int32_t* fn, const int32_t* idx, const int32_t* ld,
                   const int32_t* off, const T* normals, const T* areas, V st, V fl, void* stream) {
   if (count <= 0) return 0;
-  if ((rank != 2 && rank != 3) || (kind != 0 && kind != 1)) return static_cast<int>(hipErrorInvalidValue);
+  if ((rank != 2 && rank != 3) || (kind < 0 || kind > 2)) return static_cast<int>(hipErrorInvalidValue);
   hipStream_t s   = static_cast<hipStream_t>(stream);
   const int   fpb = rank == 3 ? 4 : 16;
   const dim3  block(64), grid((count + fpb - 1) / fpb);
@@ -334,9 +338,9 @@ int subgrid_faces(int kind, int rank, int F, int count, const int32_t* fn, const
   hipLaunchKernelGGL((k_subgrid_faces<T, K, R, WALL>), grid, block, 0, s, F, count, fn, idx, ld, off, normals, areas, \
                      mk<T>(st), mk<T>(fl))
   if (rank == 3) {
-    if (kind == 0) T8_FACES(0, 3); else T8_FACES(1, 3);
+    if (kind == 0) T8_FACES(0, 3); else if (kind == 1) T8_FACES(1, 3); else T8_FACES(2, 3);
   } else {
-    if (kind == 0) T8_FACES(0, 2); else T8_FACES(1, 2);
+    if (kind == 0) T8_FACES(0, 2); else if (kind == 1) T8_FACES(1, 2); else T8_FACES(2, 2);
   }
 #undef T8_FACES
   return launch_status();

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_plain_fused(T8gpuPlainPlan P, int tile_
         sl[k] = pe[k * LE + l];
         sr[k] = pe[k * LE + r];
       }
-      hll_face<T>(sl, sr, wall, n, t1, t2, gm.w, g);
+      hll_face<T>(sl, sr, wall, n, t1, t2, gm.w, g, KIND == 2);
     }
 #pragma unroll
     for (int k = 0; k < 5; k++) ff[k * LF + f] = g[k];
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
           sl[k] = pe[k * LE + l];
           sr[k] = pe[k * LE + r];
         }
-        hll_face<T>(sl, sr, wall, n, t1, t2, gm.w, g);
+        hll_face<T>(sl, sr, wall, n, t1, t2, gm.w, g, KIND == 2);
       }
       if (SCATTER) {
         if (l < ne) {
@@ -399,7 +399,7 @@ FVars<T> fmk(const V& v) {
 template <class T, class V>
 int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count, V prev, V mid,
                       V out, const T* volume, T dt, T* speed, void* stream) {
-  if (!plan || (kind != 0 && kind != 1) || stage < 1 || stage > 3) return static_cast<int>(hipErrorInvalidValue);
+  if (!plan || kind < 0 || kind > 2 || stage < 1 || stage > 3) return static_cast<int>(hipErrorInvalidValue);
   if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > plan->ntiles) return static_cast<int>(hipErrorInvalidValue);
   if (plan->max_elems > 256 * 4) return static_cast<int>(hipErrorInvalidValue);
   if (tile_count == 0) return 0;
@@ -443,8 +443,10 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
   } while (0)
   if (kind == 0) {
     if (stage == 1) T8_FUSED(0, 1); else if (stage == 2) T8_FUSED(0, 2); else T8_FUSED(0, 3);
-  } else {
+  } else if (kind == 1) {
     if (stage == 1) T8_FUSED(1, 1); else if (stage == 2) T8_FUSED(1, 2); else T8_FUSED(1, 3);
+  } else {
+    if (stage == 1) T8_FUSED(2, 1); else if (stage == 2) T8_FUSED(2, 2); else T8_FUSED(2, 3);
   }
 #undef T8_FUSED
 #undef T8_LAUNCH

@@ -100,7 +100,7 @@ T8_DEV void cell_flux(const CellData<T, KIND>& L, const CellData<T, KIND>& R, bo
   } else {
     T n[3], t1[3], t2[3];
     axis_basis<T>(axis, positive, n, t1, t2);
-    hll_face<T>(L.v, R.v, wall, n, t1, t2, area, g);
+    hll_face<T>(L.v, R.v, wall, n, t1, t2, area, g, KIND == 2);
   }
 }
 
@@ -374,7 +374,7 @@ SVars<T> smk(const V& v) {
 template <class T, class V>
 int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, int block_begin, int block_count, V prev, V mid,
                         V out, const T* volumes, T dt, void* stream) {
-  if (!plan || (kind != 0 && kind != 1) || stage < 1 || stage > 3 || (plan->rank != 2 && plan->rank != 3))
+  if (!plan || kind < 0 || kind > 2 || stage < 1 || stage > 3 || (plan->rank != 2 && plan->rank != 3))
     return static_cast<int>(hipErrorInvalidValue);
   if (block_begin < 0 || block_count < 0 || block_begin + block_count > plan->num_elements) return static_cast<int>(hipErrorInvalidValue);
   if (block_count == 0) return 0;
@@ -392,8 +392,10 @@ int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, int b
   } while (0)
   if (kind == 0) {
     if (stage == 1) T8_SGR(0, 1); else if (stage == 2) T8_SGR(0, 2); else T8_SGR(0, 3);
-  } else {
+  } else if (kind == 1) {
     if (stage == 1) T8_SGR(1, 1); else if (stage == 2) T8_SGR(1, 2); else T8_SGR(1, 3);
+  } else {
+    if (stage == 1) T8_SGR(2, 1); else if (stage == 2) T8_SGR(2, 2); else T8_SGR(2, 3);
   }
 #undef T8_SGR
 #undef T8_SG

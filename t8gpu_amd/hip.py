@@ -6,7 +6,7 @@ import numpy as np
 
 from . import build as _build
 
-KEPES, HLL = 0, 1
+KEPES, HLL, HLLC = 0, 1, 2   # HLLC is an addition: the reference has none
 
 
 class Vars32(C.Structure):

@@ -22,7 +22,7 @@ def plain_pair(mesh, dtype, seed=1, **kw):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("kind", [hip.KEPES, hip.HLL])
+@pytest.mark.parametrize("kind", [hip.KEPES, hip.HLL, hip.HLLC])
 def test_plain_flux_kernels_vs_oracle(dtype, kind):
     mesh = SynthMesh(2, 3, 6, band=0.06, periodic=False)          # AMR + hanging faces + walls
     g, o, part = plain_pair(mesh, dtype, flux_kind=kind)

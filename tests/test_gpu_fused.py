@@ -16,7 +16,7 @@ MESHES = [dict(dim=2, base_level=5, max_level=5), dict(dim=2, base_level=3, max_
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("kind", [hip.KEPES, hip.HLL])
+@pytest.mark.parametrize("kind", [hip.KEPES, hip.HLL, hip.HLLC])
 @pytest.mark.parametrize("mesh_args", MESHES)
 def test_fused_iterate_vs_oracle(dtype, kind, mesh_args):
     mesh = SynthMesh(**mesh_args)

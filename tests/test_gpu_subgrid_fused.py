@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
-@pytest.mark.parametrize("kind", [hip.KEPES, hip.HLL])
+@pytest.mark.parametrize("kind", [hip.KEPES, hip.HLL, hip.HLLC])
 @pytest.mark.parametrize("dim,mesh_args", [(3, dict(base_level=2, max_level=2)), (3, dict(base_level=3, max_level=4, band=0.03)),
                                            (3, dict(base_level=3, max_level=4, band=0.03, periodic=False)),
                                            (2, dict(base_level=3, max_level=3)), (2, dict(base_level=3, max_level=6, band=0.03)),

@@ -22,7 +22,7 @@ def time_step(part):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("kind", [hip.KEPES, hip.HLL])
+@pytest.mark.parametrize("kind", [hip.KEPES, hip.HLL, hip.HLLC])
 def test_compat_tier_on_curved_prisms(dtype, kind):
     part = PrismHexMesh((8, 8, 4), split="checker", mapping=shell_map).partition()
     st = perturbed_state(part, 5)
@@ -37,7 +37,7 @@ def test_compat_tier_on_curved_prisms(dtype, kind):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("kind", [hip.KEPES, hip.HLL])
+@pytest.mark.parametrize("kind", [hip.KEPES, hip.HLL, hip.HLLC])
 @pytest.mark.parametrize("variant", list(VARIANTS))
 @pytest.mark.parametrize("mesh", [dict(n=(8, 8, 8), split=0.5, mapping=shell_map), dict(n=(16, 8, 4), split="all", mapping=wavy_map, periodic=True)])
 def test_fused_tier_on_curved_prisms(dtype, kind, variant, mesh):

@@ -91,3 +91,57 @@ def test_rk3_truncated_coefficients_quirk_q1():
     assert out[0, 0] == 0.33333333333333 * 3.0 + 0.66666666666666 * 6.0 + 0.66666666666666 * 0.5 / 2.0 * 9.0
     assert out[0, 0] != 3.0 / 3 + 6.0 * 2 / 3 + (2.0 / 3) * 0.5 / 2.0 * 9.0
     assert (flux == 0).all()                      # every stage zeroes the flux planes
+
+
+# ---- HLLC (an addition: the reference has no HLLC) pinned by its defining properties -------------------
+HLLC = 2
+
+
+def _state(rho, v, p):
+    v = np.asarray(v, float)
+    return np.array([rho, rho * v[0], rho * v[1], rho * v[2], p / 0.4 + 0.5 * rho * (v ** 2).sum()])
+
+
+def _physical_flux(u):
+    rho, v = u[0], u[1:4] / u[0]
+    p = 0.4 * (u[4] - 0.5 * rho * (v ** 2).sum())
+    return np.array([u[1], u[1] * v[0] + p, u[1] * v[1], u[1] * v[2], v[0] * (u[4] + p)])
+
+
+def test_hllc_is_consistent_and_upwinds():
+    rng = np.random.default_rng(7)
+    for _ in range(200):
+        u = _state(rng.uniform(0.5, 2), rng.uniform(-1, 1, 3), rng.uniform(0.5, 3))
+        F = O.face_frame_flux(HLLC, u[None], u[None])[0]
+        assert np.allclose(F, _physical_flux(u), rtol=1e-13, atol=1e-13)
+    # supersonic to the right / left: the flux of the upwind state, exactly
+    L, R = _state(1.0, [5.0, 0.3, -0.2], 1.0), _state(0.7, [4.5, 0.1, 0.0], 0.8)
+    assert np.allclose(O.face_frame_flux(HLLC, L[None], R[None])[0], _physical_flux(L), rtol=1e-14)
+    L, R = _state(1.0, [-5.0, 0.3, -0.2], 1.0), _state(0.7, [-4.5, 0.1, 0.0], 0.8)
+    assert np.allclose(O.face_frame_flux(HLLC, L[None], R[None])[0], _physical_flux(R), rtol=1e-14)
+
+
+def test_hllc_keeps_contact_discontinuities_that_hll_smears():
+    # stationary contact: density and tangential velocity jump, u = 0, equal pressure -> only the pressure term
+    L, R = _state(2.0, [0.0, 0.7, -0.3], 1.5), _state(0.5, [0.0, -0.2, 0.4], 1.5)
+    F = O.face_frame_flux(HLLC, L[None], R[None])[0]
+    assert np.allclose(F, [0, 1.5, 0, 0, 0], atol=1e-15)
+    assert abs(O.face_frame_flux(1, L[None], R[None])[0][0]) > 0.1          # HLL leaks mass through it
+    # contact moving to the right with speed 0.3: everything is carried from the left state
+    L, R = _state(2.0, [0.3, 0.7, -0.3], 1.5), _state(0.5, [0.3, -0.2, 0.4], 1.5)
+    assert np.allclose(O.face_frame_flux(HLLC, L[None], R[None])[0], _physical_flux(L), rtol=1e-14, atol=1e-15)
+    L, R = _state(2.0, [-0.3, 0.7, -0.3], 1.5), _state(0.5, [-0.3, -0.2, 0.4], 1.5)
+    assert np.allclose(O.face_frame_flux(HLLC, L[None], R[None])[0], _physical_flux(R), rtol=1e-14, atol=1e-15)
+
+
+def test_hllc_is_symmetric_under_reflection_and_gives_a_pure_pressure_wall_flux():
+    rng = np.random.default_rng(8)
+    flip = np.array([1, -1, 1, 1, 1.0])
+    for _ in range(100):
+        L = _state(rng.uniform(0.5, 2), rng.uniform(-1, 1, 3), rng.uniform(0.5, 3))
+        R = _state(rng.uniform(0.5, 2), rng.uniform(-1, 1, 3), rng.uniform(0.5, 3))
+        F = O.face_frame_flux(HLLC, L[None], R[None])[0]
+        G = O.face_frame_flux(HLLC, (R * flip)[None], (L * flip)[None])[0]   # mirror image of the same problem
+        assert np.allclose(G, -F * flip, rtol=1e-12, atol=1e-13)
+        W = O.face_frame_flux(HLLC, L[None], (L * flip)[None])[0]            # reflective wall
+        assert abs(W[0]) < 1e-14 and abs(W[4]) < 1e-13 and abs(W[2]) < 1e-14 and abs(W[3]) < 1e-14
