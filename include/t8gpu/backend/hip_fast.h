@@ -12,11 +12,13 @@
 #ifndef T8GPU_HIP_BACKEND_HIP_FAST_H
 #define T8GPU_HIP_BACKEND_HIP_FAST_H
 
+#include <t8gpu/memory/subgrid_memory_manager.h>
 #include <t8gpu/mesh/mesh_manager.h>
 #include <t8gpu_hip.h>
 #include <t8gpu_host.h>
 
 #include <type_traits>
+#include <algorithm>
 #include <vector>
 
 namespace t8gpu::hip {
@@ -178,6 +180,80 @@ namespace t8gpu::hip {
     using ft = typename variable_traits<VariableType>::float_type;
     T8GPU_DISPATCH(ft, t8gpu_hip_plain_stepper_iterate, plan.stepper(), flux_kind, mesh.planes_base(), mesh.plane_stride(),
                    static_cast<int>(prev), static_cast<int>(next), delta_t, speed, stream);
+  }
+  // ---- Subgrid<4,4> / Subgrid<4,4,4> -------------------------------------------------------------------------
+  template<typename VariableType, typename SubgridType>
+  auto to_vars(SubgridMemoryAccessorOwn<VariableType, SubgridType> acc) {
+    using ft = typename variable_traits<VariableType>::float_type;
+    static_assert(variable_traits<VariableType>::nb_variables == 5, "the Euler kernels expect Rho, Rho_v1..3, Rho_e");
+    vars_t<ft> v;
+    for (int k = 0; k < 5; k++) v.p[k] = acc.data(static_cast<typename variable_traits<VariableType>::index_type>(k));
+    return v;
+  }
+
+  /// One rank's Subgrid mesh in the reference's array formats (subgrid_mesh_manager.h:29-216); normals have
+  /// `rank` components, level differences are level(right) - level(left) <= 0.
+  struct HostSubgridMeshArrays {
+    int32_t num_local_elements = 0, num_ghost_elements = 0, num_local_faces = 0, num_local_boundary_faces = 0, rank = 3;
+    std::vector<int32_t> face_neighbors, face_level_difference, face_neighbor_offset;
+    std::vector<double>  face_normals, face_surfaces, volumes;
+  };
+
+  /// Device copy of the joined per-block face records (t8gpu_plan_subgrid_create + _records) for the fused
+  /// block kernel: rebuilt where compute_connectivity_information runs (subgrid_mesh_manager.inl:560-961).
+  template<typename ft>
+  class SubgridFusedPlan {
+   public:
+    explicit SubgridFusedPlan(HostSubgridMeshArrays const& m) {
+      void* h = t8gpu_plan_subgrid_create(m.num_local_elements, m.num_local_faces, m.num_local_boundary_faces, m.rank,
+                                          m.face_neighbors.data(), m.face_level_difference.data(), m.face_neighbor_offset.data(),
+                                          m.face_normals.data());
+      if (!h) T8GPU_ABORT("t8gpu_plan_subgrid_create failed (axis-aligned unit normals required, as in the reference)");
+      int64_t sz[4];
+      t8gpu_plan_subgrid_sizes(h, sz);
+      std::vector<int32_t> block_rec(16 * static_cast<size_t>(std::max<int32_t>(1, m.num_local_elements))),
+          bf_rec(4 * static_cast<size_t>(std::max<int64_t>(1, sz[0])));
+      t8gpu_plan_subgrid_records(h, m.face_surfaces.data(), static_cast<int>(sizeof(ft)), block_rec.data(), bf_rec.data());
+      t8gpu_plan_subgrid_destroy(h);
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_block_rec, sizeof(int32_t) * block_rec.size()));
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_bf_rec, sizeof(int32_t) * bf_rec.size()));
+      T8GPU_CUDA_CHECK_ERROR(hipMemcpy(m_block_rec, block_rec.data(), sizeof(int32_t) * block_rec.size(), hipMemcpyHostToDevice));
+      T8GPU_CUDA_CHECK_ERROR(hipMemcpy(m_bf_rec, bf_rec.data(), sizeof(int32_t) * bf_rec.size(), hipMemcpyHostToDevice));
+      m_plan.block_rec = m_block_rec;
+      m_plan.bf_rec    = m_bf_rec;
+      m_plan.num_elements = m.num_local_elements;
+      m_plan.rank         = m.rank;
+      m_plan.max_faces_per_block = static_cast<int32_t>(sz[1]);
+      m_plan.n_interior_blocks   = static_cast<int32_t>(sz[3]);
+    }
+    ~SubgridFusedPlan() {
+      (void)hipFree(m_block_rec);
+      (void)hipFree(m_bf_rec);
+    }
+    SubgridFusedPlan(SubgridFusedPlan const&)            = delete;
+    SubgridFusedPlan& operator=(SubgridFusedPlan const&) = delete;
+    [[nodiscard]] T8gpuSubgridPlan const& view() const { return m_plan; }
+
+   private:
+    T8gpuSubgridPlan m_plan{};
+    int32_t *        m_block_rec = nullptr, *m_bf_rec = nullptr;
+  };
+
+  /// SubgridCompressibleEulerSolver::iterate (examples/subgrid/solver.inl:152-266) after its std::swap: three fused
+  /// stage launches instead of 3 x (inner + boundary + outer flux kernels, sync + barrier, RK kernel).
+  template<typename VariableType, typename StepType, typename SubgridType>
+  void iterate_fused(SubgridMemoryManager<VariableType, StepType, SubgridType>&                         mem,
+                     SubgridFusedPlan<typename variable_traits<VariableType>::float_type> const&        plan,
+                     typename step_traits<StepType>::index_type prev, typename step_traits<StepType>::index_type next,
+                     typename variable_traits<VariableType>::float_type delta_t, int flux_kind = T8GPU_FLUX_KEPES,
+                     hipStream_t stream = nullptr) {
+    using ft   = typename variable_traits<VariableType>::float_type;
+    using step = typename step_traits<StepType>::index_type;
+    const step src[3] = {prev, static_cast<step>(1), static_cast<step>(2)}, dst[3] = {static_cast<step>(1), static_cast<step>(2), next};
+    for (int k = 0; k < 3; k++)
+      T8GPU_DISPATCH(ft, t8gpu_hip_subgrid_fused_stage, flux_kind, k + 1, &plan.view(), 0, plan.view().num_elements,
+                     to_vars(mem.get_own_variables(prev)), to_vars(mem.get_own_variables(src[k])), to_vars(mem.get_own_variables(dst[k])),
+                     mem.get_own_volume(), delta_t, stream);
   }
 #undef T8GPU_DISPATCH
 

@@ -6,6 +6,7 @@
 #include <t8gpu/memory/subgrid_memory_manager.h>
 #include <t8gpu/mesh/subgrid_mesh_manager.h>
 #include <t8gpu/timestepping/ssp_runge_kutta.h>
+#include <t8gpu/backend/hip_fast.h>
 
 #include <cmath>
 #include <cstdio>
@@ -70,6 +71,81 @@ int main() {
   if (std::fabs(got - want) > 1e-6 || !zeroed) {
     std::printf("subgrid_api FAILED: got %g want %g zeroed %d\n", double(got), double(want), int(zeroed));
     return 1;
+  }
+  // ---- the fused block kernel through its C++ face, against the reference-dataflow kernels of the C-ABI ------------
+  {
+    void*   mesh = t8gpu_synth_mesh_create(3, 2, 3, 0.12, 1.0, 0);     // 3D, levels 2-3, walls
+    void*   part = t8gpu_synth_part_create(mesh, 0, 1, 1, 3);
+    int64_t cnt[8];
+    t8gpu_synth_part_counts(part, cnt);
+    const int N = static_cast<int>(cnt[0]), F = static_cast<int>(cnt[2]), B = static_cast<int>(cnt[3]);
+    hip::HostSubgridMeshArrays m;
+    m.num_local_elements = N; m.num_ghost_elements = static_cast<int32_t>(cnt[1]); m.num_local_faces = F; m.num_local_boundary_faces = B;
+    m.rank = 3;
+    m.face_neighbors.resize(2 * F + B); m.face_level_difference.resize(F); m.face_neighbor_offset.resize(3 * F);
+    m.face_normals.resize(3 * (F + B)); m.face_surfaces.resize(F + B); m.volumes.resize(N);
+    t8gpu_synth_part_connectivity(part, m.face_neighbors.data(), m.face_normals.data(), m.face_surfaces.data(),
+                                  m.face_level_difference.data(), m.face_neighbor_offset.data());
+    t8gpu_synth_part_elements(part, nullptr, m.volumes.data(), nullptr);
+    std::vector<double> ic(5 * static_cast<size_t>(N) * 64);
+    t8gpu_synth_part_kh_ic(part, 4, ic.data(), static_cast<size_t>(N) * 64);
+    auto make = [&](SubgridMemoryManager<VariableList, StepList, Grid3>& mm) {
+      mm.set_volume(std::vector<float_type>(m.volumes.begin(), m.volumes.end()));
+      for (int s = 0; s < nb_steps; s++)
+        for (int v = 0; v < 5; v++) mm.set_variable(static_cast<StepList>(s), static_cast<VariableList>(v), std::vector<float_type>(static_cast<size_t>(N) * 64, 0));
+      for (int v = 0; v < 5; v++)
+        mm.set_variable(Step0, static_cast<VariableList>(v),
+                        std::vector<float_type>(ic.begin() + static_cast<size_t>(v) * N * 64, ic.begin() + static_cast<size_t>(v + 1) * N * 64));
+    };
+    SubgridMemoryManager<VariableList, StepList, Grid3> a(N), b(N);
+    make(a);
+    make(b);
+    hip::SubgridFusedPlan<float_type> plan(m);
+    // device copies of the connectivity for the reference-dataflow kernels
+    auto up = [](auto const& v) {
+      using T = typename std::decay_t<decltype(v)>::value_type;
+      T* d = nullptr;
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&d, sizeof(T) * (v.empty() ? 1 : v.size())));
+      if (!v.empty()) T8GPU_CUDA_CHECK_ERROR(hipMemcpy(d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+      return d;
+    };
+    int32_t *fn = up(m.face_neighbors), *ld = up(m.face_level_difference), *off = up(m.face_neighbor_offset);
+    float_type *nrm = up(std::vector<float_type>(m.face_normals.begin(), m.face_normals.end())),
+               *ars = up(std::vector<float_type>(m.face_surfaces.begin(), m.face_surfaces.end()));
+    const float_type dts = float_type(0.1 * std::pow(0.5, t8gpu_synth_mesh_finest_level(mesh) + 2));
+    StepList next = Step0, prev = Step3;
+    for (int it = 0; it < 3; it++) {
+      std::swap(next, prev);
+      hip::iterate_fused(a, plan, prev, next, dts);
+      const StepList src[3] = {prev, Step1, Step2}, dst[3] = {Step1, Step2, next};
+      for (int k = 0; k < 3; k++) {   // the reference's launch sequence (solver.inl:166-195) on the C-ABI
+        auto st = hip::to_vars(b.get_own_variables(src[k])), fl = hip::to_vars(b.get_own_variables(Fluxes));
+        T8GPU_HIP_CHECK_ABI(t8gpu_hip_subgrid_inner_f32(T8GPU_FLUX_KEPES, 3, N, st, fl, b.get_own_volume(), nullptr));
+        T8GPU_HIP_CHECK_ABI(t8gpu_hip_subgrid_boundary_f32(T8GPU_FLUX_KEPES, 3, F, B, fn, nrm, ars, st, fl, nullptr));
+        T8GPU_HIP_CHECK_ABI(t8gpu_hip_subgrid_outer_f32(T8GPU_FLUX_KEPES, 3, F, fn, nullptr, ld, off, nrm, ars, st, fl, nullptr));
+        T8GPU_HIP_CHECK_ABI(t8gpu_hip_subgrid_rk3_stage_f32(k + 1, 3, N, hip::to_vars(b.get_own_variables(prev)), st,
+                                                            hip::to_vars(b.get_own_variables(dst[k])), fl, b.get_own_volume(), dts, nullptr));
+      }
+    }
+    T8GPU_CUDA_CHECK_ERROR(hipDeviceSynchronize());
+    double worst = 0, scale = 0;
+    for (int v = 0; v < 5; v++) {
+      std::vector<float_type> ha(static_cast<size_t>(N) * 64), hb(ha.size());
+      T8GPU_CUDA_CHECK_ERROR(hipMemcpy(ha.data(), static_cast<float_type*>(a.get_own_variable(next, static_cast<VariableList>(v))), sizeof(float_type) * ha.size(), hipMemcpyDeviceToHost));
+      T8GPU_CUDA_CHECK_ERROR(hipMemcpy(hb.data(), static_cast<float_type*>(b.get_own_variable(next, static_cast<VariableList>(v))), sizeof(float_type) * hb.size(), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < ha.size(); i++) {
+        worst = std::max(worst, std::fabs(double(ha[i]) - double(hb[i])));
+        scale = std::max(scale, std::fabs(double(hb[i])));
+      }
+    }
+    for (void* p : {static_cast<void*>(fn), static_cast<void*>(ld), static_cast<void*>(off), static_cast<void*>(nrm), static_cast<void*>(ars)}) (void)hipFree(p);
+    t8gpu_synth_part_destroy(part);
+    t8gpu_synth_mesh_destroy(mesh);
+    if (!(worst < 1e-4 * scale) || !(scale > 0)) {
+      std::printf("subgrid_api FAILED: fused vs reference-dataflow kernels differ by %g (scale %g)\n", worst, scale);
+      return 1;
+    }
+    std::printf("fused block kernel vs reference-dataflow kernels over 3 steps: max |diff| = %.3g (scale %.3g)\n", worst, scale);
   }
   std::printf("subgrid_api OK\n");
   return 0;
