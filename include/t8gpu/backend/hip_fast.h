@@ -181,6 +181,45 @@ namespace t8gpu::hip {
     T8GPU_DISPATCH(ft, t8gpu_hip_plain_stepper_iterate, plan.stepper(), flux_kind, mesh.planes_base(), mesh.plane_stride(),
                    static_cast<int>(prev), static_cast<int>(next), delta_t, speed, stream);
   }
+  // ---- the two scalar reductions of the reference solver, on the device ----------------------------
+  /// Workspace + result slot for compute_integral / max_speed (allocate once, reuse).
+  class Reducer {
+   public:
+    Reducer() {
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_work, t8gpu_hip_reduce_workspace_bytes()));
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_result, sizeof(double)));
+    }
+    ~Reducer() {
+      (void)hipFree(m_work);
+      (void)hipFree(m_result);
+    }
+    Reducer(Reducer const&)            = delete;
+    Reducer& operator=(Reducer const&) = delete;
+    /// CompressibleEulerSolver::compute_integral (solver.cu:190-211), this rank's part (the caller all-reduces)
+    template<typename ft>
+    [[nodiscard]] double integral(size_t num_cells, ft const* variable, ft const* volume, int cells_per_element = 1,
+                                  hipStream_t stream = nullptr) {
+      T8GPU_DISPATCH(ft, t8gpu_hip_integral, num_cells, cells_per_element, variable, volume, m_work, m_result, stream);
+      return fetch(stream);
+    }
+    /// the thrust::reduce(maximum) of compute_timestep (solver.cu:213-217); dt = cfl * 0.5^max_level / this
+    template<typename ft>
+    [[nodiscard]] double max_speed(size_t n, ft const* speed_estimates, hipStream_t stream = nullptr) {
+      T8GPU_DISPATCH(ft, t8gpu_hip_max_speed, n, speed_estimates, m_work, m_result, stream);
+      return fetch(stream);
+    }
+
+   private:
+    void*   m_work   = nullptr;
+    double* m_result = nullptr;
+    double  fetch(hipStream_t stream) {
+      double h = 0;
+      T8GPU_CUDA_CHECK_ERROR(hipMemcpyAsync(&h, m_result, sizeof(double), hipMemcpyDeviceToHost, stream));
+      T8GPU_CUDA_CHECK_ERROR(hipStreamSynchronize(stream));
+      return h;
+    }
+  };
+
   // ---- Subgrid<4,4> / Subgrid<4,4,4> -------------------------------------------------------------------------
   template<typename VariableType, typename SubgridType>
   auto to_vars(SubgridMemoryAccessorOwn<VariableType, SubgridType> acc) {

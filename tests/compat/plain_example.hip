@@ -188,6 +188,8 @@ int main(int argc, char** argv) {
 
   Solver a(m, ic), b(m, ic), c(m, ic);
   hip::PlainFusedPlan<float_type> plan(m);
+  hip::Reducer                    reduce;
+  const double mass0 = reduce.integral<float_type>(m.num_local_elements, c.mesh.get_own_variable(c.next, Rho), c.mesh.get_own_volume());
   T8GPU_TIMER_START(three_variants);
   for (int i = 0; i < steps; i++) {
     a.iterate_user_kernels(delta_t);
@@ -196,6 +198,13 @@ int main(int argc, char** argv) {
   }
   T8GPU_CUDA_CHECK_ERROR(hipDeviceSynchronize());
   T8GPU_TIMER_STOP(three_variants);
+  // compute_integral / compute_timestep of the reference solver (solver.cu:190-229) on the device
+  const double mass1 = reduce.integral<float_type>(m.num_local_elements, c.mesh.get_own_variable(c.next, Rho), c.mesh.get_own_volume());
+  const double vmax  = reduce.max_speed<float_type>(m.num_local_faces + m.num_local_boundary_faces, c.speed);
+  if (!(std::fabs(mass1 - mass0) <= (sizeof(float_type) == 8 ? 1e-12 : 1e-5) * std::fabs(mass0)) || !(vmax > 0.5 && vmax < 10.0)) {
+    std::fprintf(stderr, "mass %.17g -> %.17g, max speed %g\n", mass0, mass1, vmax);
+    return 5;
+  }
 
   std::FILE* f = std::fopen(argv[7], "wb");
   if (!f) return 3;
