@@ -19,6 +19,7 @@
 
 #include <type_traits>
 #include <algorithm>
+#include <array>
 #include <vector>
 
 namespace t8gpu::hip {
@@ -105,11 +106,39 @@ namespace t8gpu::hip {
     return m;
   }
 
+  /// One RCCL communicator per process (one rank per GPU). Rank 0 makes the id, the application distributes the 128
+  /// bytes (MPI_Bcast in the reference's setting), every rank constructs. Stands where the reference exchanges CUDA-IPC
+  /// handles with MPI_Allgather (shared_device_vector.inl:21-22,179-185).
+  class Communicator {
+   public:
+    [[nodiscard]] static std::array<char, 128> unique_id() {
+      std::array<char, 128> id{};
+      T8GPU_HIP_CHECK_ABI(t8gpu_hip_comm_unique_id(id.data()));
+      return id;
+    }
+    Communicator(std::array<char, 128> const& id, int rank, int nranks) : m_rank{rank}, m_size{nranks} {
+      T8GPU_HIP_CHECK_ABI(t8gpu_hip_comm_create(id.data(), rank, nranks, &m_comm));
+    }
+    ~Communicator() { (void)t8gpu_hip_comm_destroy(m_comm); }
+    Communicator(Communicator const&)            = delete;
+    Communicator& operator=(Communicator const&) = delete;
+    [[nodiscard]] void* handle() const { return m_comm; }
+    [[nodiscard]] int   rank() const { return m_rank; }
+    [[nodiscard]] int   size() const { return m_size; }
+
+   private:
+    void* m_comm = nullptr;
+    int   m_rank, m_size;
+  };
+
   /// Device copy of the tile plan (t8gpu_plan_plain_create) + the native step driver.
   template<typename ft>
   class PlainFusedPlan {
    public:
-    explicit PlainFusedPlan(HostMeshArrays const& m, int ndim = 3, int tmax = 256, int fcap = 512) {
+    /// Single rank: halo = comm = nullptr. Several ranks: the rank's halo lists (host_mesh_arrays_from_query fills
+    /// them) and the communicator; iterate_fused then exchanges the ghost layer per stage (csrc/hip/stepper.hip).
+    explicit PlainFusedPlan(HostMeshArrays const& m, int ndim = 3, int tmax = 256, int fcap = 512, HostHaloArrays const* halo = nullptr,
+                            Communicator const* comm = nullptr) {
       void* h = t8gpu_plan_plain_create(m.num_local_elements, m.num_ghost_elements, m.num_local_faces,
                                         m.num_local_boundary_faces, ndim, m.face_neighbors.data(), m.face_normals.data(),
                                         m.face_surfaces.data(), tmax, fcap);
@@ -144,7 +173,24 @@ namespace t8gpu::hip {
       m_plan.max_faces = static_cast<int32_t>(sz[6]); m_plan.ell_width = static_cast<int32_t>(w);
       m_plan.n_geo = static_cast<int32_t>(ngeo); m_plan.max_slots = static_cast<int32_t>(sz[12]);
       m_plan.n_deep_tiles = static_cast<int32_t>(sz[13]); m_plan.reserved = 0;
-      T8GPU_HIP_CHECK_ABI(t8gpu_hip_plain_stepper_create(&m_plan, nullptr, &m_stepper));
+      T8gpuHalo  hl{};
+      const bool multi = halo && comm && !halo->peers.empty();
+      if (multi) {
+        m_halo             = *halo;   // host index arrays must outlive the stepper
+        hl.num_elements     = m.num_local_elements;
+        hl.num_ghosts       = m.num_ghost_elements;
+        hl.n_peers          = static_cast<int32_t>(m_halo.peers.size());
+        hl.n_send           = static_cast<int32_t>(m_halo.send_idx.size());
+        hl.cells_per_element = 1;
+        hl.peers            = m_halo.peers.data();
+        hl.send_off         = m_halo.send_off.data();
+        hl.recv_off         = m_halo.recv_off.data();
+        hl.send_idx         = up(m_halo.send_idx);
+        hl.sendbuf          = up(std::vector<ft>(5 * m_halo.send_idx.size() + 1));
+        hl.recvbuf          = up(std::vector<ft>(5 * static_cast<size_t>(m.num_ghost_elements) + 1));
+        hl.comm             = comm->handle();
+      }
+      T8GPU_HIP_CHECK_ABI(t8gpu_hip_plain_stepper_create(&m_plan, multi ? &hl : nullptr, &m_stepper));
     }
     ~PlainFusedPlan() {
       t8gpu_hip_plain_stepper_destroy(m_stepper);
@@ -157,6 +203,7 @@ namespace t8gpu::hip {
 
    private:
     T8gpuPlainPlan     m_plan{};
+    HostHaloArrays     m_halo;
     void*              m_stepper = nullptr;
     std::vector<void*> m_allocs;
     template<typename T>
@@ -176,10 +223,11 @@ namespace t8gpu::hip {
                      typename step_traits<StepType>::index_type prev, typename step_traits<StepType>::index_type next,
                      typename variable_traits<VariableType>::float_type delta_t,
                      typename variable_traits<VariableType>::float_type* speed, int flux_kind = T8GPU_FLUX_KEPES,
-                     hipStream_t stream = nullptr) {
+                     hipStream_t stream = nullptr, int n_steps = 1) {
     using ft = typename variable_traits<VariableType>::float_type;
-    T8GPU_DISPATCH(ft, t8gpu_hip_plain_stepper_iterate, plan.stepper(), flux_kind, mesh.planes_base(), mesh.plane_stride(),
-                   static_cast<int>(prev), static_cast<int>(next), delta_t, speed, stream);
+    // n_steps > 1: prev / next are the roles of the FIRST step and alternate (after an odd count the caller swaps once more)
+    T8GPU_DISPATCH(ft, t8gpu_hip_plain_stepper_iterate_steps, plan.stepper(), flux_kind, mesh.planes_base(), mesh.plane_stride(),
+                   static_cast<int>(prev), static_cast<int>(next), delta_t, speed, n_steps, stream);
   }
   // ---- the two scalar reductions of the reference solver, on the device ----------------------------
   /// Workspace + result slot for compute_integral / max_speed (allocate once, reuse).

@@ -149,6 +149,13 @@ struct Solver {
     hip::iterate_fused(mesh, plan, prev, next, delta_t, speed);
   }
 
+  // C': the whole run in one call of the driver (prev / next alternate inside; an odd count leaves them swapped)
+  void iterate_fused_steps(hip::PlainFusedPlan<float_type> const& plan, float_type delta_t, int n) {
+    std::swap(next, prev);
+    hip::iterate_fused(mesh, plan, prev, next, delta_t, speed, T8GPU_FLUX_KEPES, nullptr, n);
+    if (n % 2 == 0) std::swap(next, prev);
+  }
+
   std::vector<float_type> download() {
     const size_t            n = mesh.get_num_local_elements();
     std::vector<float_type> out(5 * n);
@@ -206,6 +213,20 @@ int main(int argc, char** argv) {
     return 5;
   }
 
+  // the multi-rank constructor path with a one-rank communicator and no peers, and all steps in one driver call:
+  // must reproduce variant C bit for bit
+  {
+    hip::Communicator                comm(hip::Communicator::unique_id(), 0, 1);
+    hip::HostHaloArrays              no_peers;
+    hip::PlainFusedPlan<float_type>  plan1(m, 3, 256, 512, &no_peers, &comm);
+    Solver                           d(m, ic);
+    d.iterate_fused_steps(plan1, delta_t, steps);
+    T8GPU_CUDA_CHECK_ERROR(hipDeviceSynchronize());
+    if (d.download() != c.download()) {
+      std::fprintf(stderr, "iterate_fused with n_steps = %d differs from %d single-step calls\n", steps, steps);
+      return 6;
+    }
+  }
   std::FILE* f = std::fopen(argv[7], "wb");
   if (!f) return 3;
   const int32_t header[3] = {m.num_local_elements, static_cast<int32_t>(sizeof(float_type)), steps};
