@@ -14,6 +14,7 @@
 
 #include <t8gpu/memory/subgrid_memory_manager.h>
 #include <t8gpu/mesh/mesh_manager.h>
+#include <t8gpu/mesh/subgrid_mesh_manager.h>
 #include <t8gpu_hip.h>
 #include <t8gpu_host.h>
 
@@ -278,13 +279,7 @@ namespace t8gpu::hip {
     return v;
   }
 
-  /// One rank's Subgrid mesh in the reference's array formats (subgrid_mesh_manager.h:29-216); normals have
-  /// `rank` components, level differences are level(right) - level(left) <= 0.
-  struct HostSubgridMeshArrays {
-    int32_t num_local_elements = 0, num_ghost_elements = 0, num_local_faces = 0, num_local_boundary_faces = 0, rank = 3;
-    std::vector<int32_t> face_neighbors, face_level_difference, face_neighbor_offset;
-    std::vector<double>  face_normals, face_surfaces, volumes;
-  };
+  using t8gpu::HostSubgridMeshArrays;
 
   /// Device copy of the joined per-block face records (t8gpu_plan_subgrid_create + _records) for the fused
   /// block kernel: rebuilt where compute_connectivity_information runs (subgrid_mesh_manager.inl:560-961).

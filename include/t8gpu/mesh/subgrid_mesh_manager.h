@@ -4,12 +4,18 @@
 // Subgrid mesh with the getters of the reference (t8gpu/mesh/subgrid_mesh_manager.h:29-216): the plain
 // arrays plus face_level_difference[F] (level(right) - level(left) <= 0) and face_neighbor_offset[rank*F]
 // (anchor inside the right block; subgrid_mesh_manager.inl:587-680). Normals have SubgridType::rank
-// components. The t8code-bound SubgridMeshManager is out of scope this round.
+// components. SyntheticSubgridMeshManager<V, S, Subgrid>: SubgridMemoryManager + those arrays from host vectors, with
+// the part of SubgridMeshManager's interface the hot path and the output step use (subgrid_mesh_manager.h:288-462):
+// get_connectivity_information(), get_num_local_{elements,faces,boundary_faces}(), save_variable_to_vtk(),
+// save_mesh_to_vtk(). The t8code-bound constructor / adapt / partition need t8code.
 #ifndef T8GPU_HIP_MESH_SUBGRID_MESH_MANAGER_H
 #define T8GPU_HIP_MESH_SUBGRID_MESH_MANAGER_H
 
 #include <t8gpu/memory/subgrid_memory_manager.h>
 #include <t8gpu/mesh/mesh_manager.h>
+
+#include <string>
+#include <vector>
 
 namespace t8gpu {
 
@@ -66,6 +72,116 @@ namespace t8gpu {
       std::array<float_type, dim> n{};
       for (int k = 0; k < dim; k++) n[k] = m_face_normals[dim * slot + k];
       return n;
+    }
+  };
+
+  /// One rank's Subgrid mesh in the reference's array formats (subgrid_mesh_manager.h:29-216); normals have
+  /// `rank` components, level differences are level(right) - level(left) <= 0.
+  struct HostSubgridMeshArrays {
+    int32_t num_local_elements = 0, num_ghost_elements = 0, num_local_faces = 0, num_local_boundary_faces = 0, rank = 3;
+    int     mpirank = 0;
+    std::vector<int32_t> face_neighbors, face_level_difference, face_neighbor_offset;
+    std::vector<double>  face_normals, face_surfaces, volumes;
+    // only needed by the VTK members: geometry of the owned blocks on the unit domain
+    int64_t              first_global_element = 0;
+    std::vector<double>  centres;   // [N][3]
+    std::vector<int32_t> levels;    // [N]
+  };
+
+  template<typename VariableType, typename StepType, typename SubgridType>
+  class SyntheticSubgridMeshManager : public SubgridMemoryManager<VariableType, StepType, SubgridType> {
+   public:
+    using float_type          = typename variable_traits<VariableType>::float_type;
+    using variable_index_type = typename variable_traits<VariableType>::index_type;
+    using step_index_type     = typename step_traits<StepType>::index_type;
+
+    explicit SyntheticSubgridMeshManager(HostSubgridMeshArrays const& m, sc_MPI_Comm comm = sc_MPI_COMM_WORLD)
+        : SubgridMemoryManager<VariableType, StepType, SubgridType>(static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements, comm),
+          m_host{m} {
+      const size_t tot = static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements;
+      std::vector<int>         ranks(tot, m.mpirank);
+      std::vector<t8_locidx_t> indices(tot);
+      for (size_t i = 0; i < tot; i++) indices[i] = static_cast<t8_locidx_t>(i);
+      upload(m_ranks, ranks);
+      upload(m_indices, indices);
+      upload(m_face_neighbors, m.face_neighbors);
+      upload(m_level_difference, m.face_level_difference);
+      upload(m_neighbor_offset, m.face_neighbor_offset);
+      upload(m_face_normals, std::vector<float_type>(m.face_normals.begin(), m.face_normals.end()));
+      upload(m_face_surfaces, std::vector<float_type>(m.face_surfaces.begin(), m.face_surfaces.end()));
+      std::vector<float_type> vol(m.volumes.begin(), m.volumes.end());
+      vol.resize(tot, float_type(1));
+      this->set_volume(vol);
+    }
+    ~SyntheticSubgridMeshManager() {
+      for (void* p : {static_cast<void*>(m_ranks), static_cast<void*>(m_indices), static_cast<void*>(m_face_neighbors),
+                      static_cast<void*>(m_level_difference), static_cast<void*>(m_neighbor_offset), static_cast<void*>(m_face_normals),
+                      static_cast<void*>(m_face_surfaces), static_cast<void*>(m_scratch), static_cast<void*>(m_scratch64)})
+        (void)hipFree(p);
+    }
+    SyntheticSubgridMeshManager(SyntheticSubgridMeshManager const&)            = delete;
+    SyntheticSubgridMeshManager& operator=(SyntheticSubgridMeshManager const&) = delete;
+
+    [[nodiscard]] SubgridMeshConnectivityAccessor<float_type, SubgridType> get_connectivity_information() const {
+      return {m_ranks, m_indices, m_face_neighbors, m_level_difference, m_neighbor_offset, m_face_normals, m_face_surfaces,
+              m_host.num_local_faces, m_host.num_local_boundary_faces};
+    }
+    [[nodiscard]] t8_locidx_t get_num_local_elements() const { return m_host.num_local_elements; }
+    [[nodiscard]] t8_locidx_t get_num_ghost_elements() const { return m_host.num_ghost_elements; }
+    [[nodiscard]] t8_locidx_t get_num_local_faces() const { return m_host.num_local_faces; }
+    [[nodiscard]] t8_locidx_t get_num_local_boundary_faces() const { return m_host.num_local_boundary_faces; }
+    [[nodiscard]] HostSubgridMeshArrays const& host_arrays() const { return m_host; }
+
+    /// subgrid_mesh_manager.inl:1051-1138: the variable on the forest refined uniformly twice (z-order), field "variables"
+    void save_variable_to_vtk(step_index_type step, variable_index_type variable, std::string const& prefix) {
+      const size_t n = static_cast<size_t>(m_host.num_local_elements) * SubgridType::size;
+      if (!m_scratch) T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_scratch, sizeof(float_type) * (n ? n : 1)));
+      if (!m_scratch64) T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_scratch64, sizeof(double) * (n ? n : 1)));
+      float_type const* src = static_cast<float_type const*>(this->get_own_variable(step, variable));
+      if constexpr (std::is_same_v<float_type, double>) {
+        T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_column_major_to_z_order_f64(SubgridType::rank, m_host.num_local_elements, src, m_scratch, nullptr)));
+        T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_host_scalar_variable_f64(n, m_scratch, m_scratch64, nullptr)));
+      } else {
+        T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_column_major_to_z_order_f32(SubgridType::rank, m_host.num_local_elements, src, m_scratch, nullptr)));
+        T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_host_scalar_variable_f32(n, m_scratch, m_scratch64, nullptr)));
+      }
+      std::vector<double> host(n);
+      T8GPU_CUDA_CHECK_ERROR(hipMemcpy(host.data(), m_scratch64, sizeof(double) * n, hipMemcpyDeviceToHost));
+      char const*   name = "variables";
+      const int32_t comp = 1;
+      double const* data = host.data();
+      write(prefix, 4, 1, &name, &comp, &data);
+    }
+    /// subgrid_mesh_manager.inl:1185-1206: the forest itself, no data
+    void save_mesh_to_vtk(std::string const& prefix) const { write(prefix, 1, 0, nullptr, nullptr, nullptr); }
+
+   private:
+    HostSubgridMeshArrays m_host;
+    int*                  m_ranks            = nullptr;
+    t8_locidx_t*          m_indices          = nullptr;
+    t8_locidx_t*          m_face_neighbors   = nullptr;
+    t8_locidx_t*          m_level_difference = nullptr;
+    t8_locidx_t*          m_neighbor_offset  = nullptr;
+    float_type*           m_face_normals     = nullptr;
+    float_type*           m_face_surfaces    = nullptr;
+    float_type*           m_scratch          = nullptr;
+    double*               m_scratch64        = nullptr;
+
+    void write(std::string const& prefix, int cells_per_dim, int nf, char const* const* names, int32_t const* comps,
+               double const* const* data) const {
+      const std::string path = prefix + ".vtu";
+      const int rc = t8gpu_host_write_vtu(path.c_str(), SubgridType::rank, m_host.num_local_elements, m_host.centres.data(),
+                                          m_host.levels.data(), cells_per_dim, m_host.mpirank, m_host.first_global_element, nf, names, comps,
+                                          data, 0);
+      if (rc != 0) {
+        std::fprintf(stderr, "t8gpu: writing %s failed (code %d)\n", path.c_str(), rc);
+        std::abort();
+      }
+    }
+    template<typename T>
+    static void upload(T*& dst, std::vector<T> const& src) {
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&dst, sizeof(T) * (src.empty() ? 1 : src.size())));
+      if (!src.empty()) T8GPU_CUDA_CHECK_ERROR(hipMemcpy(dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
     }
   };
 

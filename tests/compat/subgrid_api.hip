@@ -10,6 +10,8 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <vector>
 
 using namespace t8gpu;
@@ -79,14 +81,16 @@ int main() {
     int64_t cnt[8];
     t8gpu_synth_part_counts(part, cnt);
     const int N = static_cast<int>(cnt[0]), F = static_cast<int>(cnt[2]), B = static_cast<int>(cnt[3]);
-    hip::HostSubgridMeshArrays m;
+    HostSubgridMeshArrays m;
     m.num_local_elements = N; m.num_ghost_elements = static_cast<int32_t>(cnt[1]); m.num_local_faces = F; m.num_local_boundary_faces = B;
     m.rank = 3;
     m.face_neighbors.resize(2 * F + B); m.face_level_difference.resize(F); m.face_neighbor_offset.resize(3 * F);
     m.face_normals.resize(3 * (F + B)); m.face_surfaces.resize(F + B); m.volumes.resize(N);
     t8gpu_synth_part_connectivity(part, m.face_neighbors.data(), m.face_normals.data(), m.face_surfaces.data(),
                                   m.face_level_difference.data(), m.face_neighbor_offset.data());
-    t8gpu_synth_part_elements(part, nullptr, m.volumes.data(), nullptr);
+    m.centres.resize(3 * static_cast<size_t>(N));
+    m.levels.resize(N);
+    t8gpu_synth_part_elements(part, m.levels.data(), m.volumes.data(), m.centres.data());
     std::vector<double> ic(5 * static_cast<size_t>(N) * 64);
     t8gpu_synth_part_kh_ic(part, 4, ic.data(), static_cast<size_t>(N) * 64);
     auto make = [&](SubgridMemoryManager<VariableList, StepList, Grid3>& mm) {
@@ -136,6 +140,19 @@ int main() {
       for (size_t i = 0; i < ha.size(); i++) {
         worst = std::max(worst, std::fabs(double(ha[i]) - double(hb[i])));
         scale = std::max(scale, std::fabs(double(hb[i])));
+      }
+    }
+    // the mesh-manager face of the same arrays: accessor counts and the VTK members (subgrid_mesh_manager.inl:1051-1206)
+    {
+      SyntheticSubgridMeshManager<VariableList, StepList, Grid3> mm(m);
+      if (mm.get_num_local_elements() != N || mm.get_connectivity_information().get_num_local_faces() != F) return 3;
+      for (int v = 0; v < 5; v++)
+        mm.set_variable(Step0, static_cast<VariableList>(v),
+                        std::vector<float_type>(ic.begin() + static_cast<size_t>(v) * N * 64, ic.begin() + static_cast<size_t>(v + 1) * N * 64));
+      const char* out = std::getenv("T8GPU_TEST_VTK_PREFIX");
+      if (out) {
+        mm.save_variable_to_vtk(Step0, Rho, std::string(out) + "_rho");
+        mm.save_mesh_to_vtk(std::string(out) + "_mesh");
       }
     }
     for (void* p : {static_cast<void*>(fn), static_cast<void*>(ld), static_cast<void*>(off), static_cast<void*>(nrm), static_cast<void*>(ars)}) (void)hipFree(p);

@@ -76,7 +76,15 @@ def test_reference_style_solver_matches_the_oracle(ft, tol, args, tmp_path):
 
 
 @pytest.mark.gpu
-def test_subgrid_api_runs():
+def test_subgrid_api_runs(tmp_path):
     exe = compile_example("subgrid_api.hip", "subgrid_api")
-    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    prefix = str(tmp_path / "sg")
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(os.environ, T8GPU_TEST_VTK_PREFIX=prefix))
     assert res.returncode == 0 and "subgrid_api OK" in res.stdout, res.stdout + res.stderr
+    # SyntheticSubgridMeshManager::save_variable_to_vtk / save_mesh_to_vtk: twice-refined blocks in z-order
+    from _vtu import read_vtu
+    v, mesh = read_vtu(prefix + "_rho.vtu"), read_vtu(prefix + "_mesh.vtu")
+    assert v["n_cells"] == 64 * mesh["n_cells"] and set(np.unique(v["arrays"]["variables"])) <= {1.0, 2.0}
+    mid = v["arrays"]["Position"].reshape(-1, 8, 3).mean(axis=1)
+    inside = np.abs(mid[:, 2] - 0.5) < 0.25
+    assert (v["arrays"]["variables"][inside] == 2).all() and (v["arrays"]["variables"][~inside] == 1).all()
