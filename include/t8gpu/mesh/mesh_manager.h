@@ -20,8 +20,11 @@
 #include <t8gpu_hip.h>
 #include <t8gpu_host.h>
 
+#include <algorithm>
 #include <array>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <type_traits>
@@ -120,27 +123,82 @@ namespace t8gpu {
     using step_index_type     = typename step_traits<StepType>::index_type;
 
     explicit SyntheticMeshManager(HostMeshArrays const& m, sc_MPI_Comm comm = sc_MPI_COMM_WORLD)
-        : MemoryManager<VariableType, StepType>(static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements, comm),
-          m_num_local_elements{m.num_local_elements}, m_num_ghost_elements{m.num_ghost_elements},
-          m_num_local_faces{m.num_local_faces}, m_num_local_boundary_faces{m.num_local_boundary_faces}, m_rank{m.rank},
-          m_mesh_dim{m.mesh_dim}, m_first_global{m.first_global_element}, m_centres{m.centres}, m_levels{m.levels} {
-      const size_t tot = static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements;
-      std::vector<int>         ranks(tot, m.rank);
-      std::vector<t8_locidx_t> indices(tot);
-      for (size_t i = 0; i < tot; i++) indices[i] = static_cast<t8_locidx_t>(i);
-      upload(m_ranks, ranks);
-      upload(m_indices, indices);
-      upload(m_face_neighbors, m.face_neighbors);
-      upload(m_face_normals, std::vector<float_type>(m.face_normals.begin(), m.face_normals.end()));
-      upload(m_face_surfaces, std::vector<float_type>(m.face_surfaces.begin(), m.face_surfaces.end()));
+        : MemoryManager<VariableType, StepType>(static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements, comm) {
+      rebuild_connectivity(m);
       this->set_volume(std::vector<float_type>(m.volumes.begin(), m.volumes.end()));
     }
+    /// From a synthetic forest (t8gpu_synth_mesh_create; the manager takes ownership): stands for
+    /// MeshManager(comm, scheme, cmesh, forest) (mesh_manager.inl:3-44). The connectivity comes through the
+    /// forest-query adapter (csrc/host/connectivity.cpp), i.e. the way a t8code build would provide it.
+    explicit SyntheticMeshManager(void* synth_mesh, int min_level, int max_level, sc_MPI_Comm comm = sc_MPI_COMM_WORLD)
+        : SyntheticMeshManager(arrays_of(synth_mesh), comm) {
+      m_forest    = synth_mesh;
+      m_min_level = min_level;
+      m_max_level = max_level;
+    }
+
+    /// MeshManager::adapt (mesh_manager.inl:196-330), single rank: the reference's adapt callback on the criteria
+    /// (refine above `threshold`, coarsen a family whose first four members are below it; :125-162), 2:1 balance,
+    /// the data-transfer kernel adapt_variables_and_volume (:165-193) from `step` into the new buffers, new
+    /// connectivity. Only `step` and the volume are valid afterwards, as in the reference.
+    void adapt(std::vector<float_type> const& refinement_criteria, step_index_type step, double threshold = 10.0) {
+      if (!m_forest) {
+        std::fprintf(stderr, "t8gpu: adapt() needs a manager constructed from a forest\n");
+        std::abort();
+      }
+      const int32_t n_old = m_num_local_elements;
+      std::vector<double> crit(refinement_criteria.begin(), refinement_criteria.end());
+      std::vector<int8_t> marks(static_cast<size_t>(n_old));
+      t8gpu_synth_mesh_marks(m_forest, crit.data(), threshold, m_min_level, m_max_level, 4, marks.data());
+      void* new_forest = t8gpu_synth_mesh_adapt(m_forest, marks.data());
+      if (!new_forest) {
+        std::fprintf(stderr, "t8gpu: forest adaptation failed\n");
+        std::abort();
+      }
+      const int32_t        n_new = static_cast<int32_t>(t8gpu_synth_mesh_num_elements(new_forest));
+      std::vector<int32_t> adapt_data(static_cast<size_t>(n_new) + 1);
+      if (t8gpu_synth_mesh_adapt_data(m_forest, new_forest, adapt_data.data()) != 0) std::abort();
+      // device: transfer into temporary planes (5 variables + volume), then into the (possibly re-allocated) manager
+      int32_t*    d_ad  = nullptr;
+      float_type* d_tmp = nullptr;
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&d_ad, sizeof(int32_t) * adapt_data.size()));
+      T8GPU_CUDA_CHECK_ERROR(hipMemcpy(d_ad, adapt_data.data(), sizeof(int32_t) * adapt_data.size(), hipMemcpyHostToDevice));
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&d_tmp, sizeof(float_type) * 6 * static_cast<size_t>(std::max(n_new, 1))));
+      auto old_vars = this->get_own_variables(step);
+      if constexpr (std::is_same_v<float_type, double>) {
+        T8gpuVars_f64 o, n;
+        for (int k = 0; k < 5; k++) {
+          o.p[k] = old_vars.get(k);
+          n.p[k] = d_tmp + static_cast<size_t>(k) * n_new;
+        }
+        T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_adapt_variables_and_volume_f64(
+            n_new, static_cast<int>(m_mesh_dim), d_ad, o, n, this->get_own_volume(), d_tmp + 5 * static_cast<size_t>(n_new), nullptr)));
+      } else {
+        T8gpuVars_f32 o, n;
+        for (int k = 0; k < 5; k++) {
+          o.p[k] = old_vars.get(k);
+          n.p[k] = d_tmp + static_cast<size_t>(k) * n_new;
+        }
+        T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_adapt_variables_and_volume_f32(
+            n_new, static_cast<int>(m_mesh_dim), d_ad, o, n, this->get_own_volume(), d_tmp + 5 * static_cast<size_t>(n_new), nullptr)));
+      }
+      T8GPU_CUDA_CHECK_ERROR(hipDeviceSynchronize());
+      this->resize(static_cast<size_t>(n_new));
+      for (int k = 0; k < 5; k++)
+        this->set_variable(step, static_cast<variable_index_type>(k), d_tmp + static_cast<size_t>(k) * n_new);
+      this->set_volume(d_tmp + 5 * static_cast<size_t>(n_new));
+      (void)hipFree(d_ad);
+      (void)hipFree(d_tmp);
+      t8gpu_synth_mesh_destroy(m_forest);
+      m_forest = new_forest;
+      rebuild_connectivity(arrays_of(m_forest));
+    }
+    [[nodiscard]] void const* forest() const { return m_forest; }
+    [[nodiscard]] HostMeshArrays const& host_arrays() const { return m_host; }
+
     ~SyntheticMeshManager() {
-      (void)hipFree(m_ranks);
-      (void)hipFree(m_indices);
-      (void)hipFree(m_face_neighbors);
-      (void)hipFree(m_face_normals);
-      (void)hipFree(m_face_surfaces);
+      if (m_forest) t8gpu_synth_mesh_destroy(m_forest);
+      free_connectivity();
       (void)hipFree(m_staging);
     }
     SyntheticMeshManager(SyntheticMeshManager const&)            = delete;
@@ -208,6 +266,70 @@ namespace t8gpu {
     }
 
    private:
+    void*          m_forest    = nullptr;   // synthetic forest (owned) when constructed from one
+    int            m_min_level = 0, m_max_level = 0;
+    HostMeshArrays m_host;
+
+    /// HostMeshArrays of a synthetic forest on one rank: connectivity through the forest-query adapter, plus the
+    /// leaf geometry the VTK members need
+    static HostMeshArrays arrays_of(void* forest) {
+      T8gpuForestQuery* q = t8gpu_synth_query_create(forest, 0, 1);
+      void*             h = q ? t8gpu_host_connectivity_create(q) : nullptr;
+      if (!h) {
+        std::fprintf(stderr, "t8gpu: connectivity of the synthetic forest could not be built\n");
+        std::abort();
+      }
+      int64_t c[6];
+      t8gpu_host_connectivity_counts(h, c);
+      HostMeshArrays m;
+      m.num_local_elements = static_cast<int32_t>(c[0]); m.num_ghost_elements = static_cast<int32_t>(c[1]);
+      m.num_local_faces = static_cast<int32_t>(c[2]); m.num_local_boundary_faces = static_cast<int32_t>(c[3]);
+      m.face_neighbors.resize(2 * c[2] + c[3]);
+      m.face_normals.resize(3 * (c[2] + c[3]));
+      m.face_surfaces.resize(c[2] + c[3]);
+      m.volumes.resize(c[0] + c[1]);
+      t8gpu_host_connectivity_arrays(h, m.face_neighbors.data(), m.face_normals.data(), m.face_surfaces.data(), m.volumes.data(), nullptr,
+                                     nullptr, nullptr, nullptr);
+      t8gpu_host_connectivity_destroy(h);
+      t8gpu_synth_query_destroy(q);
+      void* part = t8gpu_synth_part_create(forest, 0, 1, 0, 3);
+      m.mesh_dim = t8gpu_synth_mesh_dim(forest);
+      m.levels.resize(c[0]);
+      m.centres.resize(3 * c[0]);
+      t8gpu_synth_part_elements(part, m.levels.data(), nullptr, m.centres.data());
+      t8gpu_synth_part_destroy(part);
+      return m;
+    }
+    void free_connectivity() {
+      (void)hipFree(m_ranks);
+      (void)hipFree(m_indices);
+      (void)hipFree(m_face_neighbors);
+      (void)hipFree(m_face_normals);
+      (void)hipFree(m_face_surfaces);
+      m_ranks = nullptr; m_indices = nullptr; m_face_neighbors = nullptr; m_face_normals = nullptr; m_face_surfaces = nullptr;
+    }
+    /// compute_connectivity_information (mesh_manager.inl:333-481): device copies of the face arrays
+    void rebuild_connectivity(HostMeshArrays const& m) {
+      free_connectivity();
+      m_host                     = m;
+      m_num_local_elements       = m.num_local_elements;
+      m_num_ghost_elements       = m.num_ghost_elements;
+      m_num_local_faces          = m.num_local_faces;
+      m_num_local_boundary_faces = m.num_local_boundary_faces;
+      m_rank = m.rank; m_mesh_dim = m.mesh_dim; m_first_global = m.first_global_element;
+      m_centres = m.centres;
+      m_levels  = m.levels;
+      const size_t tot = static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements;
+      std::vector<int>         ranks(tot, m.rank);
+      std::vector<t8_locidx_t> indices(tot);
+      for (size_t i = 0; i < tot; i++) indices[i] = static_cast<t8_locidx_t>(i);
+      upload(m_ranks, ranks);
+      upload(m_indices, indices);
+      upload(m_face_neighbors, m.face_neighbors);
+      upload(m_face_normals, std::vector<float_type>(m.face_normals.begin(), m.face_normals.end()));
+      upload(m_face_surfaces, std::vector<float_type>(m.face_surfaces.begin(), m.face_surfaces.end()));
+    }
+
     int                  m_rank = 0, m_mesh_dim = 2;
     int64_t              m_first_global = 0;
     std::vector<double>  m_centres;
@@ -229,7 +351,7 @@ namespace t8gpu {
       return h;
     }
 
-    t8_locidx_t  m_num_local_elements, m_num_ghost_elements, m_num_local_faces, m_num_local_boundary_faces;
+    t8_locidx_t  m_num_local_elements = 0, m_num_ghost_elements = 0, m_num_local_faces = 0, m_num_local_boundary_faces = 0;
     int*         m_ranks          = nullptr;
     t8_locidx_t* m_indices        = nullptr;
     t8_locidx_t* m_face_neighbors = nullptr;

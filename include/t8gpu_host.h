@@ -23,6 +23,7 @@ void*   t8gpu_synth_mesh_create(int dim, int base_level, int max_level, double b
 void    t8gpu_synth_mesh_destroy(void* mesh);
 int64_t t8gpu_synth_mesh_num_elements(const void* mesh);
 int     t8gpu_synth_mesh_finest_level(const void* mesh);
+int     t8gpu_synth_mesh_dim(const void* mesh);
 
 void* t8gpu_synth_part_create(const void* mesh, int rank, int nranks, int subgrid, int normal_dim);
 void  t8gpu_synth_part_destroy(void* part);

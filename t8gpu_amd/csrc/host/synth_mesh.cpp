@@ -320,6 +320,7 @@ void* t8gpu_synth_mesh_create(int dim, int base_level, int max_level, double ban
   return m;
 }
 void    t8gpu_synth_mesh_destroy(void* h) { delete static_cast<Mesh*>(h); }
+int t8gpu_synth_mesh_dim(const void* h) { return static_cast<const Mesh*>(h)->dim; }
 int64_t t8gpu_synth_mesh_num_elements(const void* h) { return static_cast<int64_t>(static_cast<const Mesh*>(h)->leaves.size()); }
 int     t8gpu_synth_mesh_finest_level(const void* h) {
   int l = 0;

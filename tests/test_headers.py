@@ -34,6 +34,10 @@ def test_reference_style_solver_compiles_against_the_headers(ft):
     compile_example("plain_example.hip", f"plain_example_{ft}", (f"-DT8GPU_FLOAT_TYPE={ft}",))
 
 
+def test_adapt_example_compiles():
+    compile_example("adapt_example.hip", "adapt_example")
+
+
 def test_subgrid_api_compiles():
     compile_example("subgrid_api.hip", "subgrid_api")
 
@@ -88,3 +92,11 @@ def test_subgrid_api_runs(tmp_path):
     mid = v["arrays"]["Position"].reshape(-1, 8, 3).mean(axis=1)
     inside = np.abs(mid[:, 2] - 0.5) < 0.25
     assert (v["arrays"]["variables"][inside] == 2).all() and (v["arrays"]["variables"][~inside] == 1).all()
+
+
+@pytest.mark.gpu
+def test_adapt_example_runs():
+    """MeshManager::adapt + the adaptive main loop in C++ (tests/compat/adapt_example.hip): mesh changes, mass is kept."""
+    exe = compile_example("adapt_example.hip", "adapt_example")
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and "adapt_example OK" in res.stdout, res.stdout + res.stderr
