@@ -14,6 +14,7 @@
 #include <t8gpu/memory/subgrid_memory_manager.h>
 #include <t8gpu/mesh/mesh_manager.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -98,22 +99,75 @@ namespace t8gpu {
     explicit SyntheticSubgridMeshManager(HostSubgridMeshArrays const& m, sc_MPI_Comm comm = sc_MPI_COMM_WORLD)
         : SubgridMemoryManager<VariableType, StepType, SubgridType>(static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements, comm),
           m_host{m} {
-      const size_t tot = static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements;
-      std::vector<int>         ranks(tot, m.mpirank);
-      std::vector<t8_locidx_t> indices(tot);
-      for (size_t i = 0; i < tot; i++) indices[i] = static_cast<t8_locidx_t>(i);
-      upload(m_ranks, ranks);
-      upload(m_indices, indices);
-      upload(m_face_neighbors, m.face_neighbors);
-      upload(m_level_difference, m.face_level_difference);
-      upload(m_neighbor_offset, m.face_neighbor_offset);
-      upload(m_face_normals, std::vector<float_type>(m.face_normals.begin(), m.face_normals.end()));
-      upload(m_face_surfaces, std::vector<float_type>(m.face_surfaces.begin(), m.face_surfaces.end()));
+      rebuild_connectivity(m);
+      const size_t            tot = static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements;
       std::vector<float_type> vol(m.volumes.begin(), m.volumes.end());
       vol.resize(tot, float_type(1));
       this->set_volume(vol);
     }
+    /// From a synthetic forest (owned afterwards): stands for SubgridMeshManager(comm, scheme, cmesh, forest)
+    /// (subgrid_mesh_manager.inl:3-60); connectivity through the forest-query adapter.
+    explicit SyntheticSubgridMeshManager(void* synth_mesh, int min_level, int max_level, sc_MPI_Comm comm = sc_MPI_COMM_WORLD)
+        : SyntheticSubgridMeshManager(arrays_of(synth_mesh), comm) {
+      m_forest    = synth_mesh;
+      m_min_level = min_level;
+      m_max_level = max_level;
+    }
+
+    /// SubgridMeshManager::adapt (subgrid_mesh_manager.inl:428-558), single rank: adapt callback on the per-block
+    /// criteria, 2:1 balance, block-wise transfer adapt_variables + adapt_volume (:246-425) from `step`, new
+    /// connectivity. Only `step` and the volumes are valid afterwards.
+    void adapt(std::vector<float_type> const& refinement_criteria, step_index_type step, double threshold = 0.02) {
+      if (!m_forest) {
+        std::fprintf(stderr, "t8gpu: adapt() needs a manager constructed from a forest\n");
+        std::abort();
+      }
+      constexpr size_t     S = SubgridType::size;
+      std::vector<double>  crit(refinement_criteria.begin(), refinement_criteria.end());
+      std::vector<int8_t>  marks(static_cast<size_t>(m_host.num_local_elements));
+      t8gpu_synth_mesh_marks(m_forest, crit.data(), threshold, m_min_level, m_max_level, 4, marks.data());
+      void* new_forest = t8gpu_synth_mesh_adapt(m_forest, marks.data());
+      if (!new_forest) std::abort();
+      const int32_t        n_new = static_cast<int32_t>(t8gpu_synth_mesh_num_elements(new_forest));
+      std::vector<int32_t> adapt_data(static_cast<size_t>(n_new) + 1);
+      if (t8gpu_synth_mesh_adapt_data(m_forest, new_forest, adapt_data.data()) != 0) std::abort();
+      int32_t*    d_ad  = nullptr;
+      float_type *d_tmp = nullptr, *d_vol = nullptr;
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&d_ad, sizeof(int32_t) * adapt_data.size()));
+      T8GPU_CUDA_CHECK_ERROR(hipMemcpy(d_ad, adapt_data.data(), sizeof(int32_t) * adapt_data.size(), hipMemcpyHostToDevice));
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&d_tmp, sizeof(float_type) * 5 * S * static_cast<size_t>(std::max(n_new, 1))));
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&d_vol, sizeof(float_type) * static_cast<size_t>(std::max(n_new, 1))));
+      auto old_vars = this->get_own_variables(step);
+      auto run = [&](auto o, auto n, auto fn) {
+        for (int k = 0; k < 5; k++) {
+          o.p[k] = old_vars.data(static_cast<variable_index_type>(k));
+          n.p[k] = d_tmp + static_cast<size_t>(k) * S * n_new;
+        }
+        T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(fn(SubgridType::rank, n_new, d_ad, o, n, this->get_own_volume(), d_vol, nullptr)));
+      };
+      if constexpr (std::is_same_v<float_type, double>)
+        run(T8gpuVars_f64{}, T8gpuVars_f64{}, t8gpu_hip_subgrid_adapt_variables_and_volume_f64);
+      else
+        run(T8gpuVars_f32{}, T8gpuVars_f32{}, t8gpu_hip_subgrid_adapt_variables_and_volume_f32);
+      T8GPU_CUDA_CHECK_ERROR(hipDeviceSynchronize());
+      this->resize(static_cast<size_t>(n_new));
+      for (int k = 0; k < 5; k++) this->set_variable(step, static_cast<variable_index_type>(k), d_tmp + static_cast<size_t>(k) * S * n_new);
+      T8GPU_CUDA_CHECK_ERROR(hipMemcpy(this->get_own_volume(), d_vol, sizeof(float_type) * n_new, hipMemcpyDeviceToDevice));
+      (void)hipFree(d_ad);
+      (void)hipFree(d_tmp);
+      (void)hipFree(d_vol);
+      t8gpu_synth_mesh_destroy(m_forest);
+      m_forest = new_forest;
+      rebuild_connectivity(arrays_of(m_forest));
+      (void)hipFree(m_scratch);      // sized for the old mesh
+      (void)hipFree(m_scratch64);
+      m_scratch   = nullptr;
+      m_scratch64 = nullptr;
+    }
+    [[nodiscard]] void const* forest() const { return m_forest; }
+
     ~SyntheticSubgridMeshManager() {
+      if (m_forest) t8gpu_synth_mesh_destroy(m_forest);
       for (void* p : {static_cast<void*>(m_ranks), static_cast<void*>(m_indices), static_cast<void*>(m_face_neighbors),
                       static_cast<void*>(m_level_difference), static_cast<void*>(m_neighbor_offset), static_cast<void*>(m_face_normals),
                       static_cast<void*>(m_face_surfaces), static_cast<void*>(m_scratch), static_cast<void*>(m_scratch64)})
@@ -156,6 +210,64 @@ namespace t8gpu {
     void save_mesh_to_vtk(std::string const& prefix) const { write(prefix, 1, 0, nullptr, nullptr, nullptr); }
 
    private:
+    void* m_forest    = nullptr;
+    int   m_min_level = 0, m_max_level = 0;
+
+    static HostSubgridMeshArrays arrays_of(void* forest) {
+      constexpr int     R = SubgridType::rank;
+      T8gpuForestQuery* q = t8gpu_synth_query_create(forest, 0, 1);
+      void*             h = q ? t8gpu_host_connectivity_create_subgrid(q, R) : nullptr;
+      if (!h) {
+        std::fprintf(stderr, "t8gpu: connectivity of the synthetic forest could not be built\n");
+        std::abort();
+      }
+      int64_t c[6];
+      t8gpu_host_connectivity_counts(h, c);
+      HostSubgridMeshArrays m;
+      m.rank = R;
+      m.num_local_elements = static_cast<int32_t>(c[0]); m.num_ghost_elements = static_cast<int32_t>(c[1]);
+      m.num_local_faces = static_cast<int32_t>(c[2]); m.num_local_boundary_faces = static_cast<int32_t>(c[3]);
+      const size_t nf = static_cast<size_t>(c[2] + c[3]);
+      std::vector<double> n3(3 * nf);
+      m.face_neighbors.resize(2 * c[2] + c[3]);
+      m.face_surfaces.resize(nf);
+      m.volumes.resize(c[0] + c[1]);
+      m.face_level_difference.resize(c[2]);
+      m.face_neighbor_offset.resize(static_cast<size_t>(R) * c[2]);
+      t8gpu_host_connectivity_arrays(h, m.face_neighbors.data(), n3.data(), m.face_surfaces.data(), m.volumes.data(), nullptr, nullptr,
+                                     nullptr, nullptr);
+      t8gpu_host_connectivity_subgrid_arrays(h, m.face_level_difference.data(), m.face_neighbor_offset.data());
+      t8gpu_host_connectivity_destroy(h);
+      t8gpu_synth_query_destroy(q);
+      m.face_normals.resize(static_cast<size_t>(R) * nf);   // the Subgrid accessors carry `rank` components
+      for (size_t i = 0; i < nf; i++)
+        for (int d = 0; d < R; d++) m.face_normals[R * i + d] = n3[3 * i + d];
+      void* part = t8gpu_synth_part_create(forest, 0, 1, 1, R);
+      m.levels.resize(c[0]);
+      m.centres.resize(3 * c[0]);
+      t8gpu_synth_part_elements(part, m.levels.data(), nullptr, m.centres.data());
+      t8gpu_synth_part_destroy(part);
+      return m;
+    }
+    void rebuild_connectivity(HostSubgridMeshArrays const& m) {
+      for (void* p : {static_cast<void*>(m_ranks), static_cast<void*>(m_indices), static_cast<void*>(m_face_neighbors),
+                      static_cast<void*>(m_level_difference), static_cast<void*>(m_neighbor_offset), static_cast<void*>(m_face_normals),
+                      static_cast<void*>(m_face_surfaces)})
+        (void)hipFree(p);
+      m_host = m;
+      const size_t tot = static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements;
+      std::vector<int>         ranks(tot, m.mpirank);
+      std::vector<t8_locidx_t> indices(tot);
+      for (size_t i = 0; i < tot; i++) indices[i] = static_cast<t8_locidx_t>(i);
+      upload(m_ranks, ranks);
+      upload(m_indices, indices);
+      upload(m_face_neighbors, m.face_neighbors);
+      upload(m_level_difference, m.face_level_difference);
+      upload(m_neighbor_offset, m.face_neighbor_offset);
+      upload(m_face_normals, std::vector<float_type>(m.face_normals.begin(), m.face_normals.end()));
+      upload(m_face_surfaces, std::vector<float_type>(m.face_surfaces.begin(), m.face_surfaces.end()));
+    }
+
     HostSubgridMeshArrays m_host;
     int*                  m_ranks            = nullptr;
     t8_locidx_t*          m_indices          = nullptr;

@@ -164,6 +164,57 @@ int main() {
     }
     std::printf("fused block kernel vs reference-dataflow kernels over 3 steps: max |diff| = %.3g (scale %.3g)\n", worst, scale);
   }
+  // ---- SubgridMeshManager::adapt in C++ (subgrid_mesh_manager.inl:428-558): criteria kernel, forest adapt, block-wise
+  //      transfer, new connectivity, fused steps on the new mesh; mass must be kept ---------------------------------
+  {
+    SyntheticSubgridMeshManager<VariableList, StepList, Grid3> mm(t8gpu_synth_mesh_create(3, 2, 2, 0.0, 1.0, 1), 1, 3);
+    auto fill_ic = [&]() {
+      void*        part = t8gpu_synth_part_create(mm.forest(), 0, 1, 1, 3);
+      const size_t n    = static_cast<size_t>(mm.get_num_local_elements()) * 64;
+      std::vector<double> ic(5 * n);
+      t8gpu_synth_part_kh_ic(part, 4, ic.data(), n);
+      t8gpu_synth_part_destroy(part);
+      for (int st = 0; st < nb_steps; st++)
+        for (int v = 0; v < 5; v++) mm.set_variable(static_cast<StepList>(st), static_cast<VariableList>(v), std::vector<float_type>(n, 0));
+      for (int v = 0; v < 5; v++)
+        mm.set_variable(Step0, static_cast<VariableList>(v), std::vector<float_type>(ic.begin() + v * n, ic.begin() + (v + 1) * n));
+    };
+    fill_ic();
+    hip::Reducer reduce;
+    auto mass = [&](StepList st) {
+      return reduce.integral<float_type>(static_cast<size_t>(mm.get_num_local_elements()) * 64,
+                                         static_cast<float_type const*>(mm.get_own_variable(st, Rho)), mm.get_own_volume(), 64);
+    };
+    const double m0 = mass(Step0);
+    const int    n0 = mm.get_num_local_elements();
+    float_type*  crit = nullptr;
+    T8GPU_CUDA_CHECK_ERROR(hipMalloc(&crit, sizeof(float_type) * n0));
+    T8GPU_HIP_CHECK_ABI(t8gpu_hip_subgrid_refinement_criteria_f32(3, n0, static_cast<float_type const*>(mm.get_own_variable(Step0, Rho)),
+                                                                  mm.get_own_volume(), crit, nullptr));
+    std::vector<float_type> hc(n0);
+    T8GPU_CUDA_CHECK_ERROR(hipMemcpy(hc.data(), crit, sizeof(float_type) * n0, hipMemcpyDeviceToHost));
+    (void)hipFree(crit);
+    mm.adapt(hc, Step0);
+    const int    n1 = mm.get_num_local_elements();
+    const double m1 = mass(Step0);
+    hip::SubgridFusedPlan<float_type> plan(mm.host_arrays());
+    for (int st = 1; st < nb_steps; st++)
+      for (int v = 0; v < 5; v++)
+        mm.set_variable(static_cast<StepList>(st), static_cast<VariableList>(v), std::vector<float_type>(static_cast<size_t>(n1) * 64, 0));
+    StepList next = Step0, prev = Step3;
+    const float_type dts = float_type(0.1 * std::pow(0.5, t8gpu_synth_mesh_finest_level(mm.forest()) + 2));
+    for (int it = 0; it < 3; it++) {
+      std::swap(next, prev);
+      hip::iterate_fused(mm, plan, prev, next, dts);
+    }
+    T8GPU_CUDA_CHECK_ERROR(hipDeviceSynchronize());
+    const double m2 = mass(next);
+    std::printf("subgrid adapt: %d -> %d blocks, mass %.9g -> %.9g -> %.9g after 3 steps\n", n0, n1, m0, m1, m2);
+    if (n1 == n0 || !(std::fabs(m1 - m0) <= 1e-5 * std::fabs(m0)) || !(std::fabs(m2 - m0) <= 1e-5 * std::fabs(m0))) {
+      std::printf("subgrid_api FAILED: adapt\n");
+      return 1;
+    }
+  }
   std::printf("subgrid_api OK\n");
   return 0;
 }
