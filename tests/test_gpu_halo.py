@@ -33,7 +33,26 @@ def loopback(halos):
 @pytest.mark.parametrize("mode", ["fused", "compat"])
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_k_way_partition_on_one_gpu_equals_single_rank(world, mode, dtype):
-    mesh = SynthMesh(2, 4, 7, band=0.06)
+    k_way_plain(SynthMesh(2, 4, 7, band=0.06), world, mode, dtype, small_tiles=True)
+
+
+@pytest.mark.parametrize("mode", ["fused", "compat"])
+def test_more_ranks_than_elements(mode):
+    """4 elements on 6 ranks: two ranks own nothing (no elements, faces, ghosts or peers) and every launch on them
+    is a no-op; the others own one element whose neighbours are all ghosts."""
+    mesh = SynthMesh(2, 1, 1)
+    assert sorted(mesh.partition(r, 6).N for r in range(6)) == [0, 0, 1, 1, 1, 1]
+    k_way_plain(mesh, 6, mode, torch.float64, small_tiles=False)
+    if mode == "fused":                                         # the C++ step driver on a rank that owns nothing
+        empty = PlainSolver(mesh.partition(0, 6), torch.float64, mode="fused")
+        empty.use_native_stepper()
+        empty.iterate(0.05)
+        empty.iterate_steps(3, 0.05)
+        torch.cuda.synchronize()
+        assert tuple(empty.state().shape) == (5, 0) and empty.compute_integral(0) == 0.0
+
+
+def k_way_plain(mesh, world, mode, dtype, small_tiles):
     whole = mesh.partition()
     st = perturbed_state(whole, 77)
     ref = PlainSolver(whole, dtype, mode=mode, state=st)
@@ -45,7 +64,7 @@ def test_k_way_partition_on_one_gpu_equals_single_rank(world, mode, dtype):
         local[:, part.N:] = np.nan                              # ghost values must arrive through the exchange
         solvers.append(PlainSolver(part, dtype, mode=mode, state=local))
         halos.append(HaloExchange(part, dtype, dist=None, overlap=False))
-    if mode == "fused":
+    if mode == "fused" and small_tiles:
         from t8gpu_amd import fused
         for s, part in zip(solvers, parts):                     # small tiles: interior AND ghost-reading tiles on every rank
             s.plan = fused.PlainPlan(part, dtype, tmax=32, fcap=80)
@@ -94,7 +113,18 @@ def test_pack_unpack_kernels_match_numpy():
 @pytest.mark.parametrize("dim", [3, 2])
 def test_k_way_subgrid_partition_on_one_gpu_equals_single_rank(world, mode, dim):
     """Ghost BLOCKS (all 16 / 64 subcells mirrored), interior / ghost-touching block split of the fused kernel."""
-    mesh = SynthMesh(dim, 3, 4 if dim == 3 else 6, band=0.03)
+    k_way_subgrid(SynthMesh(dim, 3, 4 if dim == 3 else 6, band=0.03), world, mode, dim, both_classes=True)
+
+
+@pytest.mark.parametrize("mode", ["fused", "compat"])
+def test_more_ranks_than_blocks(mode):
+    """8 blocks of Subgrid<4,4,4> on 10 ranks: two ranks own nothing."""
+    mesh = SynthMesh(3, 1, 1)
+    assert sorted(mesh.partition(r, 10, subgrid=True).N for r in range(10)) == [0, 0] + [1] * 8
+    k_way_subgrid(mesh, 10, mode, 3, both_classes=False)
+
+
+def k_way_subgrid(mesh, world, mode, dim, both_classes):
     whole = mesh.partition(subgrid=True)
     S = 4 ** dim
     st = perturbed_state(whole, 78)
@@ -109,7 +139,7 @@ def test_k_way_subgrid_partition_on_one_gpu_equals_single_rank(world, mode, dim)
         local[:, part.N * S:] = np.nan
         solvers.append(SubgridSolver(part, dtype, mode=mode, state=local))
         halos.append(HaloExchange(part, dtype, dist=None, overlap=False))
-    if mode == "fused":
+    if mode == "fused" and both_classes:
         assert all(0 < s.plan.host.n_interior < s.N for s in solvers)
     dt = 0.1 * 2.0 ** -(mesh.finest_level + 2)
     for _ in range(2):
