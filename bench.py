@@ -88,7 +88,11 @@ def main():
 
     hip.lib()
     dist = None
-    if world > 1:
+    # T8GPU_BENCH_FORCE_DIST=1 sends a ONE-rank run through the N > 1 code path (process group on the real RCCL
+    # backend, collective decisions, native communicator from a broadcast id, the multi-rank stepper bring-up):
+    # the only way to execute that path on a one-GPU box; tests/test_gpu_bench_rehearsal.py uses it.
+    distributed = world > 1 or os.environ.get("T8GPU_BENCH_FORCE_DIST", "0") == "1"
+    if distributed:
         import torch.distributed as dist
         if rehearsal:
             dist.init_process_group("gloo")
@@ -127,15 +131,15 @@ def main():
     halo = None
     halo_kind = "none"
     stepper = None
-    if world > 1:
+    if distributed:
         from t8gpu_amd import halo as halo_mod
         halo = halo_mod.HaloExchange(part, tdtype, dist, stage_through_host=rehearsal)   # torch.distributed transport
         halo_kind = "torch.distributed (gloo, host-staged REHEARSAL)" if rehearsal else "torch.distributed"
     if mode == "fused" and w["kind"] == "plain" and os.environ.get("T8GPU_STEPPER", "native") == "native":
         native_halo = None
-        if world > 1 and os.environ.get("T8GPU_HALO", "native") == "native":
+        if distributed and os.environ.get("T8GPU_HALO", "native") == "native":
             native_halo = make_native_halo(part, tdtype, solver, halo, dist, rank, world)
-        if world == 1:
+        if not distributed:
             try:
                 stepper = solver.use_native_stepper(None)
             except Exception as exc:  # noqa: BLE001  (keep the run alive on the python-driven path)

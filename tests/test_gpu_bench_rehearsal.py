@@ -56,3 +56,28 @@ def test_adaptive_example_on_three_ranks_rehearsal(tmp_path):
     assert os.path.exists(prefix + ".pvtu")
     drift = float(out.stdout.split("conservation drift")[-1].split()[0])
     assert drift < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["c1", "c3q"])
+def test_bench_distributed_path_on_real_rccl_with_one_rank(workload):
+    """T8GPU_BENCH_FORCE_DIST=1: a one-rank run through the N > 1 branch of bench.py on the REAL backend -- nccl (=RCCL)
+    process group bound to the device, barrier / all-reduce on device tensors, the native communicator made from an
+    id broadcast through torch.distributed, both collective bring-up decisions and the C++ stepper constructed with
+    a halo descriptor. (A rank has no peer here, so no message is sent: that part is the self-exchange test's.)"""
+    env = dict(os.environ, T8GPU_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("T8GPU_REHEARSAL", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29655", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--prewarm-seconds", "0.05", "--no-cpu-baseline", "--workload", workload]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["config"]["finite"] is True and rec["value"] > 0
+    assert "unavailable" not in out.stderr, out.stderr[-3000:]          # no fall-back was taken
+    if workload == "c1":
+        assert rec["config"]["halo"] == "native rccl (C++ stepper)" and rec["config"]["driver"] == "native C++ stepper"
+    else:
+        assert rec["config"]["halo"] == "torch.distributed"            # Subgrid runs use the python-driven stages
