@@ -49,8 +49,6 @@ namespace t8gpu {
   class SubgridMemoryManager;
   template<typename VariableType, typename StepType, size_t dim>
   class MeshManager;
-  template<typename VariableType, typename StepType, size_t dim>
-  class SyntheticMeshManager;
 
   namespace detail {
     /// Shared implementation of both accessors: N handles indexed by the variable enum.
@@ -107,8 +105,6 @@ namespace t8gpu {
     friend class MemoryManager;
     template<typename VT, typename ST, size_t dim_>
     friend class MeshManager;
-    template<typename VT, typename ST, size_t dim_>
-    friend class SyntheticMeshManager;
     template<typename VT, typename ST, typename SubgridType>
     friend class SubgridMeshManager;
 
@@ -133,8 +129,6 @@ namespace t8gpu {
     friend class MemoryManager;
     template<typename VT, typename ST, size_t dim_>
     friend class MeshManager;
-    template<typename VT, typename ST, size_t dim_>
-    friend class SyntheticMeshManager;
 
    public:
     MemoryAccessorAll(MemoryAccessorAll const&)            = default;

@@ -3,15 +3,20 @@
 // MeshConnectivityAccessor<float_type, dim>: the device-side view of the face lists, with the getters
 // of the reference (t8gpu/mesh/mesh_manager.h:30-182) over the same arrays:
 //   ranks[N+G], indices[N+G], face_neighbors[2F + B], face_normals[dim * (F + B)], face_surfaces[F + B].
-// SyntheticMeshManager<V, S, dim>: MemoryManager + those arrays filled from host vectors (e.g. the
-// t8code-free provider of include/t8gpu_host.h). It exposes the part of MeshManager's interface the hot
-// path uses (mesh_manager.h:253-421): get_connectivity_information(), get_num_local_{elements,faces,
-// boundary_faces}(), get_num_ghost_elements(), get_{own,all}_variable(s), get_own_volume().
-// plus the read-back / VTK members (mesh_manager.inl:516-623): get_host_scalar_variable,
-// get_host_vector_variable, save_variables_to_vtk -- the device half in csrc/hip/kernels_readback.hip, the
-// file written by t8gpu_host_write_vtu where the reference calls t8_forest_write_vtk_ext.
-// The t8code-bound MeshManager (constructor from a forest, adapt, partition) is NOT part of this
-// round; it needs t8code, which this build does not have.
+// MeshManager<V, S, dim>: the class of the reference (t8gpu/mesh/mesh_manager.h:232-465) with the same public
+// members -- constructor (comm, scheme, cmesh, forest), initialize_variables(Func), adapt(criteria, step),
+// partition(step), compute_connectivity_information(), save_variable(s)_to_vtk, HostVariableInfo,
+// get_host_{scalar,vector}_variable, get_connectivity_information(), get_num_local_{elements,faces,
+// boundary_faces}(), get_num_ghost_elements(), min_level / max_level -- on top of MemoryManager. Where the mesh
+// comes from is a provider behind the class:
+//   * a t8code forest: the (comm, scheme, cmesh, forest) constructor. It is DECLARED here and defined only in a
+//     build that has t8code (it fills a T8gpuForestQuery from t8code calls); this image
+//     has no t8code, so example TUs compile against it and link once that adapter is compiled in.
+//   * the t8code-free synthetic forest of include/t8gpu_host.h, or plain host arrays (HostMeshArrays): the two
+//     extra constructors below. `SyntheticMeshManager<V,S,dim>` is an alias of MeshManager kept for code written
+//     against the earlier name.
+// Read-back / VTK members (mesh_manager.inl:516-623): device half in csrc/hip/kernels_readback.hip, the file is
+// written by t8gpu_host_write_vtu where the reference calls t8_forest_write_vtk_ext.
 #ifndef T8GPU_HIP_MESH_MESH_MANAGER_H
 #define T8GPU_HIP_MESH_MESH_MANAGER_H
 
@@ -30,10 +35,19 @@
 #include <type_traits>
 #include <vector>
 
-#if !__has_include(<t8.h>)
-using t8_locidx_t = int32_t;
-#else
+#include <thrust/host_vector.h>
+
+#if __has_include(<t8.h>)
 #include <t8.h>
+#else
+// no t8code on the include path: the handle types of the constructor's signature, opaque
+using t8_locidx_t = int32_t;
+typedef struct t8_forest* t8_forest_t;
+typedef struct t8_cmesh*  t8_cmesh_t;
+struct t8_scheme_cxx;
+typedef struct t8_scheme_cxx t8_scheme_cxx_t;
+struct t8_element;
+typedef struct t8_element t8_element_t;
 #endif
 
 namespace t8gpu {
@@ -42,8 +56,6 @@ namespace t8gpu {
   class MeshConnectivityAccessor {
     template<typename VT, typename ST, size_t dim_>
     friend class MeshManager;
-    template<typename VT, typename ST, size_t dim_>
-    friend class SyntheticMeshManager;
 
    public:
     MeshConnectivityAccessor(MeshConnectivityAccessor const&)            = default;
@@ -115,26 +127,109 @@ namespace t8gpu {
   /// T8_VTK_SCALAR / T8_VTK_VECTOR of t8code's t8_vtk_data_field_t: values per cell
   enum : int { T8GPU_VTK_SCALAR = 1, T8GPU_VTK_VECTOR = 3 };
 
-  template<typename VariableType, typename StepType, size_t dim>
-  class SyntheticMeshManager : public MemoryManager<VariableType, StepType> {
-   public:
-    using float_type          = typename variable_traits<VariableType>::float_type;
-    using variable_index_type = typename variable_traits<VariableType>::index_type;
-    using step_index_type     = typename step_traits<StepType>::index_type;
+  /// What initialize_variables hands to the user function as `t8_element_t const*` when the forest is the synthetic
+  /// provider's (there is no t8code element behind it): centre, level and volume of the leaf on the unit domain.
+  /// `t8gpu::synthetic_element(element)` turns the opaque pointer back into this record.
+  struct SyntheticElement {
+    double  centre[3];
+    int32_t level;
+    double  volume;
+  };
+  [[nodiscard]] inline SyntheticElement const& synthetic_element(t8_element_t const* element) {
+    return *reinterpret_cast<SyntheticElement const*>(element);
+  }
 
-    explicit SyntheticMeshManager(HostMeshArrays const& m, sc_MPI_Comm comm = sc_MPI_COMM_WORLD)
+  template<typename VariableType, typename StepType, size_t dim>
+  class MeshManager : public MemoryManager<VariableType, StepType> {
+   public:
+    using float_type                  = typename variable_traits<VariableType>::float_type;
+    using variable_index_type         = typename variable_traits<VariableType>::index_type;
+    static constexpr int nb_variables = variable_traits<VariableType>::nb_variables;
+
+    using step_index_type            = typename step_traits<StepType>::index_type;
+    static constexpr size_t nb_steps = step_traits<StepType>::nb_steps;
+
+    static constexpr t8_locidx_t min_level = 1;   // mesh_manager.h:240-241 (adapt() of a t8code forest uses them)
+    static constexpr t8_locidx_t max_level = 4;
+
+    /// mesh_manager.h:253 / mesh_manager.inl:20-64: takes ownership of cmesh and forest. Declared for every build;
+    /// DEFINED by the t8code adapter only (fills a T8gpuForestQuery from t8_forest_leaf_face_neighbors & co.,
+    /// INTEGRATION.md section 4) -- a build without t8code cannot call it and gets a link error if it tries.
+    MeshManager(sc_MPI_Comm comm, t8_scheme_cxx_t* scheme, t8_cmesh_t cmesh, t8_forest_t forest);
+
+    /// From host arrays in the reference's formats (one rank's share; ghosts resolved to mirror slots).
+    explicit MeshManager(HostMeshArrays const& m, sc_MPI_Comm comm = sc_MPI_COMM_WORLD)
         : MemoryManager<VariableType, StepType>(static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements, comm) {
+      int comm_rank = 0;
+      detail::comm_layout(comm, comm_rank, m_nb_ranks);
       rebuild_connectivity(m);
       this->set_volume(std::vector<float_type>(m.volumes.begin(), m.volumes.end()));
     }
     /// From a synthetic forest (t8gpu_synth_mesh_create; the manager takes ownership): stands for
     /// MeshManager(comm, scheme, cmesh, forest) (mesh_manager.inl:3-44). The connectivity comes through the
     /// forest-query adapter (csrc/host/connectivity.cpp), i.e. the way a t8code build would provide it.
-    explicit SyntheticMeshManager(void* synth_mesh, int min_level, int max_level, sc_MPI_Comm comm = sc_MPI_COMM_WORLD)
-        : SyntheticMeshManager(arrays_of(synth_mesh), comm) {
+    /// `lowest_level` / `highest_level` bound adapt() (the class constants min_level / max_level by default).
+    explicit MeshManager(void* synth_mesh, int lowest_level = min_level, int highest_level = max_level,
+                         sc_MPI_Comm comm = sc_MPI_COMM_WORLD)
+        : MeshManager(arrays_of(synth_mesh), comm) {
       m_forest    = synth_mesh;
-      m_min_level = min_level;
-      m_max_level = max_level;
+      m_min_level = lowest_level;
+      m_max_level = highest_level;
+    }
+
+    /// mesh_manager.inl:76-122: `func(accessor, forest, tree_idx, element, e_idx)` fills the variables of element
+    /// e_idx in a HOST accessor; all 26 planes are zeroed, Step 0 and the volume uploaded. With the synthetic provider
+    /// `forest` is its handle, tree_idx 0 and `element` a SyntheticElement (see synthetic_element()).
+    template<typename Func>
+    void initialize_variables(Func func) {
+      const size_t n = static_cast<size_t>(m_num_local_elements);
+      std::array<std::vector<float_type>, nb_variables> host_variables{};
+      std::array<float_type*, nb_variables>             array{};
+      for (size_t k = 0; k < static_cast<size_t>(nb_variables); k++) {
+        host_variables[k].resize(n);
+        array[k] = host_variables[k].data();
+      }
+      MemoryAccessorOwn<VariableType> host_variable_memory{array};
+      std::vector<float_type>         element_volume(n + static_cast<size_t>(m_num_ghost_elements), float_type(1));
+      for (size_t e = 0; e < n; e++) {
+        SyntheticElement el{{m_centres[3 * e], m_centres[3 * e + 1], m_centres[3 * e + 2]}, m_levels[e], m_host.volumes[e]};
+        element_volume[e] = static_cast<float_type>(el.volume);
+        func(host_variable_memory, reinterpret_cast<t8_forest_t>(m_forest), t8_locidx_t{0},
+             reinterpret_cast<t8_element_t const*>(&el), static_cast<t8_locidx_t>(e));
+      }
+      for (size_t g = n; g < element_volume.size(); g++) element_volume[g] = static_cast<float_type>(m_host.volumes[g]);
+      // every plane of every step zeroed one by one (the reference memsets 26*N values from plane 0, valid only while
+      // capacity == size: SURVEY quirk Q10)
+      std::vector<float_type> zeros(n + static_cast<size_t>(m_num_ghost_elements), float_type(0));
+      for (size_t st = 0; st < nb_steps; st++)
+        for (size_t k = 0; k < static_cast<size_t>(nb_variables); k++)
+          this->set_variable(static_cast<step_index_type>(st), static_cast<variable_index_type>(k), zeros);
+      for (size_t k = 0; k < static_cast<size_t>(nb_variables); k++) {
+        host_variables[k].resize(zeros.size(), float_type(0));
+        this->set_variable(static_cast<step_index_type>(0), static_cast<variable_index_type>(k), host_variables[k]);
+      }
+      this->set_volume(element_volume);
+    }
+
+    /// mesh_manager.h:297 (the reference's signature); criteria above 10 refine, families below it coarsen
+    void adapt(thrust::host_vector<float_type> const& refinement_criteria, step_index_type step) {
+      adapt(std::vector<float_type>(refinement_criteria.begin(), refinement_criteria.end()), step);
+    }
+
+    /// mesh_manager.inl:626-723. One process drives one GPU and, in this header-level API, one rank's share that was
+    /// partitioned when the arrays were made: on a single rank t8_forest_partition is the identity, so this keeps
+    /// `step` and returns. (SFC repartition of a multi-rank run: t8gpu_amd/amr.py PartitionedAdapt over RCCL.)
+    void partition(step_index_type /*step*/) {
+      if (m_nb_ranks > 1) {
+        std::fprintf(stderr, "t8gpu: MeshManager::partition across ranks is driven by the RCCL repartition (amr.PartitionedAdapt)\n");
+        std::abort();
+      }
+    }
+
+    /// mesh_manager.inl:333-481: face lists, normals, areas, ghost slots of the current forest -> device arrays.
+    /// adapt() already leaves them current; calling this again is harmless (the reference requires the call).
+    void compute_connectivity_information() {
+      if (m_forest) rebuild_connectivity(arrays_of(m_forest));
     }
 
     /// MeshManager::adapt (mesh_manager.inl:196-330), single rank: the reference's adapt callback on the criteria
@@ -196,13 +291,13 @@ namespace t8gpu {
     [[nodiscard]] void const* forest() const { return m_forest; }
     [[nodiscard]] HostMeshArrays const& host_arrays() const { return m_host; }
 
-    ~SyntheticMeshManager() {
+    ~MeshManager() {
       if (m_forest) t8gpu_synth_mesh_destroy(m_forest);
       free_connectivity();
       (void)hipFree(m_staging);
     }
-    SyntheticMeshManager(SyntheticMeshManager const&)            = delete;
-    SyntheticMeshManager& operator=(SyntheticMeshManager const&) = delete;
+    MeshManager(MeshManager const&)            = delete;
+    MeshManager& operator=(MeshManager const&) = delete;
 
     [[nodiscard]] MeshConnectivityAccessor<float_type, dim> get_connectivity_information() const {
       return {m_ranks, m_indices, m_face_neighbors, m_face_normals, m_face_surfaces, m_num_local_faces, m_num_local_boundary_faces};
@@ -214,10 +309,17 @@ namespace t8gpu {
 
     /// Named host array of doubles ready for the writer (mesh_manager.h: HostVariableInfo).
     struct HostVariableInfo {
-      int                       m_type;  // T8GPU_VTK_SCALAR | T8GPU_VTK_VECTOR
+      int                       m_type = T8GPU_VTK_SCALAR;  // T8GPU_VTK_SCALAR | T8GPU_VTK_VECTOR
       std::unique_ptr<double[]> m_data;
       std::string               m_name;
     };
+
+    /// mesh_manager.h:326: one variable in one file
+    void save_variable_to_vtk(step_index_type step, variable_index_type variable, std::string const& prefix) const {
+      std::vector<HostVariableInfo> v;
+      v.push_back(get_host_scalar_variable(step, variable, "variable"));
+      save_variables_to_vtk(std::move(v), prefix);
+    }
 
     /// mesh_manager.inl:516-545: one variable of one step, cast to double (on the device), on the host.
     [[nodiscard]] HostVariableInfo get_host_scalar_variable(step_index_type step, variable_index_type variable,
@@ -266,8 +368,11 @@ namespace t8gpu {
     }
 
    private:
+    using MemoryManager<VariableType, StepType>::resize;   // private here, as in the reference (mesh_manager.h:425)
+
     void*          m_forest    = nullptr;   // synthetic forest (owned) when constructed from one
-    int            m_min_level = 0, m_max_level = 0;
+    int            m_min_level = min_level, m_max_level = max_level;
+    int            m_nb_ranks  = 1;
     HostMeshArrays m_host;
 
     /// HostMeshArrays of a synthetic forest on one rank: connectivity through the forest-query adapter, plus the
@@ -292,6 +397,14 @@ namespace t8gpu {
                                      nullptr, nullptr, nullptr);
       t8gpu_host_connectivity_destroy(h);
       t8gpu_synth_query_destroy(q);
+      if constexpr (dim != 3) {   // the adapter hands out xyz; MeshConnectivityAccessor<ft, dim> strides by `dim`
+        static_assert(dim == 2, "face normals have 2 or 3 components");
+        const size_t        nf = static_cast<size_t>(c[2] + c[3]);
+        std::vector<double> nd(dim * nf);
+        for (size_t i = 0; i < nf; i++)
+          for (size_t k = 0; k < dim; k++) nd[dim * i + k] = m.face_normals[3 * i + k];
+        m.face_normals.swap(nd);
+      }
       void* part = t8gpu_synth_part_create(forest, 0, 1, 0, 3);
       m.mesh_dim = t8gpu_synth_mesh_dim(forest);
       m.levels.resize(c[0]);
@@ -364,6 +477,10 @@ namespace t8gpu {
       if (!src.empty()) T8GPU_CUDA_CHECK_ERROR(hipMemcpy(dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
     }
   };
+
+  /// earlier name of the class when it is built from the synthetic provider or from host arrays
+  template<typename VariableType, typename StepType, size_t dim>
+  using SyntheticMeshManager = MeshManager<VariableType, StepType, dim>;
 
 }  // namespace t8gpu
 

@@ -4,10 +4,13 @@
 // Subgrid mesh with the getters of the reference (t8gpu/mesh/subgrid_mesh_manager.h:29-216): the plain
 // arrays plus face_level_difference[F] (level(right) - level(left) <= 0) and face_neighbor_offset[rank*F]
 // (anchor inside the right block; subgrid_mesh_manager.inl:587-680). Normals have SubgridType::rank
-// components. SyntheticSubgridMeshManager<V, S, Subgrid>: SubgridMemoryManager + those arrays from host vectors, with
-// the part of SubgridMeshManager's interface the hot path and the output step use (subgrid_mesh_manager.h:288-462):
-// get_connectivity_information(), get_num_local_{elements,faces,boundary_faces}(), save_variable_to_vtk(),
-// save_mesh_to_vtk(). The t8code-bound constructor / adapt / partition need t8code.
+// components. SubgridMeshManager<V, S, Subgrid>: the class of the reference (subgrid_mesh_manager.h:266-509) with
+// the same public members (constructor (comm, scheme, cmesh, forest), initialize_variables, adapt, partition,
+// compute_connectivity_information, save_variable_to_vtk, save_mesh_to_vtk, HostVariableInfo, get_host_*,
+// save_variables_to_vtk, get_connectivity_information, get_num_*, min_level / max_level) on top of
+// SubgridMemoryManager. As for MeshManager (mesh_manager.h) the t8code constructor is declared for every build and
+// defined by the t8code adapter only; the synthetic forest / host arrays constructors make the class usable here,
+// and SyntheticSubgridMeshManager is an alias kept for the earlier name.
 #ifndef T8GPU_HIP_MESH_SUBGRID_MESH_MANAGER_H
 #define T8GPU_HIP_MESH_SUBGRID_MESH_MANAGER_H
 
@@ -90,15 +93,28 @@ namespace t8gpu {
   };
 
   template<typename VariableType, typename StepType, typename SubgridType>
-  class SyntheticSubgridMeshManager : public SubgridMemoryManager<VariableType, StepType, SubgridType> {
+  class SubgridMeshManager : public SubgridMemoryManager<VariableType, StepType, SubgridType> {
    public:
-    using float_type          = typename variable_traits<VariableType>::float_type;
-    using variable_index_type = typename variable_traits<VariableType>::index_type;
-    using step_index_type     = typename step_traits<StepType>::index_type;
+    using float_type                  = typename variable_traits<VariableType>::float_type;
+    using variable_index_type         = typename variable_traits<VariableType>::index_type;
+    static constexpr int nb_variables = variable_traits<VariableType>::nb_variables;
+    static constexpr int dim          = SubgridType::rank;
 
-    explicit SyntheticSubgridMeshManager(HostSubgridMeshArrays const& m, sc_MPI_Comm comm = sc_MPI_COMM_WORLD)
+    using step_index_type            = typename step_traits<StepType>::index_type;
+    static constexpr size_t nb_steps = step_traits<StepType>::nb_steps;
+
+    static constexpr t8_locidx_t min_level = 1;   // subgrid_mesh_manager.h:276-277
+    static constexpr t8_locidx_t max_level = 6;
+
+    /// subgrid_mesh_manager.h:288 / .inl:20-75: takes ownership of cmesh and forest. Declared for every build, DEFINED
+    /// by the t8code adapter only; see MeshManager.
+    SubgridMeshManager(sc_MPI_Comm comm, t8_scheme_cxx_t* scheme, t8_cmesh_t cmesh, t8_forest_t forest);
+
+    explicit SubgridMeshManager(HostSubgridMeshArrays const& m, sc_MPI_Comm comm = sc_MPI_COMM_WORLD)
         : SubgridMemoryManager<VariableType, StepType, SubgridType>(static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements, comm),
           m_host{m} {
+      int comm_rank = 0;
+      detail::comm_layout(comm, comm_rank, m_nb_ranks);
       rebuild_connectivity(m);
       const size_t            tot = static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements;
       std::vector<float_type> vol(m.volumes.begin(), m.volumes.end());
@@ -107,11 +123,57 @@ namespace t8gpu {
     }
     /// From a synthetic forest (owned afterwards): stands for SubgridMeshManager(comm, scheme, cmesh, forest)
     /// (subgrid_mesh_manager.inl:3-60); connectivity through the forest-query adapter.
-    explicit SyntheticSubgridMeshManager(void* synth_mesh, int min_level, int max_level, sc_MPI_Comm comm = sc_MPI_COMM_WORLD)
-        : SyntheticSubgridMeshManager(arrays_of(synth_mesh), comm) {
+    explicit SubgridMeshManager(void* synth_mesh, int lowest_level = min_level, int highest_level = max_level,
+                                sc_MPI_Comm comm = sc_MPI_COMM_WORLD)
+        : SubgridMeshManager(arrays_of(synth_mesh), comm) {
       m_forest    = synth_mesh;
-      m_min_level = min_level;
-      m_max_level = max_level;
+      m_min_level = lowest_level;
+      m_max_level = highest_level;
+    }
+
+    /// subgrid_mesh_manager.inl:144-194: `func(accessor, forest, tree_idx, element, e_idx)` fills ONE value per
+    /// variable and block in a host MemoryAccessorOwn; every subcell of the block gets that value in Step 0
+    /// (copy_variables_coarse_mesh_to_fine). With the synthetic provider `element` is a SyntheticElement.
+    template<typename Func>
+    void initialize_variables(Func func) {
+      constexpr size_t S = SubgridType::size;
+      const size_t     n = static_cast<size_t>(m_host.num_local_elements), tot = n + static_cast<size_t>(m_host.num_ghost_elements);
+      std::array<std::vector<float_type>, nb_variables> coarse{};
+      std::array<float_type*, nb_variables>             array{};
+      for (size_t k = 0; k < static_cast<size_t>(nb_variables); k++) {
+        coarse[k].resize(n);
+        array[k] = coarse[k].data();
+      }
+      MemoryAccessorOwn<VariableType> host_variable_memory{array};
+      for (size_t e = 0; e < n; e++) {
+        SyntheticElement el{{m_host.centres[3 * e], m_host.centres[3 * e + 1], m_host.centres[3 * e + 2]}, m_host.levels[e],
+                            m_host.volumes[e]};
+        func(host_variable_memory, reinterpret_cast<t8_forest_t>(m_forest), t8_locidx_t{0},
+             reinterpret_cast<t8_element_t const*>(&el), static_cast<t8_locidx_t>(e));
+      }
+      std::vector<float_type> fine(tot * S, float_type(0));
+      for (size_t k = 0; k < static_cast<size_t>(nb_variables); k++) {
+        for (size_t e = 0; e < n; e++) std::fill(fine.begin() + e * S, fine.begin() + (e + 1) * S, coarse[k][e]);
+        this->set_variable(static_cast<step_index_type>(0), static_cast<variable_index_type>(k), fine);
+      }
+    }
+
+    /// subgrid_mesh_manager.h:327 (the reference's signature)
+    void adapt(thrust::host_vector<float_type> const& refinement_criteria, step_index_type step) {
+      adapt(std::vector<float_type>(refinement_criteria.begin(), refinement_criteria.end()), step);
+    }
+
+    /// subgrid_mesh_manager.inl:1217-1369; identity on one rank (see MeshManager::partition)
+    void partition(step_index_type /*step*/) {
+      if (m_nb_ranks > 1) {
+        std::fprintf(stderr, "t8gpu: SubgridMeshManager::partition across ranks is driven by the RCCL repartition (amr.PartitionedSubgridAdapt)\n");
+        std::abort();
+      }
+    }
+
+    /// subgrid_mesh_manager.inl:560-961: coarse-face lists, level differences, neighbour offsets -> device arrays
+    void compute_connectivity_information() {
+      if (m_forest) rebuild_connectivity(arrays_of(m_forest));
     }
 
     /// SubgridMeshManager::adapt (subgrid_mesh_manager.inl:428-558), single rank: adapt callback on the per-block
@@ -166,15 +228,15 @@ namespace t8gpu {
     }
     [[nodiscard]] void const* forest() const { return m_forest; }
 
-    ~SyntheticSubgridMeshManager() {
+    ~SubgridMeshManager() {
       if (m_forest) t8gpu_synth_mesh_destroy(m_forest);
       for (void* p : {static_cast<void*>(m_ranks), static_cast<void*>(m_indices), static_cast<void*>(m_face_neighbors),
                       static_cast<void*>(m_level_difference), static_cast<void*>(m_neighbor_offset), static_cast<void*>(m_face_normals),
                       static_cast<void*>(m_face_surfaces), static_cast<void*>(m_scratch), static_cast<void*>(m_scratch64)})
         (void)hipFree(p);
     }
-    SyntheticSubgridMeshManager(SyntheticSubgridMeshManager const&)            = delete;
-    SyntheticSubgridMeshManager& operator=(SyntheticSubgridMeshManager const&) = delete;
+    SubgridMeshManager(SubgridMeshManager const&)            = delete;
+    SubgridMeshManager& operator=(SubgridMeshManager const&) = delete;
 
     [[nodiscard]] SubgridMeshConnectivityAccessor<float_type, SubgridType> get_connectivity_information() const {
       return {m_ranks, m_indices, m_face_neighbors, m_level_difference, m_neighbor_offset, m_face_normals, m_face_surfaces,
@@ -186,32 +248,66 @@ namespace t8gpu {
     [[nodiscard]] t8_locidx_t get_num_local_boundary_faces() const { return m_host.num_local_boundary_faces; }
     [[nodiscard]] HostSubgridMeshArrays const& host_arrays() const { return m_host; }
 
-    /// subgrid_mesh_manager.inl:1051-1138: the variable on the forest refined uniformly twice (z-order), field "variables"
-    void save_variable_to_vtk(step_index_type step, variable_index_type variable, std::string const& prefix) {
+    /// Named host array of doubles ready for the writer (subgrid_mesh_manager.h:387-423: HostVariableInfo)
+    struct HostVariableInfo {
+      int                       m_type = T8GPU_VTK_SCALAR;  // T8GPU_VTK_SCALAR | T8GPU_VTK_VECTOR
+      std::unique_ptr<double[]> m_data;
+      std::string               m_name;
+    };
+
+    /// subgrid_mesh_manager.h:426. One variable of one step on the host: every subcell, in the z-order of the forest
+    /// refined log2(extent) times, as doubles (z-order + cast on the device, one D2H copy). The reference copies the
+    /// first num_local_elements values of the block-major array only (subgrid_mesh_manager.inl:1138-1157) and its
+    /// save_variables_to_vtk is commented out (:1181-1206); this is the field those two were written to deliver.
+    [[nodiscard]] HostVariableInfo get_host_scalar_variable(step_index_type step, variable_index_type variable,
+                                                            std::string const& name) const {
       const size_t n = static_cast<size_t>(m_host.num_local_elements) * SubgridType::size;
-      if (!m_scratch) T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_scratch, sizeof(float_type) * (n ? n : 1)));
-      if (!m_scratch64) T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_scratch64, sizeof(double) * (n ? n : 1)));
-      float_type const* src = static_cast<float_type const*>(this->get_own_variable(step, variable));
-      if constexpr (std::is_same_v<float_type, double>) {
-        T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_column_major_to_z_order_f64(SubgridType::rank, m_host.num_local_elements, src, m_scratch, nullptr)));
-        T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_host_scalar_variable_f64(n, m_scratch, m_scratch64, nullptr)));
-      } else {
-        T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_column_major_to_z_order_f32(SubgridType::rank, m_host.num_local_elements, src, m_scratch, nullptr)));
-        T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_host_scalar_variable_f32(n, m_scratch, m_scratch64, nullptr)));
+      std::unique_ptr<double[]> h = std::make_unique<double[]>(n ? n : 1);
+      z_order_doubles(step, variable);
+      T8GPU_CUDA_CHECK_ERROR(hipMemcpy(h.get(), m_scratch64, sizeof(double) * n, hipMemcpyDeviceToHost));
+      return {T8GPU_VTK_SCALAR, std::move(h), name};
+    }
+    /// subgrid_mesh_manager.h:438: three variables as interleaved xyz doubles per subcell (same ordering as above)
+    [[nodiscard]] HostVariableInfo get_host_vector_variable(step_index_type step, std::array<variable_index_type, 3> variables,
+                                                            std::string const& name) const {
+      const size_t n = static_cast<size_t>(m_host.num_local_elements) * SubgridType::size;
+      std::unique_ptr<double[]> h = std::make_unique<double[]>(3 * n ? 3 * n : 1);
+      std::vector<double>       one(n);
+      for (int c = 0; c < 3; c++) {
+        z_order_doubles(step, variables[c]);
+        T8GPU_CUDA_CHECK_ERROR(hipMemcpy(one.data(), m_scratch64, sizeof(double) * n, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) h[3 * i + c] = one[i];
       }
-      std::vector<double> host(n);
-      T8GPU_CUDA_CHECK_ERROR(hipMemcpy(host.data(), m_scratch64, sizeof(double) * n, hipMemcpyDeviceToHost));
-      char const*   name = "variables";
-      const int32_t comp = 1;
-      double const* data = host.data();
-      write(prefix, 4, 1, &name, &comp, &data);
+      return {T8GPU_VTK_VECTOR, std::move(h), name};
+    }
+    /// subgrid_mesh_manager.h:446: all fields in one file, on the forest refined down to the subcells
+    void save_variables_to_vtk(std::vector<HostVariableInfo> host_variables, std::string const& prefix) const {
+      std::vector<char const*>   names;
+      std::vector<int32_t>       comps;
+      std::vector<double const*> data;
+      for (auto const& h : host_variables) {
+        names.push_back(h.m_name.c_str());
+        comps.push_back(h.m_type);
+        data.push_back(h.m_data.get());
+      }
+      write(prefix, SubgridType::template extent<0>, static_cast<int>(names.size()), names.data(), comps.data(), data.data());
+    }
+
+    /// subgrid_mesh_manager.inl:1051-1138: the variable on the forest refined uniformly twice (z-order), field "variables"
+    void save_variable_to_vtk(step_index_type step, variable_index_type variable, std::string const& prefix) const {
+      std::vector<HostVariableInfo> v;
+      v.push_back(get_host_scalar_variable(step, variable, "variables"));
+      save_variables_to_vtk(std::move(v), prefix);
     }
     /// subgrid_mesh_manager.inl:1185-1206: the forest itself, no data
     void save_mesh_to_vtk(std::string const& prefix) const { write(prefix, 1, 0, nullptr, nullptr, nullptr); }
 
    private:
+    using SubgridMemoryManager<VariableType, StepType, SubgridType>::resize;   // subgrid_mesh_manager.h:466
+
     void* m_forest    = nullptr;
-    int   m_min_level = 0, m_max_level = 0;
+    int   m_min_level = min_level, m_max_level = max_level;
+    int   m_nb_ranks  = 1;
 
     static HostSubgridMeshArrays arrays_of(void* forest) {
       constexpr int     R = SubgridType::rank;
@@ -276,8 +372,24 @@ namespace t8gpu {
     t8_locidx_t*          m_neighbor_offset  = nullptr;
     float_type*           m_face_normals     = nullptr;
     float_type*           m_face_surfaces    = nullptr;
-    float_type*           m_scratch          = nullptr;
-    double*               m_scratch64        = nullptr;
+    mutable float_type*   m_scratch          = nullptr;   // z-ordered copy of one variable (float_type / double)
+    mutable double*       m_scratch64        = nullptr;
+
+    /// column_major_to_z_order (subgrid_mesh_manager.inl:1008-1049) + cast: `variable` of `step` -> m_scratch64
+    void z_order_doubles(step_index_type step, variable_index_type variable) const {
+      const size_t n = static_cast<size_t>(m_host.num_local_elements) * SubgridType::size;
+      if (!m_scratch) T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_scratch, sizeof(float_type) * (n ? n : 1)));
+      if (!m_scratch64) T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_scratch64, sizeof(double) * (n ? n : 1)));
+      float_type const* src = static_cast<float_type const*>(this->get_own_variable(step, variable));
+      if constexpr (std::is_same_v<float_type, double>) {
+        T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_column_major_to_z_order_f64(SubgridType::rank, m_host.num_local_elements, src, m_scratch, nullptr)));
+        T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_host_scalar_variable_f64(n, m_scratch, m_scratch64, nullptr)));
+      } else {
+        T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_column_major_to_z_order_f32(SubgridType::rank, m_host.num_local_elements, src, m_scratch, nullptr)));
+        T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_host_scalar_variable_f32(n, m_scratch, m_scratch64, nullptr)));
+      }
+      T8GPU_CUDA_CHECK_ERROR(hipDeviceSynchronize());
+    }
 
     void write(std::string const& prefix, int cells_per_dim, int nf, char const* const* names, int32_t const* comps,
                double const* const* data) const {
@@ -296,6 +408,10 @@ namespace t8gpu {
       if (!src.empty()) T8GPU_CUDA_CHECK_ERROR(hipMemcpy(dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
     }
   };
+
+  /// earlier name of the class when it is built from the synthetic provider or from host arrays
+  template<typename VariableType, typename StepType, typename SubgridType>
+  using SyntheticSubgridMeshManager = SubgridMeshManager<VariableType, StepType, SubgridType>;
 
 }  // namespace t8gpu
 

@@ -26,7 +26,8 @@ def main():
         path = os.path.join(dst, "traffic.json")
         allt = json.load(open(path)) if os.path.exists(path) else {}
         allt[f"{workload}|{dtype}|{flux}|{mode}"] = {"hbm_bytes_per_launch": int(t["avg_hbm_bytes_per_launch"]), "kernels": t["kernels"],
-                                                     "source": f"profiles/{tag}.md", "method": t["method"]}
+                                                     "source": f"profiles/{tag}.md", "method": t["method"],
+                                                     "valu_busy": t.get("valu_busy"), "lds_conflict_frac": t.get("lds_conflict_frac")}
         json.dump(allt, open(path, "w"), indent=1)
         print(f"{workload}|{dtype}|{flux}|{mode}: {int(t['avg_hbm_bytes_per_launch'])} B per launch")
 

@@ -63,12 +63,25 @@ def main(out):
         for k in dom:
             fs, ws = fetch[k]["FETCH_SIZE"], write[k]["WRITE_SIZE"]
             tot += (2 * (fs[0] / fs[1] if fs[1] else 0.0) + (ws[0] / ws[1] if ws[1] else 0.0)) * 1024
+        # utilisation from the SQ pass (MI355X_MICROARCH.md: SQ_* count quad-cycles summed over the chip's 1024 SIMDs;
+        # GRBM_GUI_ACTIVE is the sum over the 8 XCDs): VALU busy = ACTIVE_INST_VALU * 4 / 1024 / (GUI_ACTIVE / 8)
+        def mean(k, n):
+            return sq[k][n][0] / sq[k][n][1] if sq[k][n][1] else 0.0
+        busy, confl = [], []
+        for k in dom:
+            gui = mean(k, "GRBM_GUI_ACTIVE") / 8.0
+            if gui > 0:
+                busy.append(mean(k, "SQ_ACTIVE_INST_VALU") * 4.0 / 1024.0 / gui)
+            if mean(k, "SQ_LDS_IDX_ACTIVE") > 0:
+                confl.append(mean(k, "SQ_LDS_BANK_CONFLICT") / mean(k, "SQ_LDS_IDX_ACTIVE"))
         with open(os.path.join(out, "traffic.json"), "w") as fjs:
             json.dump({"kernels": dom, "avg_hbm_bytes_per_launch": tot / len(dom),
+                       "valu_busy": round(sum(busy) / len(busy), 4) if busy else None,
+                       "lds_conflict_frac": round(sum(confl) / len(confl), 4) if confl else None,
                        "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 (gfx950), KiB -> bytes"}, fjs)
     print("\n## SQ counters per launch (averages)\n")
     names = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
-             "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]
+             "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE"]
     print("| kernel | " + " | ".join(n.replace("SQ_", "") for n in names) + " |\n|---|" + "---|" * len(names))
     for k in sorted(sq):
         vals = [sq[k][n][0] / sq[k][n][1] if sq[k][n][1] else 0.0 for n in names]

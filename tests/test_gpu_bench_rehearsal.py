@@ -15,9 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def run_bench(world, extra):
     env = dict(os.environ, T8GPU_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", str(29610 + world), os.path.join(ROOT, "bench.py"),
-           "--gpus", str(world), "--steps", "3", "--warmup", "1", "--prewarm-seconds", "0.05"] + extra
+    # the plain command, as the driver issues it: bench.py starts its own N ranks (a child torchrun)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
+           "--reps", "2", "--prewarm-seconds", "0.05"] + extra
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -29,7 +31,8 @@ def run_bench(world, extra):
 @pytest.mark.parametrize("world,workload", [(2, "c1"), (3, "c2")])
 def test_bench_multirank_rehearsal(world, workload):
     rec = run_bench(world, ["--workload", workload])
-    assert rec["n_gpus"] == world and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["n_gpus"] == world and rec["steps"] == 3 and rec["warmup"] == 1 and rec["repetitions"] == 2
+    assert rec["ms_per_step_min"] <= rec["ms_per_step"] <= rec["ms_per_step_max"]
     assert rec["scaling"] == "strong" and rec["higher_is_better"] is True and rec["vs_baseline"] is None
     assert rec["config"]["finite"] is True
     assert rec["config"]["partition"] == f"sfc-contiguous x{world}"
@@ -81,3 +84,23 @@ def test_bench_distributed_path_on_real_rccl_with_one_rank(workload):
         assert rec["config"]["halo"] == "native rccl (C++ stepper)" and rec["config"]["driver"] == "native C++ stepper"
     else:
         assert rec["config"]["halo"] == "torch.distributed"            # Subgrid runs use the python-driven stages
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    """WORLD_SIZE != --gpus is an error, not a silently mislabelled run (needs no GPU: it exits before any GPU call)."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr
+
+
+def test_bench_self_launch_reports_missing_gpus():
+    """`python bench.py --gpus N` starts its own ranks; with fewer than N GPUs visible it says so and returns 2
+    (before any GPU call, so this runs on the CPU-only build container too)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "T8GPU_REHEARSAL")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 2 and "needs 2 GPUs" in out.stderr
