@@ -144,7 +144,7 @@ int main() {
     }
     // the mesh-manager face of the same arrays: accessor counts and the VTK members (subgrid_mesh_manager.inl:1051-1206)
     {
-      SyntheticSubgridMeshManager<VariableList, StepList, Grid3> mm(m);
+      SubgridMeshManager<VariableList, StepList, Grid3> mm(m);   // the reference's class name (subgrid_mesh_manager.h:266)
       if (mm.get_num_local_elements() != N || mm.get_connectivity_information().get_num_local_faces() != F) return 3;
       for (int v = 0; v < 5; v++)
         mm.set_variable(Step0, static_cast<VariableList>(v),
@@ -153,6 +153,11 @@ int main() {
       if (out) {
         mm.save_variable_to_vtk(Step0, Rho, std::string(out) + "_rho");
         mm.save_mesh_to_vtk(std::string(out) + "_mesh");
+        // get_host_{scalar,vector}_variable + save_variables_to_vtk (subgrid_mesh_manager.h:426-446)
+        std::vector<SubgridMeshManager<VariableList, StepList, Grid3>::HostVariableInfo> fields;
+        fields.push_back(mm.get_host_scalar_variable(Step0, Rho, "density"));
+        fields.push_back(mm.get_host_vector_variable(Step0, {Rho_v1, Rho_v2, Rho_v3}, "momentum"));
+        mm.save_variables_to_vtk(std::move(fields), std::string(out) + "_fields");
       }
     }
     for (void* p : {static_cast<void*>(fn), static_cast<void*>(ld), static_cast<void*>(off), static_cast<void*>(nrm), static_cast<void*>(ars)}) (void)hipFree(p);
@@ -167,7 +172,27 @@ int main() {
   // ---- SubgridMeshManager::adapt in C++ (subgrid_mesh_manager.inl:428-558): criteria kernel, forest adapt, block-wise
   //      transfer, new connectivity, fused steps on the new mesh; mass must be kept ---------------------------------
   {
-    SyntheticSubgridMeshManager<VariableList, StepList, Grid3> mm(t8gpu_synth_mesh_create(3, 2, 2, 0.0, 1.0, 1), 1, 3);
+    using SubgridManager = SubgridMeshManager<VariableList, StepList, Grid3>;
+    static_assert(SubgridManager::dim == 3 && SubgridManager::nb_variables == 5 && SubgridManager::max_level == 6);
+    SubgridManager mm(t8gpu_synth_mesh_create(3, 2, 2, 0.0, 1.0, 1), 1, 3);
+    // initialize_variables (subgrid_mesh_manager.inl:144-194): one value per block, broadcast to its 64 subcells
+    mm.initialize_variables([](MemoryAccessorOwn<VariableList>& accessor, t8_forest_t, t8_locidx_t, t8_element_t const* element,
+                               t8_locidx_t e_idx) {
+      auto [rho, rho_e] = accessor.get(Rho, Rho_e);
+      rho[e_idx]        = synthetic_element(element).centre[2] < 0.5 ? float_type(2) : float_type(1);
+      rho_e[e_idx]      = float_type(6.25) + float_type(synthetic_element(element).level);
+    });
+    {
+      const size_t            n = static_cast<size_t>(mm.get_num_local_elements()) * 64;
+      std::vector<float_type> h(n);
+      T8GPU_CUDA_CHECK_ERROR(hipMemcpy(h.data(), static_cast<float_type*>(mm.get_own_variable(Step0, Rho)), sizeof(float_type) * n, hipMemcpyDeviceToHost));
+      int twos = 0;
+      for (size_t i = 0; i < n; i++) {
+        if (h[i] != h[i - i % 64] || (h[i] != float_type(1) && h[i] != float_type(2))) return 4;   // constant per block
+        twos += h[i] == float_type(2);
+      }
+      if (2 * static_cast<size_t>(twos) != n) return 5;                                               // lower half of the cube
+    }
     auto fill_ic = [&]() {
       void*        part = t8gpu_synth_part_create(mm.forest(), 0, 1, 1, 3);
       const size_t n    = static_cast<size_t>(mm.get_num_local_elements()) * 64;
@@ -194,7 +219,9 @@ int main() {
     std::vector<float_type> hc(n0);
     T8GPU_CUDA_CHECK_ERROR(hipMemcpy(hc.data(), crit, sizeof(float_type) * n0, hipMemcpyDeviceToHost));
     (void)hipFree(crit);
-    mm.adapt(hc, Step0);
+    mm.adapt(thrust::host_vector<float_type>(hc.begin(), hc.end()), Step0);   // the reference's signature
+    mm.partition(Step0);
+    mm.compute_connectivity_information();
     const int    n1 = mm.get_num_local_elements();
     const double m1 = mass(Step0);
     hip::SubgridFusedPlan<float_type> plan(mm.host_arrays());

@@ -1,4 +1,5 @@
-"""Writes survey_8c_kat.json from the literals recorded in SURVEY.md section 8c (no reference run)."""
+"""Dumps the three known-answer literals recorded in SURVEY.md section 8c into survey_8c_kat.json (NOT a generator: no
+reference run; the generated vectors are make_reference_vectors.py -> reference_flux_vectors.npz)."""
 import json
 import os
 

@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/reference_flux_vectors.npz: outputs of the REFERENCE's own flux arithmetic on seeded inputs.
+
+Runs in the BUILD container only (it needs /root/reference; the GPU box has neither the tree nor any use for this
+script -- tests read the committed .npz). What it does, exactly as SURVEY.md section 8c describes:
+
+  * reads lines 1-332 of /root/reference/examples/subgrid/kernels.inl (ln_mean, kepes_compute_flux,
+    kepes_compute_diffusion_matrix, complete_orthonormal_basis, rotate_state, reflect_state, inverse_rotate_state,
+    compute_total_kepes_flux, compute_total_hll_flux) into a TEMPORARY directory -- nothing of the reference is
+    written into this repository, only the numbers it produces;
+  * compiles them for the host with `g++ -std=c++17 -O0 -ffp-contract=off` behind three empty macros
+    (__device__, __host__, __global__), `using std::{min,max,abs,sqrt,log}` and a 5-line stand-in for
+    t8gpu::variable_traits + the VariableList enum (the fragment's only outside dependencies), once with
+    float_type = float and once with double;
+  * feeds it seeded state pairs: generic (rho in [0.5,2], v in [-1,1]^3, p in [0.5,5]), near-equal pairs
+    (the u < 1e-4 series branch of ln_mean), strong jumps (pressure / density ratios up to 1e3), supersonic pairs,
+    and for the xyz pipeline axis-aligned and oblique unit normals, interior faces and reflective walls;
+  * stores inputs and outputs as arrays.
+
+Because the build uses a stand-in for variable_traits this does not count as a reference build under the project
+rules (parity stays "unpinned"); it is the strongest evidence available, and
+tests/test_oracle_golden.py demands BIT-EXACT agreement of the oracle with every vector.
+
+Also records whether examples/compressible_euler/kernels.cu:24-133 (the plain example's copy of ln_mean /
+kepes_compute_flux / kepes_compute_diffusion_matrix) is textually identical to kernels.inl:21-130.
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+DRIVER = r"""
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+#define __device__
+#define __host__
+#define __global__
+using std::abs; using std::log; using std::max; using std::min; using std::sqrt;
+enum VariableList { Rho, Rho_v1, Rho_v2, Rho_v3, Rho_e, nb_variables };
+namespace t8gpu { template<typename V> struct variable_traits { using float_type = FT; }; }
+#include "ref_math.inl"
+template<class T> static std::vector<T> rd(const char* path) {
+  FILE* f = std::fopen(path, "rb"); if (!f) std::exit(2);
+  std::fseek(f, 0, SEEK_END); long n = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+  std::vector<T> v(n / sizeof(T)); if (std::fread(v.data(), sizeof(T), v.size(), f) != v.size()) std::exit(3);
+  std::fclose(f); return v;
+}
+template<class T> static void wr(const char* path, const std::vector<T>& v) {
+  FILE* f = std::fopen(path, "wb"); std::fwrite(v.data(), sizeof(T), v.size(), f); std::fclose(f);
+}
+int main(int argc, char** argv) {
+  // argv: dir
+  std::string d = argv[1];
+  {  // ln_mean
+    auto a = rd<FT>((d + "/lm_a.bin").c_str()), b = rd<FT>((d + "/lm_b.bin").c_str());
+    std::vector<FT> o(a.size());
+    for (size_t i = 0; i < a.size(); i++) o[i] = ln_mean<FT>(a[i], b[i]);
+    wr((d + "/lm_out.bin").c_str(), o);
+  }
+  {  // face-frame total fluxes
+    auto L = rd<FT>((d + "/ff_L.bin").c_str()), R = rd<FT>((d + "/ff_R.bin").c_str());
+    std::vector<FT> k(L.size()), h(L.size());
+    for (size_t i = 0; i < L.size() / 5; i++) {
+      FT l[5], r[5];
+      for (int c = 0; c < 5; c++) { l[c] = L[5 * i + c]; r[c] = R[5 * i + c]; }
+      compute_total_kepes_flux<FT>(l, r, &k[5 * i]);
+      for (int c = 0; c < 5; c++) { l[c] = L[5 * i + c]; r[c] = R[5 * i + c]; }
+      compute_total_hll_flux<FT>(l, r, &h[5 * i]);
+    }
+    wr((d + "/ff_kepes.bin").c_str(), k);
+    wr((d + "/ff_hll.bin").c_str(), h);
+  }
+  {  // xyz pipeline of the kernels (kernels.inl:382-400 interior, :960-975 wall): basis, rotate / reflect, flux, rotate back
+    auto N = rd<FT>((d + "/xyz_n.bin").c_str()), L = rd<FT>((d + "/xyz_L.bin").c_str()), R = rd<FT>((d + "/xyz_R.bin").c_str());
+    const size_t n = N.size() / 3;
+    std::vector<FT> t(6 * n), k(5 * n), h(5 * n), kw(5 * n), hw(5 * n);
+    for (size_t i = 0; i < n; i++) {
+      FT nn[3] = {N[3 * i], N[3 * i + 1], N[3 * i + 2]}, t1[3], t2[3], l[5], r[5], a[5], b[5], f[5];
+      complete_orthonormal_basis<FT>(nn, t1, t2);
+      for (int c = 0; c < 3; c++) { t[6 * i + c] = t1[c]; t[6 * i + 3 + c] = t2[c]; }
+      for (int c = 0; c < 5; c++) { l[c] = L[5 * i + c]; r[c] = R[5 * i + c]; }
+      rotate_state<FT>(nn, t1, t2, l, a); rotate_state<FT>(nn, t1, t2, r, b);
+      compute_total_kepes_flux<FT>(a, b, f); inverse_rotate_state<FT>(nn, t1, t2, f, &k[5 * i]);
+      rotate_state<FT>(nn, t1, t2, l, a); rotate_state<FT>(nn, t1, t2, r, b);
+      compute_total_hll_flux<FT>(a, b, f); inverse_rotate_state<FT>(nn, t1, t2, f, &h[5 * i]);
+      rotate_state<FT>(nn, t1, t2, l, a); reflect_state<FT>(nn, t1, t2, l, b);
+      compute_total_kepes_flux<FT>(a, b, f); inverse_rotate_state<FT>(nn, t1, t2, f, &kw[5 * i]);
+      rotate_state<FT>(nn, t1, t2, l, a); reflect_state<FT>(nn, t1, t2, l, b);
+      compute_total_hll_flux<FT>(a, b, f); inverse_rotate_state<FT>(nn, t1, t2, f, &hw[5 * i]);
+    }
+    wr((d + "/xyz_t.bin").c_str(), t);
+    wr((d + "/xyz_kepes.bin").c_str(), k); wr((d + "/xyz_hll.bin").c_str(), h);
+    wr((d + "/xyz_kepes_wall.bin").c_str(), kw); wr((d + "/xyz_hll_wall.bin").c_str(), hw);
+  }
+  return 0;
+}
+"""
+
+
+def conserved(rho, v, p):
+    e = p / 0.4 + 0.5 * rho * (v ** 2).sum(axis=1)
+    return np.column_stack([rho, rho[:, None] * v, e])
+
+
+def state_pairs(rng, n):
+    """n pairs in four families: generic, near-equal, strong jump, supersonic."""
+    q = n // 4
+    out_l, out_r = [], []
+    # generic (SURVEY 8d microbench distribution)
+    for _ in range(2):
+        rho, v, p = rng.uniform(0.5, 2, q), rng.uniform(-1, 1, (q, 3)), rng.uniform(0.5, 5, q)
+        (out_l if _ == 0 else out_r).append(conserved(rho, v, p))
+    # near-equal: relative perturbations 1e-12 .. 1e-2 (both sides of the u = 1e-4 switch of ln_mean), some exactly equal
+    rho, v, p = rng.uniform(0.5, 2, q), rng.uniform(-1, 1, (q, 3)), rng.uniform(0.5, 5, q)
+    eps = 10.0 ** rng.uniform(-12, -2, q) * rng.choice([-1, 1], q)
+    eps[: q // 16] = 0.0
+    out_l.append(conserved(rho, v, p))
+    out_r.append(conserved(rho * (1 + eps), v + eps[:, None] * rng.uniform(-1, 1, (q, 3)), p * (1 - 0.7 * eps)))
+    # strong jumps: ratios up to 1e3 in density and pressure
+    rho, v, p = rng.uniform(0.5, 2, q), rng.uniform(-1, 1, (q, 3)), rng.uniform(0.5, 5, q)
+    out_l.append(conserved(rho, v, p))
+    out_r.append(conserved(rho * 10.0 ** rng.uniform(-3, 3, q), rng.uniform(-2, 2, (q, 3)), p * 10.0 ** rng.uniform(-3, 3, q)))
+    # supersonic: |v| up to 10 at p ~ 1
+    r = n - 3 * q
+    rho, p = rng.uniform(0.5, 2, r), rng.uniform(0.5, 2, r)
+    out_l.append(conserved(rho, rng.uniform(-10, 10, (r, 3)), p))
+    out_r.append(conserved(rng.uniform(0.5, 2, r), rng.uniform(-10, 10, (r, 3)), rng.uniform(0.5, 2, r)))
+    return np.vstack(out_l), np.vstack(out_r)
+
+
+def unit_normals(rng, n):
+    nrm = rng.normal(size=(n, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    ax = n // 3
+    nrm[:ax] = np.eye(3)[rng.integers(0, 3, ax)] * rng.choice([-1.0, 1.0], (ax, 1))   # exact axis normals (quirk Q3)
+    nrm[ax:ax + n // 6, 2] = 0.0                                                        # 2D meshes: normals in the xy plane
+    nrm[ax:ax + n // 6] /= np.linalg.norm(nrm[ax:ax + n // 6], axis=1, keepdims=True)
+    return nrm
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("this generator needs the reference tree at /root/reference (build container only)")
+    src = open(os.path.join(REF, "examples/subgrid/kernels.inl")).read().split("\n")
+    math_lines = src[:332]
+    plain = open(os.path.join(REF, "examples/compressible_euler/kernels.cu")).read().split("\n")
+    norm = lambda ls: [re.sub(r"\s+", " ", x).strip() for x in ls if x.strip()]
+    duplicate = norm(plain[23:133]) == norm(src[20:130])
+    rng = np.random.default_rng(20261004)
+    n_ff, n_xyz, n_lm = 2048, 1024, 2048
+    L, R = state_pairs(rng, n_ff)
+    XL, XR = state_pairs(rng, n_xyz)
+    perm = rng.permutation(n_xyz)
+    XL, XR = XL[perm], XR[perm]
+    N = unit_normals(rng, n_xyz)
+    a = 10.0 ** rng.uniform(-3, 3, n_lm)
+    b = a * np.where(rng.random(n_lm) < 0.5, 1 + 10.0 ** rng.uniform(-14, -1, n_lm) * rng.choice([-1, 1], n_lm), 10.0 ** rng.uniform(-3, 3, n_lm))
+    b[:64] = a[:64]
+    out = {"lm_a": a, "lm_b": b, "ff_L": L, "ff_R": R, "xyz_n": N, "xyz_L": XL, "xyz_R": XR}
+    with tempfile.TemporaryDirectory(prefix="t8gpu_refvec_") as tmp:
+        open(os.path.join(tmp, "ref_math.inl"), "w").write("\n".join(math_lines) + "\n")
+        open(os.path.join(tmp, "driver.cpp"), "w").write(DRIVER)
+        res = {}
+        for ft, npdt, tag in (("double", np.float64, "f64"), ("float", np.float32, "f32")):
+            exe = os.path.join(tmp, "drv_" + tag)
+            subprocess.check_call(["g++", "-std=c++17", "-O0", "-ffp-contract=off", f"-DFT={ft}", "-I", tmp,
+                                   os.path.join(tmp, "driver.cpp"), "-o", exe])
+            d = os.path.join(tmp, tag)
+            os.makedirs(d)
+            for k, v in out.items():
+                np.ascontiguousarray(v, npdt).tofile(os.path.join(d, k + ".bin"))
+            subprocess.check_call([exe, d])
+            for k, cols in (("lm_out", 0), ("ff_kepes", 5), ("ff_hll", 5), ("xyz_t", 6), ("xyz_kepes", 5), ("xyz_hll", 5),
+                            ("xyz_kepes_wall", 5), ("xyz_hll_wall", 5)):
+                v = np.fromfile(os.path.join(d, k + ".bin"), npdt)
+                res[f"{k}_{tag}"] = v.reshape(-1, cols) if cols else v
+            for k, v in out.items():      # the inputs as the reference saw them (rounded to float_type)
+                res[f"{k}_{tag}"] = np.ascontiguousarray(v, npdt)
+    res["meta"] = np.array([
+        "reference: /root/reference/examples/subgrid/kernels.inl lines 1-332, host build g++ -std=c++17 -O0 -ffp-contract=off, "
+        "stand-in for t8gpu::variable_traits (parity stays 'unpinned', DESIGN.md section 2); seed 20261004; "
+        f"kernels.cu:24-133 identical to kernels.inl:21-130 modulo whitespace: {duplicate}"])
+    path = os.path.join(HERE, "reference_flux_vectors.npz")
+    np.savez_compressed(path, **res)
+    nvec = n_lm + 2 * n_ff + 4 * n_xyz
+    print(f"wrote {path}: {nvec} vectors per float type ({os.path.getsize(path) / 1024:.0f} KiB); kernels.cu copy identical: {duplicate}")
+    bad = [k for k, v in res.items() if k != "meta" and not np.isfinite(v).all()]
+    print("arrays with non-finite entries:", bad)
+
+
+if __name__ == "__main__":
+    main()

@@ -175,3 +175,57 @@ def test_full_size_c1_properties():
     f = PlainSolver(part, torch.float64, state=uniform)
     f.iterate(dt)
     assert rel_err(f.state().cpu().numpy(), uniform) < 1e-13      # uniform state is a fixed point (atomic order: few ulp)
+
+
+# ---- the HIP kernels against the committed reference vectors (tests/golden/reference_flux_vectors.npz) -------------
+def _golden_pair_mesh(g, tag, wall):
+    """One face per vector: interior face i joins elements 2i (left) and 2i+1 (right); a wall face i belongs to element i.
+    Unit areas, the vector's normal. In the reference's array formats."""
+    nrm, L, R = g[f"xyz_n_{tag}"], g[f"xyz_L_{tag}"], g[f"xyz_R_{tag}"]
+    n = nrm.shape[0]
+    if wall:
+        state = np.ascontiguousarray(L.T)                        # [5][n]
+        fn = np.arange(n, dtype=np.int32)                        # boundary part of face_neighbors: [2F + B], F = 0
+        return state, fn, 0, n
+    state = np.empty((5, 2 * n), L.dtype)
+    state[:, 0::2], state[:, 1::2] = L.T, R.T
+    return state, np.arange(2 * n, dtype=np.int32), n, 0
+
+
+@pytest.mark.parametrize("dtype,tag", [(torch.float64, "f64"), (torch.float32, "f32")])
+@pytest.mark.parametrize("kind,name", [(hip.KEPES, "kepes"), (hip.HLL, "hll")])
+@pytest.mark.parametrize("wall", [False, True])
+def test_compat_flux_kernels_on_the_reference_vectors(dtype, tag, kind, name, wall):
+    """kepes_compute_fluxes / reflective_boundary_condition of the compat tier fed with the generated reference vectors
+    (generic, near-equal, strong-jump and supersonic pairs; axis and oblique normals): what element 2i+1 (interior) or
+    element i (wall: minus the flux) receives must be the reference's xyz flux. The compat tier keeps the reference's
+    operation order; only the device libm (log, sqrt, division sequences) may differ, hence a few ulp, not zero."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_flux_vectors.npz"))
+    state, fn, F, B = _golden_pair_mesh(g, tag, wall)
+    n = F + B
+    nel = state.shape[1]
+    planes = torch.zeros((26, nel), dtype=dtype, device="cuda")
+    planes[0:5] = torch.from_numpy(state).cuda()
+    d_fn = torch.from_numpy(fn).cuda()
+    d_n = torch.from_numpy(np.ascontiguousarray(g[f"xyz_n_{tag}"])).cuda()
+    d_a = torch.ones(n, dtype=dtype, device="cuda")
+    speed = torch.zeros(n, dtype=dtype, device="cuda")
+    st, fl = hip.vars_of(planes, 0), hip.vars_of(planes, FLUXES)
+    if wall:
+        hip.call("t8gpu_hip_flux_boundary", dtype, kind, 0, B, 3, hip.ptr(d_fn), hip.ptr(d_n), hip.ptr(d_a), st, fl,
+                 hip.ptr(speed), hip.stream_ptr())
+        got = -planes[20:25].cpu().numpy().T                       # the element loses the outward flux
+        want = g[f"xyz_{name}_wall_{tag}"]
+    else:
+        hip.call("t8gpu_hip_flux_faces", dtype, kind, F, 3, hip.ptr(d_fn), None, hip.ptr(d_n), hip.ptr(d_a), st, fl,
+                 hip.ptr(speed), hip.stream_ptr())
+        fluxes = planes[20:25].cpu().numpy()
+        got = fluxes[:, 1::2].T                                     # +F to the right element
+        assert np.array_equal(fluxes[:, 0::2], -fluxes[:, 1::2])    # -F to the left one, same bits
+        want = g[f"xyz_{name}_{tag}"]
+    torch.cuda.synchronize()
+    # per-vector scale: the largest flux component of that vector (strong jumps span 6 decades across the set)
+    scale = np.abs(want).max(axis=1, keepdims=True) + np.finfo(want.dtype).tiny
+    err = (np.abs(got.astype(np.float64) - want.astype(np.float64)) / scale).max()
+    assert err < (5e-13 if dtype == torch.float64 else 2e-5), err

@@ -92,11 +92,20 @@ def test_subgrid_api_runs(tmp_path):
     mid = v["arrays"]["Position"].reshape(-1, 8, 3).mean(axis=1)
     inside = np.abs(mid[:, 2] - 0.5) < 0.25
     assert (v["arrays"]["variables"][inside] == 2).all() and (v["arrays"]["variables"][~inside] == 1).all()
+    # get_host_{scalar,vector}_variable + save_variables_to_vtk: the same density, and momentum as xyz triples
+    f = read_vtu(prefix + "_fields.vtu")
+    assert f["n_cells"] == v["n_cells"] and np.array_equal(f["arrays"]["density"], v["arrays"]["variables"])
+    assert f["arrays"]["momentum"].shape == (f["n_cells"], 3)
+    assert set(np.unique(f["arrays"]["momentum"][:, 0])) <= {-0.5, 0.5}
 
 
 @pytest.mark.gpu
-def test_adapt_example_runs():
+def test_adapt_example_runs(tmp_path):
     """MeshManager::adapt + the adaptive main loop in C++ (tests/compat/adapt_example.hip): mesh changes, mass is kept."""
     exe = compile_example("adapt_example.hip", "adapt_example")
-    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    prefix = str(tmp_path / "adapted")
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(os.environ, T8GPU_TEST_VTK_PREFIX=prefix))
     assert res.returncode == 0 and "adapt_example OK" in res.stdout, res.stdout + res.stderr
+    from _vtu import read_vtu
+    v = read_vtu(prefix + ".vtu")                      # MeshManager::save_variable_to_vtk
+    assert v["n_cells"] > 0 and 0.9 < v["arrays"]["variable"].min() and v["arrays"]["variable"].max() < 2.2

@@ -27,6 +27,42 @@ def test_kat_hll_f32_nine_digits():
     assert [float("%.9g" % x) for x in F] == GOLD["hll_f32"]
 
 
+REFVEC = os.path.join(os.path.dirname(__file__), "golden", "reference_flux_vectors.npz")
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_oracle_is_bit_exact_on_the_generated_reference_vectors(tag):
+    """tests/golden/reference_flux_vectors.npz = outputs of the reference's own kernels.inl:1-332 compiled for the host
+    (tests/golden/make_reference_vectors.py, run in the build container; 10 240 vectors per float type: ln_mean on both
+    branches, KEPES and the dead-code HLL in the face frame on generic / near-equal / strong-jump / supersonic pairs, and
+    the kernels' xyz pipeline basis -> rotate | reflect -> flux -> rotate back on axis-aligned and oblique normals).
+    The oracle must reproduce every one of them BIT FOR BIT in both precisions."""
+    g = np.load(REFVEC)
+    lm = O.ln_mean(g[f"lm_a_{tag}"], g[f"lm_b_{tag}"])
+    assert np.array_equal(lm, g[f"lm_out_{tag}"])
+    small = np.abs(g[f"lm_b_{tag}"] / g[f"lm_a_{tag}"] - 1) < 0.02      # both branches of kernels.inl:26-32 are in the set
+    assert 200 < small.sum() < small.size - 200
+    for kind, name in ((0, "kepes"), (1, "hll")):
+        F = O.face_frame_flux(kind, g[f"ff_L_{tag}"], g[f"ff_R_{tag}"])
+        assert np.array_equal(F, g[f"ff_{name}_{tag}"]), name
+        X = O.xyz_face_flux(kind, g[f"xyz_n_{tag}"], g[f"xyz_L_{tag}"], g[f"xyz_R_{tag}"])
+        assert np.array_equal(X, g[f"xyz_{name}_{tag}"]), name
+        W = O.xyz_face_flux(kind, g[f"xyz_n_{tag}"], g[f"xyz_L_{tag}"], g[f"xyz_R_{tag}"], mirror=True)
+        assert np.array_equal(W, g[f"xyz_{name}_wall_{tag}"]), name
+    assert g[f"ff_L_{tag}"].shape[0] + g[f"xyz_L_{tag}"].shape[0] >= 3000 and np.isfinite(g[f"ff_kepes_{tag}"]).all()
+
+
+def test_reference_vector_set_covers_the_hard_cases():
+    g = np.load(REFVEC)
+    L, R = g["ff_L_f64"], g["ff_R_f64"]
+    assert (L == R).all(axis=1).sum() >= 16                               # identical states (consistency, 0/0 guards)
+    assert (np.maximum(L[:, 0] / R[:, 0], R[:, 0] / L[:, 0]) > 100).sum() >= 50   # strong density jumps
+    n = g["xyz_n_f64"]
+    assert (np.abs(n).max(axis=1) == 1.0).sum() >= 300 and (np.abs(n).max(axis=1) < 0.99).sum() >= 300   # axis + oblique
+    assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-15)
+    assert "identical to kernels.inl:21-130 modulo whitespace: True" in str(g["meta"][0])
+
+
 def test_ln_mean_branches():
     # series branch (u < 1e-4, kernels.cu:29-32) and log branch agree where they meet; a == b -> a
     a = np.array([1.0, 1.0, 1.0, 2.0])
