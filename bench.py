@@ -180,6 +180,17 @@ def main():
             py_sampled[0] += 3 if sampled else 0
             solver.iterate(delta_t, halo=halo)
 
+    import contextlib
+
+    @contextlib.contextmanager
+    def roctx(name):      # named host range for rocprofv3 --marker-trace (a no-op unless T8GPU_ROCTX=1)
+        pushed = hip.lib().t8gpu_hip_range_push(name.encode())
+        try:
+            yield
+        finally:
+            if pushed:
+                hip.lib().t8gpu_hip_range_pop()
+
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
@@ -199,16 +210,19 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t10 = float(tt.item())
     more = int(min(max(args.prewarm_seconds - t10, 0.0) / max(t10, 1e-6) * 10, 20000))
-    run(more, False)
+    with roctx("bench.prewarm"):
+        run(more, False)
     prewarm = 10 + more
-    run(args.warmup, False)
+    with roctx("bench.warmup"):
+        run(args.warmup, False)
     # the timed region: EXACTLY K steps between barrier + synchronize on both sides, MAX over ranks -- repeated
     # `--reps` times back to back (median of 5); value / ms_per_step are the MEDIAN repetition's.
     rep_s = []
-    for _ in range(max(1, args.reps)):
+    for rep in range(max(1, args.reps)):
         fence()
         t1 = time.perf_counter()
-        run(args.steps, True)
+        with roctx(f"bench.timed_rep{rep}"):
+            run(args.steps, True)
         fence()
         el = time.perf_counter() - t1
         if dist is not None:
@@ -445,25 +459,41 @@ def bring_up_native_stepper(solver, native_halo, delta_t, part, tdtype, dist, ra
 
 
 def cpu_baseline(part, w, dts, delta_t, kindf, budget_s):
-    """The CPU oracle (a port: the reference has no CPU path) timed on this box's host cores on a
-    bounded sample: whole steps of the same mesh until ~budget_s of wall time is spent."""
+    """The CPU oracle (a port: the reference has no CPU path) timed on this box's host cores on a bounded sample:
+    whole steps of the same mesh until ~budget_s of wall time is spent, with all hardware threads (OpenMP over faces
+    with owner-computes accumulation -- no atomics -- and over elements for the RK stages, oracle.hpp: OwnerScatter),
+    then ONE step on one thread (SURVEY 8d asks for both figures)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
     npdt = np.float64 if dts == "f64" else np.float32
-    case = O.PlainCase(part, npdt) if w["kind"] == "plain" else O.SubgridCase(part, npdt)
-    threads = O.lib(omp=True).oracle_num_threads()
+    lib = O.lib(omp=True)
+    threads = lib.oracle_num_threads()
     cells = part.N * part.cells_per_element
-    t0 = time.perf_counter()
-    steps = 0
-    while True:
-        case.iterate(delta_t, kind=kindf, omp=True)
-        steps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or steps >= 50 or el / steps * (steps + 1) > 2 * budget_s:
-            break
+
+    def timed(budget, max_steps, warm=True):
+        case = O.PlainCase(part, npdt) if w["kind"] == "plain" else O.SubgridCase(part, npdt)
+        if warm:
+            case.iterate(delta_t, kind=kindf, omp=True)      # first call: thread start-up, page faults
+        t0 = time.perf_counter()
+        steps = 0
+        while True:
+            case.iterate(delta_t, kind=kindf, omp=True)
+            steps += 1
+            el = time.perf_counter() - t0
+            if el >= budget or steps >= max_steps or el / steps * (steps + 1) > 1.5 * budget:
+                return steps, el
+
+    steps, el = timed(0.6 * budget_s, 50)
+    lib.oracle_set_num_threads(1)
+    try:
+        steps1, el1 = timed(0.0, 1, warm=False)
+    finally:
+        lib.oracle_set_num_threads(threads)
     return {"value": round(cells * steps / el / 1e6, 3), "unit": "M cell-updates/s", "cores": int(threads),
-            "kind": "port", "sample": f"{steps} full step(s) of the same mesh ({cells} cells), OpenMP oracle, "
-            f"{el:.1f} s wall", "cpu_model": _cpu_model()}
+            "kind": "port", "sample": f"{steps} full step(s) of the same mesh ({cells} cells) after one untimed step, OpenMP oracle "
+            f"(owner-computes accumulation, no atomics), {el:.1f} s wall",
+            "value_1_thread": round(cells * steps1 / el1 / 1e6, 3),
+            "sample_1_thread": f"{steps1} full step on 1 thread, {el1:.1f} s wall", "cpu_model": _cpu_model()}
 
 
 def _cpu_model():

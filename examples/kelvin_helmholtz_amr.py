@@ -48,8 +48,9 @@ def main():
     def adapt(s):
         if world == 1:
             return amr.adapt(s, args.threshold, args.min_level, args.max_level)[0]
-        return amr.adapt_partitioned(s, dist, host_staged=rehearsal, threshold=args.threshold, min_level=args.min_level,
-                                     max_level=args.max_level)
+        # refreshes the ghost slots of the current state itself (the indicator reads them), through the run's halo object
+        return amr.adapt_partitioned(s, dist, host_staged=rehearsal, halo=halo_of.get(id(s)), threshold=args.threshold,
+                                     min_level=args.min_level, max_level=args.max_level)
 
     def total(x, op="sum"):
         if world == 1:
@@ -61,14 +62,14 @@ def main():
     mesh = SynthMesh(2, args.min_level, args.min_level)
     solver = PlainSolver(mesh.partition(rank, world), dtype, mode="fused")
     # refine the initial mesh around the shear layers before starting (the reference adapts at step 0)
+    halo_of = {}           # id(solver) -> its HaloExchange, when one exists already
     for _ in range(args.max_level - args.min_level):
-        if world > 1:
-            HaloExchange(solver.part, dtype, dist, stage_through_host=rehearsal).exchange(solver.step_planes(solver.next))
         solver = adapt(solver)
         # re-evaluate the initial condition on the refined mesh (sharp layers)
         ic = torch.from_numpy(solver.part.kh_initial_state()).to(dtype).cuda()
         solver.planes[5 * solver.next:5 * solver.next + 5] = ic
     halo = HaloExchange(solver.part, dtype, dist, stage_through_host=rehearsal) if world > 1 else None
+    halo_of = {id(solver): halo}
     if world == 1:
         solver.use_native_stepper()
     mass0 = [total(solver.compute_integral(k)) for k in range(5)]
@@ -78,11 +79,11 @@ def main():
         if it % args.adapt_every == 0 and it > 0:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            if halo is not None:
-                halo.exchange(solver.step_planes(solver.next))          # the indicator reads current ghost values
             solver = adapt(solver)
+            say(f"adapt at it {it}: criteria sum {solver.last_adapt_criteria_sum:.12e}  elements {int(total(solver.N))}", flush=True)
             if world > 1:
                 halo = HaloExchange(solver.part, dtype, dist, stage_through_host=rehearsal)
+                halo_of = {id(solver): halo}
             else:
                 solver.use_native_stepper()
             torch.cuda.synchronize()

@@ -42,6 +42,11 @@ int         t8gpu_hip_abi_version(void);
 int         t8gpu_hip_device_count(int* count);
 int         t8gpu_hip_set_device(int device);
 const char* t8gpu_hip_error_string(int code);
+/* roctx ranges for `rocprofv3 --marker-trace`: active only with T8GPU_ROCTX=1 in the environment
+ * (the roctx library is dlopen'ed then); both return 1 when a range was pushed / popped, 0 when ranges are off. The
+ * step drivers mark iterate_steps and every RK stage themselves. */
+int         t8gpu_hip_range_push(const char* name);
+int         t8gpu_hip_range_pop(void);
 
 /* ---- plain elements, reference-dataflow kernels ("compat" tier) ------------------------------- */
 
@@ -148,7 +153,10 @@ typedef struct T8gpuPlainPlan {
 
 /* tile_begin/tile_count select a range of tile_order (0, ntiles = everything; [0, n_interior) can run
  * while the halo exchange of `src` is still in flight, [n_interior, ntiles) after it). mid = state
- * the fluxes are evaluated on (prev for stage 1, Step1, Step2); ghost slots of `mid` must be current. */
+ * the fluxes are evaluated on (prev for stage 1, Step1, Step2); ghost slots of `mid` must be current.
+ * Stage 1 is u1 = u0 + dt/vol f(u0) (ssp_runge_kutta.inl:30-50): prev and mid MUST be the same planes there,
+ * anything else returns hipErrorInvalidValue. speed_estimates (may be NULL) gets one value per face for EVERY
+ * flux_kind: |uHat| + aHat for KEPES (kernels.cu:222), max(|S_l|, |S_r|) of the wave-speed bounds for HLL / HLLC. */
 int t8gpu_hip_plain_fused_stage_f32(int flux_kind, int stage, const T8gpuPlainPlan* plan, int tile_begin,
                                     int tile_count, T8gpuVars_f32 prev, T8gpuVars_f32 mid, T8gpuVars_f32 out,
                                     const float* volume, float delta_t, float* speed_estimates, void* stream);

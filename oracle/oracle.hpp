@@ -20,6 +20,11 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#if defined(_OPENMP)
+#include <omp.h>
+
+#include <vector>
+#endif
 
 namespace oracle {
 
@@ -165,9 +170,12 @@ inline void kepes_total_flux(const T uL[5], const T uR[5], T F[5], T* speed) {
 
 // ---------------------------------------------------------------------------
 // a12: HLL flux (dead code in the reference), kernels.inl:263-332.
+// `speed` (may be null; NOT in the reference, whose HLL writes no estimate): max(|S_l|, |S_r|) of the wave-speed
+// bounds before the clamp to zero -- the CFL-relevant signal speed of this solver, so that compute_timestep works
+// with flux_kind HLL / HLLC as it does with KEPES (kernels.cu:222).
 // ---------------------------------------------------------------------------
 template <class T>
-inline void hll_total_flux(const T uL[5], const T uR[5], T F[5]) {
+inline void hll_total_flux(const T uL[5], const T uR[5], T F[5], T* speed = nullptr) {
   const T zero = T(0), one = T(1), half = T(0.5);
   const T g = T(1.4);
 
@@ -191,6 +199,7 @@ inline void hll_total_flux(const T uL[5], const T uR[5], T F[5]) {
 
   const T Sl = std::min(v1 - c, v1l - cl);
   const T Sr = std::max(v1 + c, v1r + cr);
+  if (speed) *speed = std::max(std::abs(Sl), std::abs(Sr));
 
   const T Fl[5] = {uL[1], uL[1] * uL[1] / uL[0] + pl, uL[1] * v2l, uL[1] * v3l, uL[1] * Hl};
   const T Fr[5] = {uR[1], uR[1] * uR[1] / uR[0] + pr, uR[1] * v2r, uR[1] * v3r, uR[1] * Hr};
@@ -241,7 +250,7 @@ inline void to_face_frame(const T n[3], const T t1[3], const T t2[3], const T s[
 // (consistency, exact stationary / moving contacts, upwinding) in tests/test_oracle_golden.py.
 // ---------------------------------------------------------------------------
 template <class T>
-inline void hllc_total_flux(const T uL[5], const T uR[5], T F[5]) {
+inline void hllc_total_flux(const T uL[5], const T uR[5], T F[5], T* speed = nullptr) {
   const T zero = T(0), one = T(1), half = T(0.5);
   const T g = T(1.4);
   const T v1l = uL[1] / uL[0], v2l = uL[2] / uL[0], v3l = uL[3] / uL[0];
@@ -260,6 +269,7 @@ inline void hllc_total_flux(const T uL[5], const T uR[5], T F[5]) {
   const T H  = (wl * Hl + wr * Hr) / ws;
   const T c  = std::sqrt((g - one) * (H - half * (v1 * v1 + v2 * v2 + v3 * v3)));
   const T Sl = std::min(v1 - c, v1l - cl), Sr = std::max(v1 + c, v1r + cr);
+  if (speed) *speed = std::max(std::abs(Sl), std::abs(Sr));
   const T ml = uL[0] * (Sl - v1l), mr = uR[0] * (Sr - v1r);           // rho_K (S_K - u_K)
   const T Ss = ((pr - pl) + (uL[1] * (Sl - v1l) - uR[1] * (Sr - v1r))) / (ml - mr);
   const bool left = Ss >= zero;
@@ -278,9 +288,9 @@ enum FluxKind { KEPES = 0, HLL = 1, HLLC = 2 };
 template <class T>
 inline void face_frame_flux(int kind, const T a[5], const T b[5], T F[5], T* speed) {
   if (kind == HLL) {
-    hll_total_flux<T>(a, b, F);
+    hll_total_flux<T>(a, b, F, speed);
   } else if (kind == HLLC) {
-    hllc_total_flux<T>(a, b, F);
+    hllc_total_flux<T>(a, b, F, speed);
   } else {
     kepes_total_flux<T>(a, b, F, speed);
   }
@@ -297,6 +307,56 @@ struct Planes {
   T*     at(int step, int var) const { return base + (static_cast<size_t>(step) * 5 + var) * stride; }
 };
 
+#if defined(_OPENMP)
+// ---------------------------------------------------------------------------
+// OpenMP build only (liboracle_omp.so: the TIMED cpu_baseline of bench.py, never a parity reference). The face loops
+// scatter +-F into two elements; instead of `omp atomic` on every addition (10 per face) each thread owns a range
+// of elements -- the range its static chunk of faces lists as LEFT elements, which is contiguous because faces are
+// listed by ascending left element (mesh_manager.inl:411-424) -- adds to its own elements directly and parks the few
+// contributions to other threads' elements (faces next to a chunk boundary) in per-destination buckets that the
+// owners add after a barrier. No atomics, deterministic for a given thread count; correct for any face order
+// (a non-monotone list just parks more).
+// ---------------------------------------------------------------------------
+template <class T>
+struct OwnerScatter {
+  struct Parked {
+    size_t idx;
+    T      v[5];
+  };
+  int                                           nt;
+  std::vector<int64_t>                          first;   // first[t] = first element owned by thread t; first[nt] = +inf
+  std::vector<std::vector<std::vector<Parked>>> parked;  // [source thread][destination thread]
+
+  // left(f) = left element of face f; F faces are split into nt static chunks
+  template <class Left>
+  OwnerScatter(int F, Left left) : nt(omp_get_max_threads()), first(nt + 1), parked(nt, std::vector<std::vector<Parked>>(nt)) {
+    for (int t = 0; t < nt; t++) {
+      const int64_t f0 = static_cast<int64_t>(F) * t / nt;
+      first[t]         = (t == 0 || f0 >= F) ? (t == 0 ? INT64_MIN : INT64_MAX) : left(static_cast<int>(f0));
+    }
+    first[nt] = INT64_MAX;
+    for (int t = nt - 1; t > 0; t--) first[t] = std::min(first[t], first[t + 1]);   // keep the bounds monotone
+  }
+  int owner(int64_t elem) const { return static_cast<int>(std::upper_bound(first.begin() + 1, first.end(), elem) - first.begin()) - 1; }
+  void add(int t, int64_t elem, size_t idx, const T v[5], T sign, T* const flux[5]) {
+    const int o = std::min(owner(elem), nt - 1);
+    if (o == t) {
+      for (int k = 0; k < 5; k++) flux[k][idx] += sign * v[k];
+    } else {
+      Parked p;
+      p.idx = idx;
+      for (int k = 0; k < 5; k++) p.v[k] = sign * v[k];
+      parked[t][o].push_back(p);
+    }
+  }
+  void drain(int t, T* const flux[5]) {   // call after `#pragma omp barrier`
+    for (int src = 0; src < nt; src++)
+      for (const Parked& p : parked[src][t])
+        for (int k = 0; k < 5; k++) flux[k][p.idx] += p.v[k];
+  }
+};
+#endif
+
 // ---------------------------------------------------------------------------
 // a4: interior faces of plain elements, kernels.cu:135-309. One iteration ==
 // one CUDA thread. `indices` (nullable) is the element->slot map
@@ -308,12 +368,11 @@ struct Planes {
 template <class T>
 void plain_interior_faces(int kind, int F, int dim, const int32_t* face_neighbors, const int32_t* indices,
                           const T* normals, const T* areas, const T* const state[5], T* const flux[5], T* speed) {
-#if defined(_OPENMP)
-#pragma omp parallel for schedule(static)
-#endif
-  for (int i = 0; i < F; i++) {
+  // one face: gather, rotate, flux, scale by the area, rotate back (kernels.cu:160-290); returns l, r and the xyz flux
+  auto face = [&](int i, int& l, int& r, T out[5]) {
     const T area = areas[i];
-    int     l = face_neighbors[2 * i], r = face_neighbors[2 * i + 1];
+    l = face_neighbors[2 * i];
+    r = face_neighbors[2 * i + 1];
     if (indices) {
       l = indices[l];
       r = indices[r];
@@ -332,23 +391,43 @@ void plain_interior_faces(int kind, int F, int dim, const int32_t* face_neighbor
     to_face_frame<T>(n, t1, t2, sr, b, false);
     T spd = T(0);
     face_frame_flux<T>(kind, a, b, Ff, &spd);
-    if (speed && kind == KEPES) speed[i] = spd;
+    if (speed) speed[i] = spd;
     const T f0 = area * Ff[0], f1 = area * Ff[1], f2 = area * Ff[2], f3 = area * Ff[3], f4 = area * Ff[4];
-    const T fx = f1 * n[0] + f2 * t1[0] + f3 * t2[0];
-    const T fy = f1 * n[1] + f2 * t1[1] + f3 * t2[1];
-    const T fz = f1 * n[2] + f2 * t1[2] + f3 * t2[2];
-    const T out[5] = {f0, fx, fy, fz, f4};
+    out[0] = f0;
+    out[1] = f1 * n[0] + f2 * t1[0] + f3 * t2[0];
+    out[2] = f1 * n[1] + f2 * t1[1] + f3 * t2[1];
+    out[3] = f1 * n[2] + f2 * t1[2] + f3 * t2[2];
+    out[4] = f4;
+  };
+#if defined(_OPENMP)
+  OwnerScatter<T> scatter(F, [&](int f) { return static_cast<int64_t>(indices ? indices[face_neighbors[2 * f]] : face_neighbors[2 * f]); });
+#pragma omp parallel
+  {
+    // chunk c of the faces (and the elements it owns) is handled by exactly one thread, whatever team size we got
+    for (int c = omp_get_thread_num(); c < scatter.nt; c += omp_get_num_threads()) {
+      const int f0 = static_cast<int>(static_cast<int64_t>(F) * c / scatter.nt), f1 = static_cast<int>(static_cast<int64_t>(F) * (c + 1) / scatter.nt);
+      for (int i = f0; i < f1; i++) {
+        int l, r;
+        T   out[5];
+        face(i, l, r, out);
+        scatter.add(c, l, static_cast<size_t>(l), out, T(-1), flux);
+        scatter.add(c, r, static_cast<size_t>(r), out, T(1), flux);
+      }
+    }
+#pragma omp barrier
+    for (int c = omp_get_thread_num(); c < scatter.nt; c += omp_get_num_threads()) scatter.drain(c, flux);
+  }
+#else
+  for (int i = 0; i < F; i++) {
+    int l, r;
+    T   out[5];
+    face(i, l, r, out);
     for (int k = 0; k < 5; k++) {
-#if defined(_OPENMP)
-#pragma omp atomic
-#endif
       flux[k][l] += -out[k];
-#if defined(_OPENMP)
-#pragma omp atomic
-#endif
       flux[k][r] += out[k];
     }
   }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -372,7 +451,7 @@ void plain_boundary_faces(int kind, int F, int B, int dim, const int32_t* face_n
     to_face_frame<T>(n, t1, t2, s, b, true);
     T spd = T(0);
     face_frame_flux<T>(kind, a, b, Ff, &spd);
-    if (speed && kind == KEPES) speed[F + i] = spd;
+    if (speed) speed[F + i] = spd;
     const T f0 = area * Ff[0], f1 = area * Ff[1], f2 = area * Ff[2], f3 = area * Ff[3], f4 = area * Ff[4];
     const T fx = f1 * n[0] + f2 * t1[0] + f3 * t2[0];
     const T fy = f1 * n[1] + f2 * t1[1] + f3 * t2[1];
@@ -537,7 +616,9 @@ void subgrid_outer(int kind, int rank, int F, const int32_t* face_neighbors, con
                    const T* const state[5], T* const flux[5]) {
   const int S  = sg_size(rank);
   const int nj = rank == 3 ? E : 1;
-  for (int f = 0; f < F; f++) {
+  auto left_of = [&](int f) { return static_cast<int64_t>(indices ? indices[face_neighbors[2 * static_cast<size_t>(f)]] : face_neighbors[2 * static_cast<size_t>(f)]); };
+  // one coarse face = one CUDA block of the reference; emit(block, cell index, flux, sign) receives every contribution
+  auto coarse_face = [&](int f, auto&& emit) {
     const int ds     = (level_diff[f] == 0) ? 2 : 1;
     int       off[3] = {0, 0, 0};
     for (int d = 0; d < rank; d++) off[d] = nb_offset[static_cast<size_t>(rank) * f + d];
@@ -567,12 +648,30 @@ void subgrid_outer(int kind, int rank, int F, const int32_t* face_neighbors, con
         face_frame_flux<T>(kind, a, b, Ff, nullptr);
         const T g[5] = {Ff[0], Ff[1] * n[0] + Ff[2] * t1[0] + Ff[3] * t2[0], Ff[1] * n[1] + Ff[2] * t1[1] + Ff[3] * t2[1],
                         Ff[1] * n[2] + Ff[2] * t1[2] + Ff[3] * t2[2], Ff[4]};
-        for (int k = 0; k < 5; k++) {
-          flux[k][li] += -g[k] * surface;
-          flux[k][ri] += g[k] * surface;
-        }
+        const T gs[5] = {g[0] * surface, g[1] * surface, g[2] * surface, g[3] * surface, g[4] * surface};
+        emit(l, li, gs, T(-1));
+        emit(r, ri, gs, T(1));
       }
+  };
+#if defined(_OPENMP)
+  OwnerScatter<T> scatter(F, left_of);
+#pragma omp parallel
+  {
+    for (int c = omp_get_thread_num(); c < scatter.nt; c += omp_get_num_threads()) {
+      const int f0 = static_cast<int>(static_cast<int64_t>(F) * c / scatter.nt), f1 = static_cast<int>(static_cast<int64_t>(F) * (c + 1) / scatter.nt);
+      for (int f = f0; f < f1; f++)
+        coarse_face(f, [&](int block, size_t idx, const T v[5], T sign) { scatter.add(c, block, idx, v, sign, flux); });
+    }
+#pragma omp barrier
+    for (int c = omp_get_thread_num(); c < scatter.nt; c += omp_get_num_threads()) scatter.drain(c, flux);
   }
+#else
+  (void)left_of;
+  for (int f = 0; f < F; f++)
+    coarse_face(f, [&](int, size_t idx, const T v[5], T sign) {
+      for (int k = 0; k < 5; k++) flux[k][idx] += sign * v[k];
+    });
+#endif
 }
 
 // a15: compute_boundary_fluxes, kernels.inl:913-1107 (reflect_state on the right).

@@ -11,6 +11,14 @@
 
 using namespace oracle;
 
+extern "C" void oracle_set_num_threads(int n) {
+#if defined(_OPENMP)
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 extern "C" int oracle_num_threads() {
 #if defined(_OPENMP)
   return omp_get_max_threads();

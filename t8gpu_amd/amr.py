@@ -47,6 +47,7 @@ def adapt(solver, threshold=10.0, min_level=1, max_level=4, family_members_avera
     torch.cuda.synchronize()
     if getattr(solver, "stepper", None) is not None:
         new.use_native_stepper()
+    new.last_adapt_criteria_sum = float(crit.sum())
     return new, marks, adapt_data
 
 
@@ -159,13 +160,26 @@ def _gather_criteria(crit, solver, dist, host_staged):
     return torch.cat([c[:n] for c, n in zip(chunks, sizes)]).cpu().numpy()
 
 
-def adapt_partitioned(solver, dist, host_staged=False, **kw):
+def adapt_partitioned(solver, dist, host_staged=False, halo=None, **kw):
     """Collective: every rank calls it with its own solver; returns the rank's new solver.
-    host_staged: collectives and messages through host memory (gloo)."""
+    host_staged: collectives and messages through host memory (gloo).
+
+    The indicator (estimate_gradient, solver.cu:245-263) reads rho of GHOST elements of the `next` state, and neither
+    step driver refreshes those slots -- a stage only exchanges the ghosts of its SOURCE state, so after a step the
+    last stage's output carries ghost values two stages old. The exchange is therefore part of this function (through
+    `halo`, the run's HaloExchange of this partition, or a temporary one): refinement marks must not depend on the
+    number of ranks."""
+    if solver.part.nranks > 1:
+        if halo is None:
+            from .halo import HaloExchange
+            halo = HaloExchange(solver.part, solver.dtype, dist, overlap=False, stage_through_host=host_staged)
+        halo.exchange(solver.step_planes(solver.next))
     all_crit = _gather_criteria(refinement_criteria(solver).double(), solver, dist, host_staged)
     pa = PartitionedAdapt(solver, all_crit, **kw)
     pa.transport(dist, host_staged)
-    return pa.finish()
+    new = pa.finish()
+    new.last_adapt_criteria_sum = float(all_crit.sum())      # diagnostic: equal (to rounding) for every rank count
+    return new
 
 
 def subgrid_refinement_criteria(solver):

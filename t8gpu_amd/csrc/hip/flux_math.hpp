@@ -131,7 +131,7 @@ T8_DEV void kepes_ref(const T uL[5], const T uR[5], T F[5], T& speed) {
 
 // HLL (reference dead code), kernels.inl:263-332
 template <class T>
-T8_DEV void hll_ref(const T uL[5], const T uR[5], T F[5]) {
+T8_DEV void hll_ref(const T uL[5], const T uR[5], T F[5], T& speed) {
   const T zero = T(0), one = T(1), half = T(0.5);
   const T g = T(1.4);
   const T v1l = uL[1] / uL[0], v2l = uL[2] / uL[0], v3l = uL[3] / uL[0];
@@ -151,6 +151,7 @@ T8_DEV void hll_ref(const T uL[5], const T uR[5], T F[5]) {
   const T c  = t8_sqrt((g - one) * (H - half * (v1 * v1 + v2 * v2 + v3 * v3)));
   const T Sl = t8_min(v1 - c, v1l - cl);
   const T Sr = t8_max(v1 + c, v1r + cr);
+  speed = t8_max(t8_abs(Sl), t8_abs(Sr));   // signal speed for the CFL step (not in the reference; oracle.hpp: hll_total_flux)
   const T Fl[5] = {uL[1], uL[1] * uL[1] / uL[0] + pl, uL[1] * v2l, uL[1] * v3l, uL[1] * Hl};
   const T Fr[5] = {uR[1], uR[1] * uR[1] / uR[0] + pr, uR[1] * v2r, uR[1] * v3r, uR[1] * Hr};
   const T sl = t8_min(Sl, zero);
@@ -161,7 +162,7 @@ T8_DEV void hll_ref(const T uL[5], const T uR[5], T F[5]) {
 
 // HLLC (not in the reference; see oracle.hpp): the HLL above with the contact wave restored, same wave speeds.
 template <class T>
-T8_DEV void hllc_ref(const T uL[5], const T uR[5], T F[5]) {
+T8_DEV void hllc_ref(const T uL[5], const T uR[5], T F[5], T& speed) {
   const T zero = T(0), one = T(1), half = T(0.5);
   const T g = T(1.4);
   const T v1l = uL[1] / uL[0], v2l = uL[2] / uL[0], v3l = uL[3] / uL[0];
@@ -180,6 +181,7 @@ T8_DEV void hllc_ref(const T uL[5], const T uR[5], T F[5]) {
   const T H  = (wl * Hl + wr * Hr) / ws;
   const T c  = t8_sqrt((g - one) * (H - half * (v1 * v1 + v2 * v2 + v3 * v3)));
   const T Sl = t8_min(v1 - c, v1l - cl), Sr = t8_max(v1 + c, v1r + cr);
+  speed = t8_max(t8_abs(Sl), t8_abs(Sr));
   const T ml = uL[0] * (Sl - v1l), mr = uR[0] * (Sr - v1r);
   const T Ss = ((pr - pl) + (uL[1] * (Sl - v1l) - uR[1] * (Sr - v1r))) / (ml - mr);
   const bool left = Ss >= zero;
@@ -255,11 +257,9 @@ T8_DEV void face_frame_flux_ref(const T n[3], const T t1[3], const T t2[3], cons
   to_face_frame<T>(n, t1, t2, sL, a, false);
   to_face_frame<T>(n, t1, t2, mirror ? sL : sR, b, mirror);
   if (KIND == 1) {
-    hll_ref<T>(a, b, Ff);
-    speed = T(0);
+    hll_ref<T>(a, b, Ff, speed);
   } else if (KIND == 2) {
-    hllc_ref<T>(a, b, Ff);
-    speed = T(0);
+    hllc_ref<T>(a, b, Ff, speed);
   } else {
     kepes_ref<T>(a, b, Ff, speed);
   }
@@ -505,33 +505,7 @@ T8_DEV void kepes_axis(const Prim<T>& L, const Prim<T>& R, bool mirror, int axis
 // HLL for the fast tier: the formulas of hll_ref (examples/subgrid/kernels.inl:263-332) with shared
 // reciprocals and the fast division above; takes the states already rotated into the face frame.
 template <class T>
-T8_DEV void hll_fast(const T uL[5], const T uR[5], T F[5]) {
-  const T zero = T(0), one = T(1), half = T(0.5);
-  const T gm1 = T(1.4) - one;
-  const T irl = t8_rcp(uL[0]), irr = t8_rcp(uR[0]);
-  const T v1l = uL[1] * irl, v2l = uL[2] * irl, v3l = uL[3] * irl;
-  const T v1r = uR[1] * irr, v2r = uR[2] * irr, v3r = uR[3] * irr;
-  const T kl = half * (v1l * v1l + v2l * v2l + v3l * v3l), kr = half * (v1r * v1r + v2r * v2r + v3r * v3r);
-  const T pl = gm1 * (uL[4] - uL[0] * kl), pr = gm1 * (uR[4] - uR[0] * kr);
-  const T Hl = (uL[4] + pl) * irl, Hr = (uR[4] + pr) * irr;
-  const T cl = t8_sqrt_fast(gm1 * (Hl - kl)), cr = t8_sqrt_fast(gm1 * (Hr - kr));
-  const T wl = t8_sqrt_fast(uL[0]), wr = t8_sqrt_fast(uR[0]);
-  const T iw = t8_rcp(wl + wr);
-  const T v1 = (wl * v1l + wr * v1r) * iw, v2 = (wl * v2l + wr * v2r) * iw, v3 = (wl * v3l + wr * v3r) * iw;
-  const T H  = (wl * Hl + wr * Hr) * iw;
-  const T c  = t8_sqrt_fast(gm1 * (H - half * (v1 * v1 + v2 * v2 + v3 * v3)));
-  const T sl = t8_min(t8_min(v1 - c, v1l - cl), zero);
-  const T sr = t8_max(t8_max(v1 + c, v1r + cr), zero);
-  const T Fl[5] = {uL[1], uL[1] * v1l + pl, uL[1] * v2l, uL[1] * v3l, uL[1] * Hl};
-  const T Fr[5] = {uR[1], uR[1] * v1r + pr, uR[1] * v2r, uR[1] * v3r, uR[1] * Hr};
-  const T id = t8_rcp(sr - sl);
-#pragma unroll
-  for (int k = 0; k < 5; k++) F[k] = ((sr * Fl[k] - sl * Fr[k]) + sr * sl * (uR[k] - uL[k])) * id;
-}
-
-// HLLC for the fast tier: hllc_ref with shared reciprocals and the fast division / sqrt
-template <class T>
-T8_DEV void hllc_fast(const T uL[5], const T uR[5], T F[5]) {
+T8_DEV void hll_fast(const T uL[5], const T uR[5], T F[5], T& speed) {
   const T zero = T(0), one = T(1), half = T(0.5);
   const T gm1 = T(1.4) - one;
   const T irl = t8_rcp(uL[0]), irr = t8_rcp(uR[0]);
@@ -547,6 +521,35 @@ T8_DEV void hllc_fast(const T uL[5], const T uR[5], T F[5]) {
   const T H  = (wl * Hl + wr * Hr) * iw;
   const T c  = t8_sqrt_fast(gm1 * (H - half * (v1 * v1 + v2 * v2 + v3 * v3)));
   const T Sl = t8_min(v1 - c, v1l - cl), Sr = t8_max(v1 + c, v1r + cr);
+  speed      = t8_max(t8_abs(Sl), t8_abs(Sr));
+  const T sl = t8_min(Sl, zero);
+  const T sr = t8_max(Sr, zero);
+  const T Fl[5] = {uL[1], uL[1] * v1l + pl, uL[1] * v2l, uL[1] * v3l, uL[1] * Hl};
+  const T Fr[5] = {uR[1], uR[1] * v1r + pr, uR[1] * v2r, uR[1] * v3r, uR[1] * Hr};
+  const T id = t8_rcp(sr - sl);
+#pragma unroll
+  for (int k = 0; k < 5; k++) F[k] = ((sr * Fl[k] - sl * Fr[k]) + sr * sl * (uR[k] - uL[k])) * id;
+}
+
+// HLLC for the fast tier: hllc_ref with shared reciprocals and the fast division / sqrt
+template <class T>
+T8_DEV void hllc_fast(const T uL[5], const T uR[5], T F[5], T& speed) {
+  const T zero = T(0), one = T(1), half = T(0.5);
+  const T gm1 = T(1.4) - one;
+  const T irl = t8_rcp(uL[0]), irr = t8_rcp(uR[0]);
+  const T v1l = uL[1] * irl, v2l = uL[2] * irl, v3l = uL[3] * irl;
+  const T v1r = uR[1] * irr, v2r = uR[2] * irr, v3r = uR[3] * irr;
+  const T kl = half * (v1l * v1l + v2l * v2l + v3l * v3l), kr = half * (v1r * v1r + v2r * v2r + v3r * v3r);
+  const T pl = gm1 * (uL[4] - uL[0] * kl), pr = gm1 * (uR[4] - uR[0] * kr);
+  const T Hl = (uL[4] + pl) * irl, Hr = (uR[4] + pr) * irr;
+  const T cl = t8_sqrt_fast(gm1 * (Hl - kl)), cr = t8_sqrt_fast(gm1 * (Hr - kr));
+  const T wl = t8_sqrt_fast(uL[0]), wr = t8_sqrt_fast(uR[0]);
+  const T iw = t8_rcp(wl + wr);
+  const T v1 = (wl * v1l + wr * v1r) * iw, v2 = (wl * v2l + wr * v2r) * iw, v3 = (wl * v3l + wr * v3r) * iw;
+  const T H  = (wl * Hl + wr * Hr) * iw;
+  const T c  = t8_sqrt_fast(gm1 * (H - half * (v1 * v1 + v2 * v2 + v3 * v3)));
+  const T Sl = t8_min(v1 - c, v1l - cl), Sr = t8_max(v1 + c, v1r + cr);
+  speed = t8_max(t8_abs(Sl), t8_abs(Sr));
   const T ml = uL[0] * (Sl - v1l), mr = uR[0] * (Sr - v1r);
   const T Ss = t8_div((pr - pl) + (uL[1] * (Sl - v1l) - uR[1] * (Sr - v1r)), ml - mr);
   const bool left = Ss >= zero;
@@ -566,14 +569,14 @@ T8_DEV void hllc_fast(const T uL[5], const T uR[5], T F[5]) {
 // face-frame HLL (hllc = false) or HLLC flux of an xyz state pair, scaled by `area`, rotated back to xyz (fast tier)
 template <class T>
 T8_DEV void hll_face(const T sL[5], const T sR[5], bool mirror, const T n[3], const T t1[3], const T t2[3], T area, T g[5],
-                     bool hllc = false) {
+                     T& speed, bool hllc = false) {
   T a[5], b[5], Ff[5];
   to_face_frame<T>(n, t1, t2, sL, a, false);
   to_face_frame<T>(n, t1, t2, mirror ? sL : sR, b, mirror);
   if (hllc)
-    hllc_fast<T>(a, b, Ff);
+    hllc_fast<T>(a, b, Ff, speed);
   else
-    hll_fast<T>(a, b, Ff);
+    hll_fast<T>(a, b, Ff, speed);
 #pragma unroll
   for (int k = 0; k < 5; k++) Ff[k] = area * Ff[k];
   from_face_frame<T>(n, t1, t2, Ff, g);

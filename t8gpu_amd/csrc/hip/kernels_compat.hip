@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_flux_faces(int F, int ndim, const int32
   T t1[3], t2[3], Ff[5], g[5], spd;
   face_basis<T>(n, t1, t2);
   face_frame_flux_ref<T, KIND>(n, t1, t2, sl, sr, false, Ff, spd);
-  if (speed && KIND == 0) speed[i] = spd;
+  if (speed) speed[i] = spd;
 #pragma unroll
   for (int k = 0; k < 5; k++) Ff[k] = area * Ff[k];
   from_face_frame<T>(n, t1, t2, Ff, g);
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_flux_boundary(int F, int B, int ndim, c
   T t1[3], t2[3], Ff[5], g[5], spd;
   face_basis<T>(n, t1, t2);
   face_frame_flux_ref<T, KIND>(n, t1, t2, s, s, true, Ff, spd);
-  if (speed && KIND == 0) speed[F + i] = spd;
+  if (speed) speed[F + i] = spd;
 #pragma unroll
   for (int k = 0; k < 5; k++) Ff[k] = area * Ff[k];
   from_face_frame<T>(n, t1, t2, Ff, g);

@@ -102,10 +102,6 @@ __global__ __launch_bounds__(256) void k_plain_fused(T8gpuPlainPlan P, int tile_
       R.rho = pe[0 * LE + r]; R.vx = pe[1 * LE + r]; R.vy = pe[2 * LE + r]; R.vz = pe[3 * LE + r]; R.p = pe[4 * LE + r];
       R.beta = pe[5 * LE + r]; R.lrho = pe[6 * LE + r]; R.lbeta = pe[7 * LE + r]; R.v0 = pe[8 * LE + r];
       kepes_prim<T>(L, R, wall, n, t1, t2, gm.w, g, spd);
-      if (speed) {
-        const int orig = P.face_orig[f0 + f];
-        if (orig >= 0) speed[orig] = spd;
-      }
     } else {
       T sl[5], sr[5];
 #pragma unroll
@@ -113,7 +109,11 @@ __global__ __launch_bounds__(256) void k_plain_fused(T8gpuPlainPlan P, int tile_
         sl[k] = pe[k * LE + l];
         sr[k] = pe[k * LE + r];
       }
-      hll_face<T>(sl, sr, wall, n, t1, t2, gm.w, g, KIND == 2);
+      hll_face<T>(sl, sr, wall, n, t1, t2, gm.w, g, spd, KIND == 2);
+    }
+    if (speed) {
+      const int orig = P.face_orig[f0 + f];
+      if (orig >= 0) speed[orig] = spd;
     }
 #pragma unroll
     for (int k = 0; k < 5; k++) ff[k * LF + f] = g[k];
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
       f.gi = 3 * P.geo_idx[j];
     else
       f.gm = reinterpret_cast<const V4*>(P.face_geo)[j];
-    f.orig = (speed && KIND == 0) ? P.face_orig[j] : -1;
+    f.orig = speed ? P.face_orig[j] : -1;
     return f;
   };
   FaceIn fin[MAXP + 1];
@@ -316,7 +316,6 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
         load_prim<T>(pe, LE, l, L);
         load_prim<T>(pe, LE, r, R);
         kepes_prim<T>(L, R, wall, n, t1, t2, gm.w, g, spd);
-        if (fi.orig >= 0) speed[fi.orig] = spd;
       } else {
         T sl[5], sr[5];
 #pragma unroll
@@ -324,8 +323,9 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
           sl[k] = pe[k * LE + l];
           sr[k] = pe[k * LE + r];
         }
-        hll_face<T>(sl, sr, wall, n, t1, t2, gm.w, g, KIND == 2);
+        hll_face<T>(sl, sr, wall, n, t1, t2, gm.w, g, spd, KIND == 2);
       }
+      if (fi.orig >= 0) speed[fi.orig] = spd;
       if (SCATTER) {
         if (l < ne) {
 #pragma unroll
@@ -402,6 +402,12 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
   if (!plan || kind < 0 || kind > 2 || stage < 1 || stage > 3) return static_cast<int>(hipErrorInvalidValue);
   if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > plan->ntiles) return static_cast<int>(hipErrorInvalidValue);
   if (plan->max_elems > 256 * 4) return static_cast<int>(hipErrorInvalidValue);
+  // stage 1 is u1 = u0 + dt/vol f(u0) (ssp_runge_kutta.inl:30-50: `prev` is both the flux source and the summand):
+  // the pipelined kernel keeps the source state in registers and never reads `prev` at stage 1, the generic kernel
+  // does -- so a caller passing prev != mid at stage 1 would get variant-dependent results. Refused instead.
+  if (stage == 1)
+    for (int k = 0; k < 5; k++)
+      if (prev.p[k] != mid.p[k]) return static_cast<int>(hipErrorInvalidValue);
   if (tile_count == 0) return 0;
   const int   nw = kind == 0 ? kPrimWords : 5;
   hipStream_t s  = static_cast<hipStream_t>(stream);

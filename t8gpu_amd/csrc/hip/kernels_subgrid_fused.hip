@@ -100,7 +100,8 @@ T8_DEV void cell_flux(const CellData<T, KIND>& L, const CellData<T, KIND>& R, bo
   } else {
     T n[3], t1[3], t2[3];
     axis_basis<T>(axis, positive, n, t1, t2);
-    hll_face<T>(L.v, R.v, wall, n, t1, t2, area, g, KIND == 2);
+    T spd;   // Subgrid kernels write no speed estimates (kernels.inl:204)
+    hll_face<T>(L.v, R.v, wall, n, t1, t2, area, g, spd, KIND == 2);
   }
 }
 

@@ -13,6 +13,7 @@
 #include <thread>
 #include <vector>
 
+#include "ranges.hpp"
 #include "t8gpu_hip.h"
 
 namespace {
@@ -121,8 +122,11 @@ int iterate(Stepper* S, int kind, T* planes, size_t stride, int prev, int next, 
   const int  nt = S->plan.ntiles, ni = S->plan.n_interior_tiles;
   const int  nd = (S->plan.n_deep_tiles > 0 && S->plan.n_deep_tiles <= ni) ? S->plan.n_deep_tiles : 0;
   const bool comm = S->has_halo && S->halo.n_peers > 0;
+  t8gpu_hip::Range whole(comm ? "t8gpu.iterate_steps (exchange + 3 tile classes)" : "t8gpu.iterate_steps");
+  static const char* const stage_name[3] = {"t8gpu.rk_stage1", "t8gpu.rk_stage2", "t8gpu.rk_stage3"};
   for (int g = 0; g < 3 * n_steps; g++) {
     const int k  = g % 3;
+    t8gpu_hip::Range stage_range(stage_name[k]);
     S->sample    = S->timing > 0 && (g / 3) % S->timing == 0;
     if (S->sample) S->stages_timed++;
     const int pr = (g / 3) % 2 == 0 ? prev : next, nx = (g / 3) % 2 == 0 ? next : prev;
@@ -172,6 +176,18 @@ int iterate(Stepper* S, int kind, T* planes, size_t stride, int prev, int next, 
 }  // namespace
 
 extern "C" {
+
+// roctx ranges for host code above the C-ABI (bench.py marks pre-warm / warm-up / timed repetitions with them)
+int t8gpu_hip_range_push(const char* name) {
+  if (!t8gpu_hip::roctx().on) return 0;
+  t8gpu_hip::roctx().push(name ? name : "t8gpu");
+  return 1;
+}
+int t8gpu_hip_range_pop(void) {
+  if (!t8gpu_hip::roctx().on) return 0;
+  t8gpu_hip::roctx().pop();
+  return 1;
+}
 
 int t8gpu_hip_comm_unique_id(char* id128) {
   ncclUniqueId id;

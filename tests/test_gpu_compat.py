@@ -46,8 +46,8 @@ def test_plain_flux_kernels_vs_oracle(dtype, kind):
     # fluxes are differences of O(area) terms: normalise by the largest single-face contribution
     scale = np.abs(want).max(axis=1, keepdims=True) + part.areas.max()
     assert (np.abs(got - want) / scale).max() < TOL1[dtype]
-    if kind == hip.KEPES:
-        assert rel_err(g.speed.cpu().numpy()[None], o.speed[None]) < TOL1[dtype]
+    # per-face wave-speed estimates for every flux kind (HLL / HLLC: max |S| of the wave-speed bounds)
+    assert o.speed.min() > 0 and rel_err(g.speed.cpu().numpy()[None], o.speed[None]) < TOL1[dtype]
     # conservation: interior faces add -F and +F
     if part.B == 0:
         assert np.abs(got.sum(1)).max() < 1e-10

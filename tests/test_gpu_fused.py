@@ -29,7 +29,8 @@ def test_fused_iterate_vs_oracle(dtype, kind, mesh_args):
     o.iterate(dt, kind=kind)
     torch.cuda.synchronize()
     assert rel_err(g.state().cpu().numpy(), o.current()[:, :part.N]) < TOL1[dtype]
-    if kind == hip.KEPES:                                        # speed estimates of the last stage, every face
+    if True:                                                     # speed estimates of the last stage, every face, every flux
+        assert o.speed.min() > 0
         assert rel_err(g.speed.cpu().numpy()[None, :part.F + part.B], o.speed[None]) < TOL1[dtype] * 10
     assert (g.planes[20:25] == 0).all()                          # Fluxes planes stay zero, as after the reference's RK
     for _ in range(9):
@@ -228,3 +229,34 @@ def test_long_run_stays_physical_and_conservative(kind):
         assert float((m - m0 * (0.33333333333333 + 0.66666666666666) ** steps).abs().max()) < 2.3e-16 * steps * float(m0.abs().max())
         assert e >= e_prev - 1e-12 * abs(e_prev)
         e_prev = e
+
+
+@pytest.mark.parametrize("kind", [hip.HLL, hip.HLLC])
+def test_cfl_timestep_works_for_every_flux_kind(kind):
+    """compute_timestep (solver.cu:213-229) needs per-face speed estimates; HLL / HLLC write max(|S_l|, |S_r|)."""
+    mesh = SynthMesh(2, 4, 6, band=0.06)
+    part = mesh.partition()
+    g = PlainSolver(part, torch.float64, flux_kind=kind, mode="fused")
+    k = PlainSolver(part, torch.float64, flux_kind=hip.KEPES, mode="fused")
+    dt = 0.1 * 2.0 ** -mesh.finest_level
+    g.iterate(dt)
+    k.iterate(dt)
+    torch.cuda.synchronize()
+    assert float(g.speed[:part.F].min()) > 0
+    step, step_kepes = g.compute_timestep(cfl=0.7), k.compute_timestep(cfl=0.7)
+    assert 0 < step < float("inf") and 0.5 < step / step_kepes < 2.0      # same physics, two signal-speed estimates
+
+
+def test_stage_one_requires_prev_and_mid_to_be_the_same_planes():
+    """Stage 1 is u1 = u0 + dt/vol f(u0): the pipelined kernel never reads `prev` there, the generic one does, so a
+    call with prev != mid is refused (hipErrorInvalidValue = 1) instead of giving variant-dependent results."""
+    import ctypes as C
+    mesh = SynthMesh(2, 3, 4, band=0.06)
+    part = mesh.partition()
+    g = PlainSolver(part, torch.float64, mode="fused")
+    lib = hip.lib()
+    args = lambda prev, mid: (hip.KEPES, 1, C.byref(g.plan.c), 0, g.plan.host.ntiles, g.get_own_variables(prev), g.get_own_variables(mid),
+                              g.get_own_variables(1), hip.ptr(g.planes[25]), C.c_double(1e-3), hip.ptr(g.speed), hip.stream_ptr())
+    assert lib.t8gpu_hip_plain_fused_stage_f64(*args(0, 0)) == 0
+    assert lib.t8gpu_hip_plain_fused_stage_f64(*args(3, 0)) == 1
+    torch.cuda.synchronize()
