@@ -44,6 +44,13 @@ WORKLOADS = {
     "c5": dict(kind="plain", dim=3, base=6, lmax=8, band=0.05, dtype="f64", desc="3D hex AMR levels 6-8 (~3.93 M elements), geometry-synthetic"),
     "c5p": dict(kind="plain", dim=3, prism=(128, 128, 160), dtype="f64",
                 desc="3D prisms + hexahedra on a curved shell, 128x128x160 cells half split (~3.93 M elements), geometry-synthetic"),
+    # c5t = mixed tetrahedra / hexahedra (4 faces / 6-12 faces where the two kinds meet), curved shell, walls
+    "c5t": dict(kind="plain", dim=3, tets=(96, 96, 128), dtype="f64",
+                desc="3D tetrahedra + hexahedra on a curved shell, 96x96x128 cells in 2x2x2 blocks of either kind (~4.13 M elements), geometry-synthetic"),
+    # c5a = BASELINE config 5's LOOP: adapt (+ repartition over the ranks) every 20 steps INSIDE the measured region,
+    # on a 3D hexahedral forest refined by the reference's gradient indicator (handled by bench_adaptive below)
+    "c5a": dict(kind="plain", dim=3, adaptive=dict(every=20, min_level=5, max_level=8, threshold=10.0), dtype="f64",
+                desc="3D hex AMR levels 5-8 by the reference's indicator, adapt + repartition every 20 steps inside the timed loop"),
 }
 
 
@@ -121,8 +128,14 @@ def main():
         except ImportError:
             mode = "compat"
 
+    if "adaptive" in w:
+        return bench_adaptive(args, w, dts, tdtype, kindf, mode, rank, world, dist, rehearsal)
     t0 = time.time()
-    if "prism" in w:
+    if "tets" in w:
+        from t8gpu_amd.unstructured import TetHexMesh
+        mesh = TetHexMesh(w["tets"], tets="blocks")
+        part = mesh.partition(rank, world)
+    elif "prism" in w:
         from t8gpu_amd.unstructured import PrismHexMesh
         mesh = PrismHexMesh(w["prism"], split=0.5)
         part = mesh.partition(rank, world)
@@ -133,7 +146,7 @@ def main():
     cells = part.cells_per_element
     if w["kind"] == "plain":
         solver = PlainSolver(part, tdtype, flux_kind=kindf, mode=mode)
-        delta_t = 0.1 * float(mesh.volumes.min()) ** (1 / 3) if "prism" in w else 0.1 * 2.0 ** -mesh.finest_level
+        delta_t = (0.05 if "tets" in w else 0.1) * float(mesh.volumes.min()) ** (1 / 3) if ("prism" in w or "tets" in w) else 0.1 * 2.0 ** -mesh.finest_level
     else:
         solver = SubgridSolver(part, tdtype, flux_kind=kindf, mode=mode)
         delta_t = 0.1 * 2.0 ** -(mesh.finest_level + 2)
@@ -144,7 +157,7 @@ def main():
         from t8gpu_amd import halo as halo_mod
         halo = halo_mod.HaloExchange(part, tdtype, dist, stage_through_host=rehearsal)   # torch.distributed transport
         halo_kind = "torch.distributed (gloo, host-staged REHEARSAL)" if rehearsal else "torch.distributed"
-    if mode == "fused" and w["kind"] == "plain" and os.environ.get("T8GPU_STEPPER", "native") == "native":
+    if mode == "fused" and os.environ.get("T8GPU_STEPPER", "native") == "native":   # plain tiles and Subgrid blocks alike
         native_halo = None
         if distributed and os.environ.get("T8GPU_HALO", "native") == "native":
             native_halo = make_native_halo(part, tdtype, solver, halo, dist, rank, world)
@@ -331,6 +344,110 @@ def launch_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def bench_adaptive(args, w, dts, tdtype, kindf, mode, rank, world, dist, rehearsal):
+    """BASELINE config 5's loop: K steps with adapt + repartition every `every` steps INSIDE the timed region
+    (MeshManager::adapt + partition + compute_connectivity_information, mesh_manager.inl:196-330,626-723,333-481, and this
+    backend's tile plan). One JSON line: value = cell-updates/s of the whole loop; config carries the step and the
+    cycle time separately (the device kernels are the small part of a cycle, as in the reference: DESIGN.md section 7)."""
+    from t8gpu_amd import amr
+    from t8gpu_amd.halo import HaloExchange
+    from t8gpu_amd.solver import PlainSolver
+    from t8gpu_amd.synth import SynthMesh
+    a = w["adaptive"]
+    t0 = time.time()
+
+    def adapt(s):
+        if world == 1:
+            new = amr.adapt(s, a["threshold"], a["min_level"], a["max_level"])[0]
+        else:
+            new = amr.adapt_partitioned(s, dist, host_staged=rehearsal, threshold=a["threshold"], min_level=a["min_level"],
+                                        max_level=a["max_level"])
+        return new
+
+    def total(x, op="sum"):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX)
+        return float(t.item())
+
+    mesh = SynthMesh(w["dim"], a["min_level"], a["min_level"])
+    solver = PlainSolver(mesh.partition(rank, world), tdtype, flux_kind=kindf, mode=mode)
+    for _ in range(a["max_level"] - a["min_level"]):        # the reference adapts before it starts stepping
+        solver = adapt(solver)
+        ic = torch.from_numpy(solver.part.kh_initial_state()).to(tdtype).cuda()
+        solver.planes[5 * solver.next:5 * solver.next + 5] = ic
+    setup_s = time.time() - t0
+
+    def attach(s):
+        halo = HaloExchange(s.part, tdtype, dist, stage_through_host=rehearsal) if world > 1 else None
+        if world == 1 and mode == "fused":
+            s.use_native_stepper()
+        return halo
+
+    halo = attach(solver)
+    t_step = t_cycle = 0.0
+    cells = cycles = 0
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def chunk(n, timed):
+        nonlocal t_step, cells
+        dt = 0.1 * 2.0 ** -solver.part.mesh.finest_level
+        sync()
+        t1 = time.perf_counter()
+        if halo is None:
+            solver.iterate_steps(n, dt)
+        else:
+            for _ in range(n):
+                solver.iterate(dt, halo=halo)
+        sync()
+        if timed:
+            t_step += time.perf_counter() - t1
+            cells += solver.N * n
+
+    chunk(args.warmup, False)
+    sync()
+    tstart = time.perf_counter()
+    done = 0
+    while done < args.steps:
+        n = min(a["every"], args.steps - done)
+        chunk(n, True)
+        done += n
+        if done < args.steps:
+            sync()
+            t1 = time.perf_counter()
+            solver = adapt(solver)
+            halo = attach(solver)
+            sync()
+            t_cycle += time.perf_counter() - t1
+            cycles += 1
+    sync()
+    elapsed = total(time.perf_counter() - tstart, "max")
+    finite = bool(torch.isfinite(solver.state()).all().item())
+    tot_cells = total(cells)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "M cell-updates/sec (flux+RK3 step) on Kelvin-Helmholtz AMR", "value": round(tot_cells / elapsed / 1e6, 2),
+            "unit": "M cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": dts, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {w['desc']}", "elements_at_end": int(total(solver.N)), "flux": args.flux,
+                       "kernels": mode, "adapt_every": a["every"], "adapt_cycles_timed": cycles,
+                       "step_ms": round(total(t_step, "max") / max(1, args.steps) * 1e3, 4),
+                       "cycle_ms": round(total(t_cycle, "max") / max(1, cycles) * 1e3, 2) if cycles else None,
+                       "stepping_only_M_cell_updates_per_s": round(tot_cells / total(t_step, "max") / 1e6, 2),
+                       "partition": f"sfc-contiguous x{world}, repartitioned at every adapt", "finite": finite,
+                       "setup_s": round(setup_s, 1)},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def measured_profile(workload, dts, flux, mode, world):
     """The committed rocprofv3 PMC record of exactly this workload / dtype / flux / kernel tier at N = 1
     (profiles/traffic.json, written by scripts/profile_gpu.sh + commit_profile.py): HBM bytes per launch of the
@@ -353,9 +470,10 @@ def fused_min_bytes(solver, kind, ft, part):
     if kind == "plain":
         n_tf = int(h.face_lr.size)                       # tile faces (cut faces appear in both tiles)
         geo = 2 * n_tf if h.geo_table.shape[0] else 4 * ft * n_tf
-        plan = n_tf * (4 + 4) + geo + int(h.ell.size) * 2 + int(h.halo_ids.size) * 4 + 3 * 4 * (h.ntiles + 1)
+        # speed estimates (+ the original face ids they are scattered by) are written by the third stage only
+        plan = n_tf * (4 + 4 / 3.0) + geo + int(h.ell.size) * 2 + int(h.halo_ids.size) * 4 + 32 * h.ntiles
         state = part.N * ft * (5 + 5 + 10.0 / 3.0 + 1)
-        return int(state + (part.F + part.B) * ft + plan)
+        return int(state + (part.F + part.B) * ft / 3.0 + plan)
     cells = part.N * part.cells_per_element
     plan = part.N * 64 + h.n_entries * 16
     return int(cells * ft * (5 + 5 + 10.0 / 3.0) + part.N * ft + plan)
@@ -451,9 +569,9 @@ def bring_up_native_stepper(solver, native_halo, delta_t, part, tdtype, dist, ra
     except Exception:  # noqa: BLE001
         pass
     solver.stepper = None
-    tot = part.N + part.G
+    ic = torch.from_numpy(part.kh_initial_state()).to(tdtype).cuda()      # [5, (N + G) * cells per element]
     solver.planes[:25].zero_()
-    solver.planes[0:5, :tot] = torch.from_numpy(part.kh_initial_state()).to(tdtype).cuda()
+    solver.planes[0:5, :ic.shape[1]] = ic
     solver.next, solver.prev = 0, 3   # Step0 / Step3, as after construction (solver.h:100-101)
     return None
 

@@ -155,6 +155,8 @@ namespace t8gpu::hip {
       t8gpu_plan_plain_arrays(h, elem_off.data(), halo_off.data(), face_off.data(), halo_ids.data(), face_lr.data(),
                               geo.data(), face_orig.data(), csr_off.data(), csr_ent.data(), tile_order.data());
       t8gpu_plan_plain_compressed(h, ell.data(), ngeo ? geo_idx.data() : nullptr, ngeo ? table.data() : nullptr);
+      std::vector<int32_t> tile_desc(8 * std::max<size_t>(nt, 1));
+      t8gpu_plan_plain_tile_desc(h, tile_desc.data());
       t8gpu_plan_plain_destroy(h);
       m_plan.elem_off   = up(elem_off);
       m_plan.halo_off   = up(halo_off);
@@ -166,6 +168,7 @@ namespace t8gpu::hip {
       m_plan.csr_off    = up(csr_off);
       m_plan.csr_ent    = up(csr_ent);
       m_plan.tile_order = up(tile_order);
+      m_plan.tile_desc  = up(tile_desc);
       m_plan.ell        = up(ell);
       m_plan.geo_idx    = ngeo ? up(geo_idx) : nullptr;
       m_plan.geo_table  = ngeo ? up(std::vector<ft>(table.begin(), table.end())) : nullptr;
@@ -291,7 +294,7 @@ namespace t8gpu::hip {
                                           m.face_neighbors.data(), m.face_level_difference.data(), m.face_neighbor_offset.data(),
                                           m.face_normals.data());
       if (!h) T8GPU_ABORT("t8gpu_plan_subgrid_create failed (axis-aligned unit normals required, as in the reference)");
-      int64_t sz[4];
+      int64_t sz[8];
       t8gpu_plan_subgrid_sizes(h, sz);
       std::vector<int32_t> block_rec(16 * static_cast<size_t>(std::max<int32_t>(1, m.num_local_elements))),
           bf_rec(4 * static_cast<size_t>(std::max<int64_t>(1, sz[0])));
@@ -307,6 +310,7 @@ namespace t8gpu::hip {
       m_plan.rank         = m.rank;
       m_plan.max_faces_per_block = static_cast<int32_t>(sz[1]);
       m_plan.n_interior_blocks   = static_cast<int32_t>(sz[3]);
+      m_plan.n_deep_blocks       = static_cast<int32_t>(sz[4]);
     }
     ~SubgridFusedPlan() {
       (void)hipFree(m_block_rec);

@@ -143,12 +143,17 @@ typedef struct T8gpuPlainPlan {
    * elements and <= 1024 faces the software-pipelined kernel variant is used (two passes of 256 faces up
    * to 512 faces per tile, up to four above) */
   const uint16_t* ell;        /* [N][ell_width] copy of the CSR lists, 0xFFFF-padded, 16-byte rows      */
-  const uint16_t* geo_idx;    /* per tile face: row of geo_table                                      */
+  const uint16_t* geo_idx;    /* per tile face: row of geo_table (bits 0-12) | direction code << 13: 2 * axis + (normal
+                               * along +axis) for an exact axis normal, 6 otherwise. Inside every block of 256 tile
+                               * faces the faces are ordered by that code                                  */
   const void*     geo_table;  /* float_type [n_geo][12]: distinct {nx,ny,nz,area, t1x,t1y,t1z,0, t2x,t2y,t2z,0} */
   int32_t n_geo;
   int32_t max_slots;          /* max over tiles of own + halo elements (0: unknown, max_elems + max_halo is used) */
   int32_t n_deep_tiles;       /* leading tiles of tile_order that read nothing a ghost-reading tile owns (0: unknown) */
   int32_t reserved;
+  const int32_t* tile_desc;   /* [ntiles][8], in tile_order order: {first element, elements, first halo entry, halo entries,
+                               * first face, faces, 0, 0} of tile_order[k] -- one 32-byte record per tile for the persistent
+                               * kernel, which reads it several tiles ahead (NULL: that kernel is not used) */
 } T8gpuPlainPlan;
 
 /* tile_begin/tile_count select a range of tile_order (0, ntiles = everything; [0, n_interior) can run
@@ -231,6 +236,11 @@ int t8gpu_hip_plain_stepper_iterate_steps_f64(void* stepper, int flux_kind, doub
 /* optional HIP-event timing of the stage kernels (for roofline accounting): enable = 0 off, n > 0 = the stage
  * kernels of every n-th step of a call are bracketed by events (n > 1 keeps the host-side cost of the
  * events out of latency-bound multi-rank runs); elapsed() sums what has been recorded since. */
+/* hipGraph replay ("hipGraph capture of the 3-stage step"): enable = 1 -> an iterate_steps() call is captured
+ * once per argument set (streams joined through their events, the RCCL group included when there is a halo) and
+ * replayed with ONE hipGraphLaunch afterwards; enable = 0 -> direct enqueue (default); enable < 0 -> query only.
+ * counts (may be NULL) receives {captures, replays}. A capture the runtime refuses returns its error code. */
+int t8gpu_hip_plain_stepper_graph(void* stepper, int enable, int* counts);
 int t8gpu_hip_plain_stepper_timing(void* stepper, int enable);
 int t8gpu_hip_plain_stepper_elapsed(void* stepper, double* total_ms, int* launches);
 int t8gpu_hip_plain_stepper_timed_stages(void* stepper); /* RK stages covered by elapsed() */
@@ -249,6 +259,8 @@ typedef struct T8gpuSubgridPlan {
   const int32_t* bf_rec;        /* [n_entries][4] generic faces in the same order: {other block (-1 wall), code
                                    (bit 12: the block is the face's RIGHT side), area (2 words)}; walls first */
   int32_t num_elements, rank, max_faces_per_block, n_interior_blocks;
+  int32_t n_deep_blocks;        /* leading blocks that have no neighbour touching a ghost block (0: unknown) */
+  int32_t reserved;
 } T8gpuSubgridPlan;
 
 /* block_begin/block_count select a range of block_order (0, num_elements = everything; [0, n_interior_blocks)
@@ -259,6 +271,18 @@ int t8gpu_hip_subgrid_fused_stage_f32(int flux_kind, int stage, const T8gpuSubgr
 int t8gpu_hip_subgrid_fused_stage_f64(int flux_kind, int stage, const T8gpuSubgridPlan* plan, int block_begin,
                                       int block_count, T8gpuVars_f64 prev, T8gpuVars_f64 mid, T8gpuVars_f64 out,
                                       const double* volumes, double delta_t, void* stream);
+
+/* Native step driver for Subgrid blocks: SubgridCompressibleEulerSolver::iterate (examples/subgrid/solver.inl:152-266)
+ * in one host call, the pipeline of t8gpu_hip_plain_stepper_* over the block classes of the plan (deep interior /
+ * near-boundary / ghost-touching blocks on three streams, one RCCL exchange of whole ghost blocks per stage;
+ * halo->cells_per_element = 4^rank). `planes` = 25 variable planes of `stride` values (stride >= (N + G) * 4^rank),
+ * `volumes` the per-block volume array. The handle is destroyed / timed with the t8gpu_hip_plain_stepper_destroy,
+ * _timing, _elapsed and _timed_stages entry points above. */
+int t8gpu_hip_subgrid_stepper_create(const T8gpuSubgridPlan* plan, const T8gpuHalo* halo_or_null, void** stepper);
+int t8gpu_hip_subgrid_stepper_iterate_steps_f32(void* stepper, int flux_kind, float* planes, size_t stride, const float* volumes,
+                                                int prev, int next, float delta_t, int n_steps, void* stream);
+int t8gpu_hip_subgrid_stepper_iterate_steps_f64(void* stepper, int flux_kind, double* planes, size_t stride, const double* volumes,
+                                                int prev, int next, double delta_t, int n_steps, void* stream);
 
 /* ---- scalar reductions next to the hot path -------------------------------------------
  * Device-side replacements of the two host round trips of the reference solvers; results are device

@@ -64,13 +64,15 @@ void t8gpu_plan_plain_arrays(const void* plan, int32_t* elem_off, int32_t* halo_
                              int32_t* csr_off, uint16_t* csr_ent, int32_t* tile_order);
 /* ell[N*ell_width], geo_idx[n_faces], geo_table[n_geo*12] = {n, area, t1, 0, t2, 0} rows */
 void t8gpu_plan_plain_compressed(const void* plan, uint16_t* ell, uint16_t* geo_idx, double* geo_table);
+/* tile_desc[ntiles][8] of T8gpuPlainPlan (one record per tile in tile_order order) */
+void t8gpu_plan_plain_tile_desc(const void* plan, int32_t* tile_desc);
 
 /* ---- per-block face lists of the fused Subgrid kernels (see T8gpuSubgridPlan in t8gpu_hip.h) -------- */
 void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, const int32_t* face_neighbors,
                                 const int32_t* face_level_difference, const int32_t* face_neighbor_offset,
                                 const double* normals);
 void  t8gpu_plan_subgrid_destroy(void* plan);
-/* sizes[4] = {n_entries, max faces per block, F + B, n_interior_blocks} */
+/* sizes[8] = {n_entries, max faces per block, F + B, n_interior_blocks, n_deep_blocks, 0, 0, 0} */
 void t8gpu_plan_subgrid_sizes(const void* plan, int64_t* sizes);
 /* block_order[N]: blocks that touch no ghost block first (they can run during the halo exchange) */
 void t8gpu_plan_subgrid_order(const void* plan, int32_t* block_order);

@@ -50,16 +50,39 @@ def build_host(force=False):
     return HOST_LIB
 
 
-def build_hip(force=False):
+HIP_FLAGS = ["--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-Wall",
+             "-Wno-unused-function"]
+
+
+def build_hip(force=False, variant=None, defines=()):
+    """One object per .hip file (compiled in parallel, rebuilt only when the file or a header changed), then one link.
+    variant / defines: an experiment build with extra -D flags into lib/variants/libt8gpu_hip_<variant>.so
+    (load it with T8GPU_HIP_LIB=...; used for A/B measurements, never by the product path)."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = _glob(os.path.join(CSRC, "hip"), (".hip", ".cpp"))
-    deps = srcs + _glob(os.path.join(CSRC, "hip"), (".h", ".hpp")) + _glob(os.path.join(ROOT, "include"), (".h",))
-    if force or _newer(HIP_LIB, deps):
-        os.makedirs(LIB, exist_ok=True)
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        _run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-shared", "-munsafe-fp-atomics", "-fno-slp-vectorize",
-              "-I", os.path.join(ROOT, "include"), "-I", os.path.join(CSRC, "hip"),
-              "-Wall", "-Wno-unused-function", "-o", HIP_LIB] + srcs + ["-L/opt/rocm/lib", "-lrccl"])
-    return HIP_LIB
+    hdrs = _glob(os.path.join(CSRC, "hip"), (".h", ".hpp")) + _glob(os.path.join(ROOT, "include"), (".h",))
+    objdir = os.path.join(LIB, "obj", variant or "default")
+    target = HIP_LIB if variant is None else os.path.join(LIB, "variants", f"libt8gpu_hip_{variant}.so")
+    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.dirname(target), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    stamp = os.path.join(objdir, "flags.txt")
+    flags = HIP_FLAGS + list(defines)
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+        force = True
+    jobs = []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if force or _newer(obj, [src] + hdrs):
+            jobs.append([hipcc] + flags + ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(CSRC, "hip"), "-c", src, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
+            list(pool.map(_run, jobs))
+        open(stamp, "w").write(" ".join(flags))
+    objs = [os.path.join(objdir, os.path.basename(src) + ".o") for src in srcs]
+    if jobs or _newer(target, objs):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs + ["-L/opt/rocm/lib", "-lrccl"])
+    return target
 
 
 def build_oracle(force=False):

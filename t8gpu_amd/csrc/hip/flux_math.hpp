@@ -284,6 +284,24 @@ T8_DEV void from_face_frame(const T n[3], const T t1[3], const T t2[3], const T 
 // ~20. Frame-invariant pieces (|v|^2, the scalar entropy variable) are not rotated at all.
 // Same flux as kernels.cu:38-133,220-279 up to rounding (a few ulp; parity tolerance in tests/).
 // ------------------------------------------------------------------------------------------------
+// ROUNDING IS PART OF THE CONTRACT of this tier: the fused kernels promise results that do not depend on the tiling,
+// the partition or the kernel variant, bit for bit. Left to the compiler, which product of `a*b - c*d` is fused into
+// an FMA depends on the code around the expression (measured: one kernel that routed the face velocities through
+// branches differed from the others by one ulp in a few hundred values). Every function below therefore switches
+// contraction off and spells its FMAs out; kernels use rk_stage_update() for the RK stage for the same reason.
+T8_DEV float  t8_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+T8_DEV double t8_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// one SSP-RK3 stage value (ssp_runge_kutta.inl:30-99) from the previous-step value, the stage's source value and
+// sa = dt / volume * (sum of the element's face fluxes)
+template <class T, int STAGE>
+T8_DEV T rk_stage_update(T pv, T s0, T scale, T acc) {
+#pragma clang fp contract(off)
+  if (STAGE == 1) return t8_fma(scale, acc, s0);
+  if (STAGE == 2) return t8_fma(rk3c<T>::c23 * scale, acc, t8_fma(rk3c<T>::c22, s0, rk3c<T>::c21 * pv));
+  return t8_fma(rk3c<T>::c33 * scale, acc, t8_fma(rk3c<T>::c32, s0, rk3c<T>::c31 * pv));
+}
+
 // Division in the fast tier. The reference-dataflow kernels keep IEEE division (v_div_scale / v_div_fmas /
 // v_div_fixup: 10 instructions in fp32, 13 in fp64); here operands are O(1) physical quantities, never
 // denormal or huge, so a reciprocal plus Newton steps is enough: fp32 v_rcp_f32 (1 ulp) and one
@@ -323,6 +341,7 @@ T8_DEV double t8_div(double a, double b) {
 // host libm in tests/test_gpu_fastmath.py): ~35 instructions.
 T8_DEV float  t8_log_fast(float x) { return logf(x); }
 T8_DEV double t8_log_fast(double x) {
+#pragma clang fp contract(off)
   double     m  = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
   int        e  = __builtin_amdgcn_frexp_exp(x);
   const bool lo = m < 0.70710678118654752440;
@@ -337,7 +356,7 @@ T8_DEV double t8_log_fast(double x) {
   const double R    = t2 + t1;
   const double hfsq = 0.5 * f * f;
   const double dk   = static_cast<double>(e);
-  return dk * 6.93147180369123816490e-01 - ((hfsq - __builtin_fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+  return __builtin_fma(dk, 6.93147180369123816490e-01, -((hfsq - __builtin_fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f));
 }
 
 template <class T>
@@ -348,6 +367,7 @@ constexpr int kPrimWords = 9;
 
 template <class T>
 T8_DEV Prim<T> prim_from_state(const T s[5]) {
+#pragma clang fp contract(off)
   const T one = T(1), half = T(0.5), kappa = T(1.4);
   const T km1 = kappa - one;
   Prim<T> q;
@@ -356,35 +376,37 @@ T8_DEV Prim<T> prim_from_state(const T s[5]) {
   q.vx       = s[1] * ir;
   q.vy       = s[2] * ir;
   q.vz       = s[3] * ir;
-  const T ke = half * (q.vx * q.vx + q.vy * q.vy + q.vz * q.vz);
-  q.p        = km1 * (s[4] - s[0] * ke);
+  const T ke = half * t8_fma(q.vx, q.vx, t8_fma(q.vy, q.vy, q.vz * q.vz));
+  q.p        = km1 * t8_fma(-s[0], ke, s[4]);
   const T rp = t8_div(s[0], q.p);
   q.beta     = half * rp;
   q.lrho     = t8_log_fast(s[0]);
   const T lp = t8_log_fast(q.p);
   q.lbeta    = q.lrho - lp;
-  q.v0       = (kappa - (lp - kappa * q.lrho)) * (one / km1) - rp * ke;
+  q.v0       = t8_fma(-rp, ke, (kappa - t8_fma(-kappa, q.lrho, lp)) * (one / km1));
   return q;
 }
 
 // logarithmic mean from the two values and log(aR) - log(aL)
 T8_DEV double ln_mean_dlog(double aL, double aR, double dlog) {
+#pragma clang fp contract(off)
   const double d = aR - aL, s = aR + aL;
   const double f = t8_div(d, s);
   const double u = f * f;
   const bool   small = u < 1.0e-4;
   const double num = small ? s * 52.50 : d;
-  const double den = small ? (105.0 + u * (35.0 + u * (21.0 + u * 15.0))) : dlog;
+  const double den = small ? t8_fma(u, t8_fma(u, t8_fma(u, 15.0, 21.0), 35.0), 105.0) : dlog;
   return t8_div(num, den);
 }
 // fp32: a difference of stored logs would cost accuracy near the branch switch; v_log_f32 is cheap.
 T8_DEV float ln_mean_dlog(float aL, float aR, float /*dlog*/) {
+#pragma clang fp contract(off)
   const float d = aR - aL, s = aR + aL;
   const float f = t8_div(d, s);
   const float u = f * f;
   const bool  small = u < 1.0e-4f;
   const float num = small ? s * 52.50f : d;
-  const float den = small ? (105.0f + u * (35.0f + u * (21.0f + u * 15.0f))) : logf(t8_div(aR, aL));
+  const float den = small ? t8_fma(u, t8_fma(u, t8_fma(u, 15.0f, 21.0f), 35.0f), 105.0f) : logf(t8_div(aR, aL));
   return t8_div(num, den);
 }
 
@@ -393,10 +415,11 @@ T8_DEV float ln_mean_dlog(float aL, float aR, float /*dlog*/) {
 // core: velocities already in the face frame; f = area-scaled flux in the face frame
 template <class T>
 T8_DEV void kepes_core(const Prim<T>& L, const Prim<T>& R, T uL, T vL, T wL, T uR, T vR, T wR, T area, T f[5], T& speed) {
+#pragma clang fp contract(off)
   const T one = T(1), half = T(0.5), kappa = T(1.4);
   const T km1 = kappa - one, skm1 = one / km1, ikappa = one / kappa;
-  const T qL = half * (uL * uL + vL * vL + wL * wL);
-  const T qR = half * (uR * uR + vR * vR + wR * wR);
+  const T qL = half * t8_fma(uL, uL, t8_fma(vL, vL, wL * wL));
+  const T qR = half * t8_fma(uR, uR, t8_fma(vR, vR, wR * wR));
 
   const T rho  = ln_mean_dlog(L.rho, R.rho, R.lrho - L.lrho);
   const T bhat = ln_mean_dlog(L.beta, R.beta, R.lbeta - L.lbeta);
@@ -404,15 +427,15 @@ T8_DEV void kepes_core(const Prim<T>& L, const Prim<T>& R, T uL, T vL, T wL, T u
   const T rho_mean = half * (L.rho + R.rho);
   const T u = half * (uL + uR), v = half * (vL + vR), w = half * (wL + wR);
   const T a  = t8_sqrt_fast(t8_div(kappa * half * (L.p + R.p), rho));
-  const T h  = (kappa / (T(2) * km1)) * ib + half * (uL * uR + vL * vR + wL * wR);
+  const T h  = t8_fma(kappa / (T(2) * km1), ib, half * t8_fma(uL, uR, t8_fma(vL, vR, wL * wR)));
   const T p1 = t8_div(rho_mean, L.beta + R.beta);
   const T q2 = qL + qR;
 
   const T Fs0 = rho * u;
-  const T Fs1 = Fs0 * u + p1;
+  const T Fs1 = t8_fma(Fs0, u, p1);
   const T Fs2 = Fs0 * v;
   const T Fs3 = Fs0 * w;
-  const T Fs4 = Fs0 * half * (skm1 * ib - q2) + u * Fs1 + v * Fs2 + w * Fs3;
+  const T Fs4 = t8_fma(Fs0 * half, t8_fma(skm1, ib, -q2), t8_fma(u, Fs1, t8_fma(v, Fs2, w * Fs3)));
 
   speed = t8_abs(u) + a;
 
@@ -424,41 +447,44 @@ T8_DEV void kepes_core(const Prim<T>& L, const Prim<T>& R, T uL, T vL, T wL, T u
 
   const T rpL = L.beta + L.beta, rpR = R.beta + R.beta;
   const T J0 = R.v0 - L.v0;
-  const T J1 = rpR * uR - rpL * uL;
-  const T J2 = rpR * vR - rpL * vL;
-  const T J3 = rpR * wR - rpL * wL;
+  const T J1 = t8_fma(rpR, uR, -(rpL * uL));
+  const T J2 = t8_fma(rpR, vR, -(rpL * vL));
+  const T J3 = t8_fma(rpR, wR, -(rpL * wL));
   const T J4 = rpL - rpR;
 
   const T ua = u * a;
-  const T hm = h - ua, hp = h + ua, k2 = half * (u * u + v * v + w * w);
-  const T c  = J0 + v * J2 + w * J3;  // common part of the three acoustic/entropy columns
-  const T d0 = D0 * (c + (u - a) * J1 + hm * J4);
-  const T d1 = D1 * (c + u * J1 + k2 * J4);
-  const T d2 = D2 * (J2 + v * J4);
-  const T d3 = D2 * (J3 + w * J4);
-  const T d4 = D4 * (c + (u + a) * J1 + hp * J4);
+  const T hm = h - ua, hp = h + ua, k2 = half * t8_fma(u, u, t8_fma(v, v, w * w));
+  const T c  = t8_fma(w, J3, t8_fma(v, J2, J0));  // common part of the three acoustic/entropy columns
+  const T d0 = D0 * t8_fma(hm, J4, t8_fma(u - a, J1, c));
+  const T d1 = D1 * t8_fma(k2, J4, t8_fma(u, J1, c));
+  const T d2 = D2 * t8_fma(v, J4, J2);
+  const T d3 = D2 * t8_fma(w, J4, J3);
+  const T d4 = D4 * t8_fma(hp, J4, t8_fma(u + a, J1, c));
   const T s014 = d0 + d1 + d4;
-  const T f0 = area * (Fs0 - half * s014);
-  const T f1 = area * (Fs1 - half * ((u - a) * d0 + u * d1 + (u + a) * d4));
-  const T f2 = area * (Fs2 - half * (v * s014 + d2));
-  const T f3 = area * (Fs3 - half * (w * s014 + d3));
-  const T f4 = area * (Fs4 - half * (hm * d0 + k2 * d1 + v * d2 + w * d3 + hp * d4));
-  f[0] = f0;
-  f[1] = f1;
-  f[2] = f2;
-  f[3] = f3;
-  f[4] = f4;
+  f[0] = area * t8_fma(-half, s014, Fs0);
+  f[1] = area * t8_fma(-half, t8_fma(u + a, d4, t8_fma(u, d1, (u - a) * d0)), Fs1);
+  f[2] = area * t8_fma(-half, t8_fma(v, s014, d2), Fs2);
+  f[3] = area * t8_fma(-half, t8_fma(w, s014, d3), Fs3);
+  f[4] = area * t8_fma(-half, t8_fma(hp, d4, t8_fma(w, d3, t8_fma(v, d2, t8_fma(k2, d1, hm * d0)))), Fs4);
+}
+
+// The rotation into the face frame and back, spelled out once (same reason: one rounding sequence everywhere).
+template <class T>
+T8_DEV T dot3(T x, T y, T z, const T b[3]) {
+#pragma clang fp contract(off)
+  return t8_fma(z, b[2], t8_fma(y, b[1], x * b[0]));
 }
 
 template <class T>
 T8_DEV void kepes_prim(const Prim<T>& L, const Prim<T>& R, bool mirror, const T n[3], const T t1[3], const T t2[3],
                        T area, T g[5], T& speed) {
-  const T uL = L.vx * n[0] + L.vy * n[1] + L.vz * n[2];
-  const T vL = L.vx * t1[0] + L.vy * t1[1] + L.vz * t1[2];
-  const T wL = L.vx * t2[0] + L.vy * t2[1] + L.vz * t2[2];
-  T       uR = R.vx * n[0] + R.vy * n[1] + R.vz * n[2];
-  T       vR = R.vx * t1[0] + R.vy * t1[1] + R.vz * t1[2];
-  T       wR = R.vx * t2[0] + R.vy * t2[1] + R.vz * t2[2];
+#pragma clang fp contract(off)
+  const T uL = dot3<T>(L.vx, L.vy, L.vz, n);
+  const T vL = dot3<T>(L.vx, L.vy, L.vz, t1);
+  const T wL = dot3<T>(L.vx, L.vy, L.vz, t2);
+  T       uR = dot3<T>(R.vx, R.vy, R.vz, n);
+  T       vR = dot3<T>(R.vx, R.vy, R.vz, t1);
+  T       wR = dot3<T>(R.vx, R.vy, R.vz, t2);
   if (mirror) {
     uR = -uL;
     vR = vL;
@@ -467,9 +493,9 @@ T8_DEV void kepes_prim(const Prim<T>& L, const Prim<T>& R, bool mirror, const T 
   T f[5];
   kepes_core<T>(L, R, uL, vL, wL, uR, vR, wR, area, f, speed);
   g[0] = f[0];
-  g[1] = f[1] * n[0] + f[2] * t1[0] + f[3] * t2[0];
-  g[2] = f[1] * n[1] + f[2] * t1[1] + f[3] * t2[1];
-  g[3] = f[1] * n[2] + f[2] * t1[2] + f[3] * t2[2];
+  g[1] = t8_fma(f[3], t2[0], t8_fma(f[2], t1[0], f[1] * n[0]));
+  g[2] = t8_fma(f[3], t2[1], t8_fma(f[2], t1[1], f[1] * n[1]));
+  g[3] = t8_fma(f[3], t2[2], t8_fma(f[2], t1[2], f[1] * n[2]));
   g[4] = f[4];
 }
 
@@ -481,6 +507,7 @@ T8_DEV T axis_pick(T x, T y, T z, int a) { return a == 0 ? x : (a == 1 ? y : z);
 
 template <class T>
 T8_DEV void kepes_axis(const Prim<T>& L, const Prim<T>& R, bool mirror, int axis, bool positive, T area, T g[5], T& speed) {
+#pragma clang fp contract(off)
   const int a1 = axis == 2 ? 0 : axis + 1, a2 = axis == 0 ? 2 : axis - 1;
   const T   uLp = axis_pick(L.vx, L.vy, L.vz, axis), uRp = axis_pick(R.vx, R.vy, R.vz, axis);
   const T   uL = positive ? uLp : -uLp;
@@ -502,56 +529,95 @@ T8_DEV void kepes_axis(const Prim<T>& L, const Prim<T>& R, bool mirror, int axis
   g[4] = f[4];
 }
 
+// Face with normal s * e_AXIS (s = +-1) in exactly the frame face_basis() returns for that normal:
+//   AXIS 0: t1 = (0, 0, -s), t2 = (0, 1, 0);   AXIS 1: t1 = (s, 0, 0), t2 = (0, 0, -1);   AXIS 2: t1 = (0, s, 0), t2 = (-1, 0, 0)
+// Every product of the general rotation (kepes_prim) is then a product with 0 or +-1, so selecting components and
+// signs gives the SAME values (at most the sign of a zero differs): a face may be evaluated by either form, e.g. by
+// this one where a whole wavefront shares the direction and by the general one in a mixed wavefront of another tile.
+template <class T, int AXIS>
+T8_DEV void kepes_axis_fixed(const Prim<T>& L, const Prim<T>& R, bool mirror, T s, T area, T g[5], T& speed) {
+#pragma clang fp contract(off)
+  T uL, vL, wL, uR, vR, wR;
+  if (AXIS == 0) {
+    uL = s * L.vx; vL = -(s * L.vz); wL = L.vy;
+    uR = s * R.vx; vR = -(s * R.vz); wR = R.vy;
+  } else if (AXIS == 1) {
+    uL = s * L.vy; vL = s * L.vx; wL = -L.vz;
+    uR = s * R.vy; vR = s * R.vx; wR = -R.vz;
+  } else {
+    uL = s * L.vz; vL = s * L.vy; wL = -L.vx;
+    uR = s * R.vz; vR = s * R.vy; wR = -R.vx;
+  }
+  if (mirror) {
+    uR = -uL;
+    vR = vL;
+    wR = wL;
+  }
+  T f[5];
+  kepes_core<T>(L, R, uL, vL, wL, uR, vR, wR, area, f, speed);
+  g[0] = f[0];
+  g[4] = f[4];
+  if (AXIS == 0) {
+    g[1] = s * f[1]; g[2] = f[3]; g[3] = -(s * f[2]);
+  } else if (AXIS == 1) {
+    g[1] = s * f[2]; g[2] = s * f[1]; g[3] = -f[3];
+  } else {
+    g[1] = -f[3]; g[2] = s * f[2]; g[3] = s * f[1];
+  }
+}
+
 // HLL for the fast tier: the formulas of hll_ref (examples/subgrid/kernels.inl:263-332) with shared
 // reciprocals and the fast division above; takes the states already rotated into the face frame.
 template <class T>
 T8_DEV void hll_fast(const T uL[5], const T uR[5], T F[5], T& speed) {
+#pragma clang fp contract(off)
   const T zero = T(0), one = T(1), half = T(0.5);
   const T gm1 = T(1.4) - one;
   const T irl = t8_rcp(uL[0]), irr = t8_rcp(uR[0]);
   const T v1l = uL[1] * irl, v2l = uL[2] * irl, v3l = uL[3] * irl;
   const T v1r = uR[1] * irr, v2r = uR[2] * irr, v3r = uR[3] * irr;
-  const T kl = half * (v1l * v1l + v2l * v2l + v3l * v3l), kr = half * (v1r * v1r + v2r * v2r + v3r * v3r);
-  const T pl = gm1 * (uL[4] - uL[0] * kl), pr = gm1 * (uR[4] - uR[0] * kr);
+  const T kl = half * t8_fma(v1l, v1l, t8_fma(v2l, v2l, v3l * v3l)), kr = half * t8_fma(v1r, v1r, t8_fma(v2r, v2r, v3r * v3r));
+  const T pl = gm1 * t8_fma(-uL[0], kl, uL[4]), pr = gm1 * t8_fma(-uR[0], kr, uR[4]);
   const T Hl = (uL[4] + pl) * irl, Hr = (uR[4] + pr) * irr;
   const T cl = t8_sqrt_fast(gm1 * (Hl - kl)), cr = t8_sqrt_fast(gm1 * (Hr - kr));
   const T wl = t8_sqrt_fast(uL[0]), wr = t8_sqrt_fast(uR[0]);
   const T iw = t8_rcp(wl + wr);
-  const T v1 = (wl * v1l + wr * v1r) * iw, v2 = (wl * v2l + wr * v2r) * iw, v3 = (wl * v3l + wr * v3r) * iw;
-  const T H  = (wl * Hl + wr * Hr) * iw;
-  const T c  = t8_sqrt_fast(gm1 * (H - half * (v1 * v1 + v2 * v2 + v3 * v3)));
+  const T v1 = t8_fma(wl, v1l, wr * v1r) * iw, v2 = t8_fma(wl, v2l, wr * v2r) * iw, v3 = t8_fma(wl, v3l, wr * v3r) * iw;
+  const T H  = t8_fma(wl, Hl, wr * Hr) * iw;
+  const T c  = t8_sqrt_fast(gm1 * t8_fma(-half, t8_fma(v1, v1, t8_fma(v2, v2, v3 * v3)), H));
   const T Sl = t8_min(v1 - c, v1l - cl), Sr = t8_max(v1 + c, v1r + cr);
   speed      = t8_max(t8_abs(Sl), t8_abs(Sr));
   const T sl = t8_min(Sl, zero);
   const T sr = t8_max(Sr, zero);
-  const T Fl[5] = {uL[1], uL[1] * v1l + pl, uL[1] * v2l, uL[1] * v3l, uL[1] * Hl};
-  const T Fr[5] = {uR[1], uR[1] * v1r + pr, uR[1] * v2r, uR[1] * v3r, uR[1] * Hr};
+  const T Fl[5] = {uL[1], t8_fma(uL[1], v1l, pl), uL[1] * v2l, uL[1] * v3l, uL[1] * Hl};
+  const T Fr[5] = {uR[1], t8_fma(uR[1], v1r, pr), uR[1] * v2r, uR[1] * v3r, uR[1] * Hr};
   const T id = t8_rcp(sr - sl);
 #pragma unroll
-  for (int k = 0; k < 5; k++) F[k] = ((sr * Fl[k] - sl * Fr[k]) + sr * sl * (uR[k] - uL[k])) * id;
+  for (int k = 0; k < 5; k++) F[k] = t8_fma(sr * sl, uR[k] - uL[k], t8_fma(sr, Fl[k], -(sl * Fr[k]))) * id;
 }
 
 // HLLC for the fast tier: hllc_ref with shared reciprocals and the fast division / sqrt
 template <class T>
 T8_DEV void hllc_fast(const T uL[5], const T uR[5], T F[5], T& speed) {
+#pragma clang fp contract(off)
   const T zero = T(0), one = T(1), half = T(0.5);
   const T gm1 = T(1.4) - one;
   const T irl = t8_rcp(uL[0]), irr = t8_rcp(uR[0]);
   const T v1l = uL[1] * irl, v2l = uL[2] * irl, v3l = uL[3] * irl;
   const T v1r = uR[1] * irr, v2r = uR[2] * irr, v3r = uR[3] * irr;
-  const T kl = half * (v1l * v1l + v2l * v2l + v3l * v3l), kr = half * (v1r * v1r + v2r * v2r + v3r * v3r);
-  const T pl = gm1 * (uL[4] - uL[0] * kl), pr = gm1 * (uR[4] - uR[0] * kr);
+  const T kl = half * t8_fma(v1l, v1l, t8_fma(v2l, v2l, v3l * v3l)), kr = half * t8_fma(v1r, v1r, t8_fma(v2r, v2r, v3r * v3r));
+  const T pl = gm1 * t8_fma(-uL[0], kl, uL[4]), pr = gm1 * t8_fma(-uR[0], kr, uR[4]);
   const T Hl = (uL[4] + pl) * irl, Hr = (uR[4] + pr) * irr;
   const T cl = t8_sqrt_fast(gm1 * (Hl - kl)), cr = t8_sqrt_fast(gm1 * (Hr - kr));
   const T wl = t8_sqrt_fast(uL[0]), wr = t8_sqrt_fast(uR[0]);
   const T iw = t8_rcp(wl + wr);
-  const T v1 = (wl * v1l + wr * v1r) * iw, v2 = (wl * v2l + wr * v2r) * iw, v3 = (wl * v3l + wr * v3r) * iw;
-  const T H  = (wl * Hl + wr * Hr) * iw;
-  const T c  = t8_sqrt_fast(gm1 * (H - half * (v1 * v1 + v2 * v2 + v3 * v3)));
+  const T v1 = t8_fma(wl, v1l, wr * v1r) * iw, v2 = t8_fma(wl, v2l, wr * v2r) * iw, v3 = t8_fma(wl, v3l, wr * v3r) * iw;
+  const T H  = t8_fma(wl, Hl, wr * Hr) * iw;
+  const T c  = t8_sqrt_fast(gm1 * t8_fma(-half, t8_fma(v1, v1, t8_fma(v2, v2, v3 * v3)), H));
   const T Sl = t8_min(v1 - c, v1l - cl), Sr = t8_max(v1 + c, v1r + cr);
   speed = t8_max(t8_abs(Sl), t8_abs(Sr));
   const T ml = uL[0] * (Sl - v1l), mr = uR[0] * (Sr - v1r);
-  const T Ss = t8_div((pr - pl) + (uL[1] * (Sl - v1l) - uR[1] * (Sr - v1r)), ml - mr);
+  const T Ss = t8_div((pr - pl) + t8_fma(uL[1], Sl - v1l, -(uR[1] * (Sr - v1r))), ml - mr);
   const bool left = Ss >= zero;
   const T    S  = left ? t8_min(Sl, zero) : t8_max(Sr, zero);
   const T    SK = left ? Sl : Sr, vn = left ? v1l : v1r, vt1 = left ? v2l : v2r, vt2 = left ? v3l : v3r;
@@ -560,26 +626,35 @@ T8_DEV void hllc_fast(const T uL[5], const T uR[5], T F[5], T& speed) {
 #pragma unroll
   for (int k = 0; k < 5; k++) u[k] = left ? uL[k] : uR[k];
   const T fac = t8_div(m, SK - Ss);
-  const T Us[5] = {fac, fac * Ss, fac * vt1, fac * vt2, fac * (u[4] * ir + (Ss - vn) * (Ss + t8_div(p, m)))};
-  const T Fk[5] = {u[1], u[1] * vn + p, u[1] * vt1, u[1] * vt2, u[1] * Hk};
+  const T Us[5] = {fac, fac * Ss, fac * vt1, fac * vt2, fac * t8_fma(Ss - vn, Ss + t8_div(p, m), u[4] * ir)};
+  const T Fk[5] = {u[1], t8_fma(u[1], vn, p), u[1] * vt1, u[1] * vt2, u[1] * Hk};
 #pragma unroll
-  for (int k = 0; k < 5; k++) F[k] = Fk[k] + S * (Us[k] - u[k]);
+  for (int k = 0; k < 5; k++) F[k] = t8_fma(S, Us[k] - u[k], Fk[k]);
 }
 
 // face-frame HLL (hllc = false) or HLLC flux of an xyz state pair, scaled by `area`, rotated back to xyz (fast tier)
 template <class T>
 T8_DEV void hll_face(const T sL[5], const T sR[5], bool mirror, const T n[3], const T t1[3], const T t2[3], T area, T g[5],
                      T& speed, bool hllc = false) {
+#pragma clang fp contract(off)
   T a[5], b[5], Ff[5];
-  to_face_frame<T>(n, t1, t2, sL, a, false);
-  to_face_frame<T>(n, t1, t2, mirror ? sL : sR, b, mirror);
+  a[0] = sL[0]; a[1] = dot3<T>(sL[1], sL[2], sL[3], n); a[2] = dot3<T>(sL[1], sL[2], sL[3], t1); a[3] = dot3<T>(sL[1], sL[2], sL[3], t2); a[4] = sL[4];
+  if (mirror) {   // reflective wall: mirror image of the left state (kernels.inl:169-176)
+    b[0] = a[0]; b[1] = -a[1]; b[2] = a[2]; b[3] = a[3]; b[4] = a[4];
+  } else {
+    b[0] = sR[0]; b[1] = dot3<T>(sR[1], sR[2], sR[3], n); b[2] = dot3<T>(sR[1], sR[2], sR[3], t1); b[3] = dot3<T>(sR[1], sR[2], sR[3], t2); b[4] = sR[4];
+  }
   if (hllc)
     hllc_fast<T>(a, b, Ff, speed);
   else
     hll_fast<T>(a, b, Ff, speed);
 #pragma unroll
   for (int k = 0; k < 5; k++) Ff[k] = area * Ff[k];
-  from_face_frame<T>(n, t1, t2, Ff, g);
+  g[0] = Ff[0];
+  g[1] = t8_fma(Ff[3], t2[0], t8_fma(Ff[2], t1[0], Ff[1] * n[0]));
+  g[2] = t8_fma(Ff[3], t2[1], t8_fma(Ff[2], t1[1], Ff[1] * n[1]));
+  g[3] = t8_fma(Ff[3], t2[2], t8_fma(Ff[2], t1[2], Ff[1] * n[2]));
+  g[4] = Ff[4];
 }
 
 }  // namespace t8gpu_hip

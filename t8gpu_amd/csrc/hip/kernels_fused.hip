@@ -14,32 +14,9 @@
 
 #include <cstdlib>
 
-#include "flux_math.hpp"
-#include "t8gpu_hip.h"
+#include "fused_common.hpp"
 
 namespace t8gpu_hip {
-
-template <class T>
-struct FVars {
-  T* p[5];
-};
-
-template <class T>
-struct vec4;
-template <>
-struct vec4<float> {
-  using type = float4;
-};
-template <>
-struct vec4<double> {
-  using type = double4;
-};
-
-// XCD-aware bijection block -> position in [0, nb): XCD x (= b % 8) owns a contiguous run.
-T8_DEV int xcd_position(int b, int nb) {
-  const int q = nb >> 3, rem = nb & 7, x = b & 7, k = b >> 3;
-  return x * q + (x < rem ? x : rem) + k;
-}
 
 template <class T, int KIND, int STAGE>
 __global__ __launch_bounds__(256) void k_plain_fused(T8gpuPlainPlan P, int tile_begin, FVars<T> prev, FVars<T> src,
@@ -139,15 +116,8 @@ __global__ __launch_bounds__(256) void k_plain_fused(T8gpuPlainPlan P, int tile_
     const T scale = dt / vol[e];
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-      T o;
-      if (STAGE == 1) {
-        o = prev.p[k][e] + scale * acc[k];
-      } else if (STAGE == 2) {
-        o = rk3c<T>::c21 * prev.p[k][e] + rk3c<T>::c22 * src.p[k][e] + rk3c<T>::c23 * scale * acc[k];
-      } else {
-        o = rk3c<T>::c31 * prev.p[k][e] + rk3c<T>::c32 * src.p[k][e] + rk3c<T>::c33 * scale * acc[k];
-      }
-      out.p[k][e] = o;
+      // (stage 1: prev is the stage's source state, plain_fused_stage() checks it)
+      out.p[k][e] = rk_stage_update<T, STAGE>(prev.p[k][e], STAGE == 1 ? prev.p[k][e] : src.p[k][e], scale, acc[k]);
     }
   }
 }
@@ -182,7 +152,12 @@ T8_DEV void ell_accumulate(uint4 w, int pass, const T* __restrict__ ff, T acc[5]
 
 template <class T>
 T8_DEV void store_prim(T* pe, int LE, int i, const T s[5]) {
+#ifdef T8GPU_EXP_NOMATH    // experiment builds only: same loads, LDS traffic, barriers and stores, (almost) no arithmetic
+  Prim<T> q;
+  q.rho = s[0]; q.vx = s[1]; q.vy = s[2]; q.vz = s[3]; q.p = s[4]; q.beta = s[0]; q.lrho = s[1]; q.lbeta = s[2]; q.v0 = s[3];
+#else
   const Prim<T> q = prim_from_state<T>(s);
+#endif
   pe[0 * LE + i] = q.rho;
   pe[1 * LE + i] = q.vx;
   pe[2 * LE + i] = q.vy;
@@ -219,7 +194,12 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
   T* const      pe  = lds;
   T* const      ff  = lds + (size_t)NW * LE;  // [5][256]: one pass of 256 faces at a time
 
+#ifdef T8GPU_EXP_TILEMOD   // experiment builds only (build.py variants): every workgroup works on one of the first few tiles,
+                           // so all traffic stays in the caches -- what remains is the kernel's instruction time
+  const int tile = P.tile_order[tile_begin + xcd_position(blockIdx.x, gridDim.x) % T8GPU_EXP_TILEMOD];
+#else
   const int tile = P.tile_order[tile_begin + xcd_position(blockIdx.x, gridDim.x)];
+#endif
   const int e0 = P.elem_off[tile], ne = P.elem_off[tile + 1] - e0;
   const int h0 = P.halo_off[tile], nh = P.halo_off[tile + 1] - h0;
   const int f0 = P.face_off[tile], nf = P.face_off[tile + 1] - f0;
@@ -251,7 +231,7 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
     f.gm = V4{};
     f.gi = 0;
     if (DICT)  // only the 2-byte row index travels with the face; the (cache-resident) row is read in phase 2
-      f.gi = 3 * P.geo_idx[j];
+      f.gi = 3 * (P.geo_idx[j] & 0x1FFF);   // (upper 3 bits: direction code, used by the persistent kernel)
     else
       f.gm = reinterpret_cast<const V4*>(P.face_geo)[j];
     f.orig = speed ? P.face_orig[j] : -1;
@@ -315,7 +295,13 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
         Prim<T> L, R;
         load_prim<T>(pe, LE, l, L);
         load_prim<T>(pe, LE, r, R);
+#ifdef T8GPU_EXP_NOMATH
+        g[0] = L.rho + R.rho + n[0] + t1[0]; g[1] = L.vx + R.vx + t2[0]; g[2] = L.vy + R.vy + L.beta + R.beta; g[3] = L.vz + R.vz + L.lrho + R.lrho;
+        g[4] = L.p + R.p + L.lbeta + R.lbeta + L.v0 + R.v0 + gm.w;
+        spd = g[0];
+#else
         kepes_prim<T>(L, R, wall, n, t1, t2, gm.w, g, spd);
+#endif
       } else {
         T sl[5], sr[5];
 #pragma unroll
@@ -376,24 +362,9 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
     const T scale = dt / volume;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-      T o;
-      if (STAGE == 1) {
-        o = s0[k] + scale * acc[k];
-      } else if (STAGE == 2) {
-        o = rk3c<T>::c21 * pv[k] + rk3c<T>::c22 * s0[k] + rk3c<T>::c23 * scale * acc[k];
-      } else {
-        o = rk3c<T>::c31 * pv[k] + rk3c<T>::c32 * s0[k] + rk3c<T>::c33 * scale * acc[k];
-      }
-      out.p[k][e] = o;
+      out.p[k][e] = rk_stage_update<T, STAGE>(pv[k], s0[k], scale, acc[k]);
     }
   }
-}
-
-template <class T, class V>
-FVars<T> fmk(const V& v) {
-  FVars<T> o;
-  for (int k = 0; k < 5; k++) o.p[k] = v.p[k];
-  return o;
 }
 
 template <class T, class V>
@@ -417,7 +388,15 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
                          slots <= 512 && plan->max_faces <= 1024;
   const bool  four = plan->max_faces > 512;
   static const bool scatter = std::getenv("T8GPU_LDS_SCATTER") && std::getenv("T8GPU_LDS_SCATTER")[0] == '1';   // measured alternative
-  const size_t lds = sizeof(T) * ((size_t)nw * slots + (size_t)5 * (pipelined ? 256 : plan->max_faces));
+  if (!scatter) {   // default for plans it takes: the persistent, software-pipelined kernel (kernels_fused_persistent.hip)
+    const int rc = plain_persistent_stage<T>(kind, stage, plan, tile_begin, tile_count, fmk<T>(prev), fmk<T>(mid), fmk<T>(out), volume,
+                                             dt, speed, s);
+    if (rc >= 0) return rc;
+  }
+  size_t lds = sizeof(T) * ((size_t)nw * slots + (size_t)5 * (pipelined ? 256 : plan->max_faces));
+#ifdef T8GPU_EXP_LDS_PAD   // experiment builds only: fewer workgroups per CU, to measure how much the kernel leans on occupancy
+  if (const char* pad = std::getenv("T8GPU_EXP_LDS_PAD")) lds += static_cast<size_t>(std::atoi(pad));
+#endif
   if (lds > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
   const bool  dict = pipelined && plan->geo_idx && plan->geo_table && plan->n_geo > 0;
 #define T8_LAUNCH(KERNEL)                                                                                    \

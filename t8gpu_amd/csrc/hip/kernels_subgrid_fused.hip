@@ -352,15 +352,7 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
     const T scale = dt / (vol / T(S));
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-      T r;
-      if (STAGE == 1) {
-        r = s0[k] + scale * acc[k];
-      } else if (STAGE == 2) {
-        r = rk3c<T>::c21 * pv[k] + rk3c<T>::c22 * s0[k] + rk3c<T>::c23 * scale * acc[k];
-      } else {
-        r = rk3c<T>::c31 * pv[k] + rk3c<T>::c32 * s0[k] + rk3c<T>::c33 * scale * acc[k];
-      }
-      out.p[k][o] = r;
+      out.p[k][o] = rk_stage_update<T, STAGE>(pv[k], s0[k], scale, acc[k]);
     }
   }
 }

@@ -32,7 +32,9 @@ inline int nccl_code(ncclResult_t r) { return r == ncclSuccess ? 0 : 10000 + sta
   } while (0)
 
 struct Stepper {
-  T8gpuPlainPlan plan{};
+  T8gpuPlainPlan   plan{};      // plain elements: units = tiles of the plan
+  T8gpuSubgridPlan splan{};     // Subgrid blocks: units = blocks in block_order position order
+  bool             subgrid = false;
   bool           has_halo = false;
   T8gpuHalo      halo{};
   std::vector<int32_t> peers, send_off, recv_off;
@@ -46,6 +48,14 @@ struct Stepper {
   std::vector<hipEvent_t> pool;   // start/stop pairs of the stage-kernel launches
   size_t         used = 0;
   int            stages_timed = 0;
+  // hipGraph replay of a whole iterate_steps() call (t8gpu_hip_plain_stepper_graph): the enqueue sequence is
+  // captured once per distinct argument set on an internal origin stream and replayed with one hipGraphLaunch
+  int             graph_mode = 0;       // 0 off, 1 on
+  hipStream_t     graph_stream = nullptr;
+  hipEvent_t      ev_graph_in = nullptr, ev_graph_out = nullptr;
+  hipGraphExec_t  graph_exec = nullptr;
+  unsigned char   graph_key[96] = {0};
+  int             graph_captures = 0, graph_replays = 0;
 };
 
 template <class T>
@@ -116,11 +126,16 @@ int tick(Stepper* S, hipStream_t s) {
 // satisfied long before it is reached. Stages two apart are ordered transitively (C_g > B_(g-1) > all of
 // g-2, and so on), which is what the reuse of the four step buffers needs. The streams meet only at the
 // entry and at the exit of the call.
+// Subgrid blocks run through the same pipeline (SubgridCompressibleEulerSolver::iterate, examples/subgrid/solver.inl:
+// 152-266): units are blocks in the plan's position order (deep interior, near-boundary, ghost-touching), a ghost
+// block mirrors all 4^rank subcells, `vol` is the separate per-block volume array of SubgridMemoryManager.
 template <class T, class V>
-int iterate(Stepper* S, int kind, T* planes, size_t stride, int prev, int next, T dt, T* speed, int n_steps, hipStream_t s) {
-  const T*   vol = planes + 25 * stride;
-  const int  nt = S->plan.ntiles, ni = S->plan.n_interior_tiles;
-  const int  nd = (S->plan.n_deep_tiles > 0 && S->plan.n_deep_tiles <= ni) ? S->plan.n_deep_tiles : 0;
+int iterate(Stepper* S, int kind, T* planes, size_t stride, const T* vol, int prev, int next, T dt, T* speed, int n_steps,
+            hipStream_t s) {
+  const int  nt = S->subgrid ? S->splan.num_elements : S->plan.ntiles;
+  const int  ni = S->subgrid ? S->splan.n_interior_blocks : S->plan.n_interior_tiles;
+  const int  ndeep = S->subgrid ? S->splan.n_deep_blocks : S->plan.n_deep_tiles;
+  const int  nd = (ndeep > 0 && ndeep <= ni) ? ndeep : 0;
   const bool comm = S->has_halo && S->halo.n_peers > 0;
   t8gpu_hip::Range whole(comm ? "t8gpu.iterate_steps (exchange + 3 tile classes)" : "t8gpu.iterate_steps");
   static const char* const stage_name[3] = {"t8gpu.rk_stage1", "t8gpu.rk_stage2", "t8gpu.rk_stage3"};
@@ -132,13 +147,23 @@ int iterate(Stepper* S, int kind, T* planes, size_t stride, int prev, int next, 
     const int pr = (g / 3) % 2 == 0 ? prev : next, nx = (g / 3) % 2 == 0 ? next : prev;
     const int src = k == 0 ? pr : k, dst = k == 2 ? nx : k + 1;   // Step1 = 1, Step2 = 2 (solver.h:24-31)
     const V   pv = step_vars<V>(planes, stride, pr), sv = step_vars<V>(planes, stride, src), ov = step_vars<V>(planes, stride, dst);
+    // The per-face speed estimates are rewritten by every stage and read only between steps (compute_timestep uses
+    // those "computed at the last step of the last timestepping", solver.h:88-91): only the third stage writes them
+    // (same contents after every step, a tenth less HBM traffic per step).
+    T* const stage_speed = k == 2 ? speed : nullptr;
     auto launch = [&](int b, int n, hipStream_t on) -> int {
       if (n <= 0) return 0;
       T8_TRY(tick(S, on));
       if constexpr (sizeof(T) == 4) {
-        T8_TRY(t8gpu_hip_plain_fused_stage_f32(kind, k + 1, &S->plan, b, n, pv, sv, ov, vol, dt, speed, on));
+        if (S->subgrid)
+          T8_TRY(t8gpu_hip_subgrid_fused_stage_f32(kind, k + 1, &S->splan, b, n, pv, sv, ov, vol, dt, on));
+        else
+          T8_TRY(t8gpu_hip_plain_fused_stage_f32(kind, k + 1, &S->plan, b, n, pv, sv, ov, vol, dt, stage_speed, on));
       } else {
-        T8_TRY(t8gpu_hip_plain_fused_stage_f64(kind, k + 1, &S->plan, b, n, pv, sv, ov, vol, dt, speed, on));
+        if (S->subgrid)
+          T8_TRY(t8gpu_hip_subgrid_fused_stage_f64(kind, k + 1, &S->splan, b, n, pv, sv, ov, vol, dt, on));
+        else
+          T8_TRY(t8gpu_hip_plain_fused_stage_f64(kind, k + 1, &S->plan, b, n, pv, sv, ov, vol, dt, stage_speed, on));
       }
       return tick(S, on);
     };
@@ -170,6 +195,59 @@ int iterate(Stepper* S, int kind, T* planes, size_t stride, int prev, int next, 
     T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_ghost, 0));
     T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_interior, 0));
   }
+  return 0;
+}
+
+// iterate() through a hipGraph: capture the enqueue sequence once per argument set, then replay it. The capture runs
+// on the stepper's own origin stream (the caller's stream may be the legacy default stream, which cannot capture);
+// the comm and near streams join the capture through the events they wait on, and rejoin before it ends. Timing
+// events are off in graph mode. With a halo the RCCL group is captured too (RCCL enqueues its kernels on the capturing
+// stream); if the runtime refuses any part of the capture the error is returned and the caller falls back.
+template <class T, class V>
+int iterate_graph(Stepper* S, int kind, T* planes, size_t stride, const T* vol, int prev, int next, T dt, T* speed, int n_steps,
+                  hipStream_t s) {
+  if (!S->graph_mode || S->timing > 0 || n_steps <= 0) return iterate<T, V>(S, kind, planes, stride, vol, prev, next, dt, speed, n_steps, s);
+  struct Key {
+    int kind, prev, next, n_steps, tsize, subgrid;
+    const void *planes, *vol, *speed;
+    size_t stride;
+    double dt;
+  } key{kind, prev, next, n_steps, static_cast<int>(sizeof(T)), S->subgrid ? 1 : 0, planes, vol, speed, stride, static_cast<double>(dt)};
+  static_assert(sizeof(Key) <= sizeof(S->graph_key), "graph key");
+  if (!S->graph_stream) {
+    T8_HIP_TRY(hipStreamCreateWithFlags(&S->graph_stream, hipStreamNonBlocking));
+    T8_HIP_TRY(hipEventCreateWithFlags(&S->ev_graph_in, hipEventDisableTiming));
+    T8_HIP_TRY(hipEventCreateWithFlags(&S->ev_graph_out, hipEventDisableTiming));
+  }
+  if (!S->graph_exec || std::memcmp(&key, S->graph_key, sizeof(Key)) != 0) {
+    if (S->graph_exec) {
+      (void)hipGraphExecDestroy(S->graph_exec);
+      S->graph_exec = nullptr;
+    }
+    hipGraph_t g = nullptr;
+    T8_HIP_TRY(hipStreamBeginCapture(S->graph_stream, hipStreamCaptureModeRelaxed));
+    const int  rc = iterate<T, V>(S, kind, planes, stride, vol, prev, next, dt, speed, n_steps, S->graph_stream);
+    hipError_t e  = hipStreamEndCapture(S->graph_stream, &g);
+    if (rc != 0 || e != hipSuccess || !g) {
+      if (g) (void)hipGraphDestroy(g);
+      return rc != 0 ? rc : static_cast<int>(e != hipSuccess ? e : hipErrorStreamCaptureInvalidated);
+    }
+    e = hipGraphInstantiate(&S->graph_exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) {
+      S->graph_exec = nullptr;
+      return static_cast<int>(e);
+    }
+    std::memset(S->graph_key, 0, sizeof(S->graph_key));
+    std::memcpy(S->graph_key, &key, sizeof(Key));
+    S->graph_captures++;
+  }
+  T8_HIP_TRY(hipEventRecord(S->ev_graph_in, s));                         // the graph starts behind the caller's work ...
+  T8_HIP_TRY(hipStreamWaitEvent(S->graph_stream, S->ev_graph_in, 0));
+  T8_HIP_TRY(hipGraphLaunch(S->graph_exec, S->graph_stream));
+  T8_HIP_TRY(hipEventRecord(S->ev_graph_out, S->graph_stream));
+  T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_graph_out, 0));                 // ... and the caller's stream continues behind it
+  S->graph_replays++;
   return 0;
 }
 
@@ -233,10 +311,7 @@ int t8gpu_hip_stream_wait(void* stream, double timeout_s) {
   }
 }
 
-int t8gpu_hip_plain_stepper_create(const T8gpuPlainPlan* plan, const T8gpuHalo* halo, void** out) {
-  if (!plan || !out) return static_cast<int>(hipErrorInvalidValue);
-  Stepper* S = new Stepper;
-  S->plan = *plan;
+static int stepper_halo_setup(Stepper* S, const T8gpuHalo* halo) {
   if (halo && halo->n_peers > 0) {
     S->has_halo = true;
     S->halo     = *halo;
@@ -252,10 +327,36 @@ int t8gpu_hip_plain_stepper_create(const T8gpuPlainPlan* plan, const T8gpuHalo* 
     if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_interior, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_deep, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&S->near_stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-      delete S;
-      return static_cast<int>(e);
-    }
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  return 0;
+}
+
+int t8gpu_hip_plain_stepper_create(const T8gpuPlainPlan* plan, const T8gpuHalo* halo, void** out) {
+  if (!plan || !out) return static_cast<int>(hipErrorInvalidValue);
+  Stepper* S = new Stepper;
+  S->plan = *plan;
+  const int rc = stepper_halo_setup(S, halo);
+  if (rc != 0) {
+    t8gpu_hip_plain_stepper_destroy(S);
+    return rc;
+  }
+  *out = S;
+  return 0;
+}
+
+// Subgrid blocks: the same driver over a T8gpuSubgridPlan (halo->cells_per_element = 4^rank). The handle is used
+// with t8gpu_hip_subgrid_stepper_iterate_steps_* and the generic destroy / timing / elapsed entry points above.
+int t8gpu_hip_subgrid_stepper_create(const T8gpuSubgridPlan* plan, const T8gpuHalo* halo, void** out) {
+  if (!plan || !out) return static_cast<int>(hipErrorInvalidValue);
+  if (halo && halo->n_peers > 0 && halo->cells_per_element != (plan->rank == 3 ? 64 : 16)) return static_cast<int>(hipErrorInvalidValue);
+  Stepper* S = new Stepper;
+  S->subgrid = true;
+  S->splan   = *plan;
+  const int rc = stepper_halo_setup(S, halo);
+  if (rc != 0) {
+    t8gpu_hip_plain_stepper_destroy(S);
+    return rc;
   }
   *out = S;
   return 0;
@@ -271,6 +372,10 @@ int t8gpu_hip_plain_stepper_destroy(void* h) {
   if (S->ev_deep) (void)hipEventDestroy(S->ev_deep);
   if (S->comm_stream) (void)hipStreamDestroy(S->comm_stream);
   if (S->near_stream) (void)hipStreamDestroy(S->near_stream);
+  if (S->graph_exec) (void)hipGraphExecDestroy(S->graph_exec);
+  if (S->ev_graph_in) (void)hipEventDestroy(S->ev_graph_in);
+  if (S->ev_graph_out) (void)hipEventDestroy(S->ev_graph_out);
+  if (S->graph_stream) (void)hipStreamDestroy(S->graph_stream);
   delete S;
   return 0;
 }
@@ -286,14 +391,44 @@ int t8gpu_hip_plain_stepper_iterate_f64(void* h, int flux_kind, double* planes, 
 int t8gpu_hip_plain_stepper_iterate_steps_f32(void* h, int flux_kind, float* planes, size_t stride, int prev, int next,
                                               float delta_t, float* speed, int n_steps, void* stream) {
   if (!h || prev < 0 || prev > 3 || next < 0 || next > 3 || prev == next || n_steps < 0) return static_cast<int>(hipErrorInvalidValue);
-  return iterate<float, T8gpuVars_f32>(static_cast<Stepper*>(h), flux_kind, planes, stride, prev, next, delta_t, speed, n_steps,
-                                       static_cast<hipStream_t>(stream));
+  if (static_cast<Stepper*>(h)->subgrid) return static_cast<int>(hipErrorInvalidValue);
+  return iterate_graph<float, T8gpuVars_f32>(static_cast<Stepper*>(h), flux_kind, planes, stride, planes + 25 * stride, prev, next,
+                                             delta_t, speed, n_steps, static_cast<hipStream_t>(stream));
 }
 int t8gpu_hip_plain_stepper_iterate_steps_f64(void* h, int flux_kind, double* planes, size_t stride, int prev, int next,
                                               double delta_t, double* speed, int n_steps, void* stream) {
   if (!h || prev < 0 || prev > 3 || next < 0 || next > 3 || prev == next || n_steps < 0) return static_cast<int>(hipErrorInvalidValue);
-  return iterate<double, T8gpuVars_f64>(static_cast<Stepper*>(h), flux_kind, planes, stride, prev, next, delta_t, speed, n_steps,
-                                        static_cast<hipStream_t>(stream));
+  if (static_cast<Stepper*>(h)->subgrid) return static_cast<int>(hipErrorInvalidValue);
+  return iterate_graph<double, T8gpuVars_f64>(static_cast<Stepper*>(h), flux_kind, planes, stride, planes + 25 * stride, prev, next,
+                                              delta_t, speed, n_steps, static_cast<hipStream_t>(stream));
+}
+
+int t8gpu_hip_subgrid_stepper_iterate_steps_f32(void* h, int flux_kind, float* planes, size_t stride, const float* volumes, int prev,
+                                                int next, float delta_t, int n_steps, void* stream) {
+  if (!h || !static_cast<Stepper*>(h)->subgrid || prev < 0 || prev > 3 || next < 0 || next > 3 || prev == next || n_steps < 0)
+    return static_cast<int>(hipErrorInvalidValue);
+  return iterate_graph<float, T8gpuVars_f32>(static_cast<Stepper*>(h), flux_kind, planes, stride, volumes, prev, next, delta_t, nullptr,
+                                             n_steps, static_cast<hipStream_t>(stream));
+}
+int t8gpu_hip_subgrid_stepper_iterate_steps_f64(void* h, int flux_kind, double* planes, size_t stride, const double* volumes, int prev,
+                                                int next, double delta_t, int n_steps, void* stream) {
+  if (!h || !static_cast<Stepper*>(h)->subgrid || prev < 0 || prev > 3 || next < 0 || next > 3 || prev == next || n_steps < 0)
+    return static_cast<int>(hipErrorInvalidValue);
+  return iterate_graph<double, T8gpuVars_f64>(static_cast<Stepper*>(h), flux_kind, planes, stride, volumes, prev, next, delta_t, nullptr,
+                                              n_steps, static_cast<hipStream_t>(stream));
+}
+
+// hipGraph replay of iterate_steps() (both step drivers): enable = 1 captures the whole call once per argument set and
+// replays it with one hipGraphLaunch; 0 enqueues directly. counts (may be NULL) = {captures, replays} so far.
+int t8gpu_hip_plain_stepper_graph(void* h, int enable, int* counts) {
+  Stepper* S = static_cast<Stepper*>(h);
+  if (!S) return static_cast<int>(hipErrorInvalidValue);
+  if (enable >= 0) S->graph_mode = enable ? 1 : 0;
+  if (counts) {
+    counts[0] = S->graph_captures;
+    counts[1] = S->graph_replays;
+  }
+  return 0;
 }
 
 int t8gpu_hip_plain_stepper_timing(void* h, int enable) {

@@ -24,7 +24,7 @@ namespace {
 struct SubgridPlan {
   int32_t N = 0, F = 0, B = 0, rank = 3, max_bf = 0;
   std::vector<int32_t> bf_off, bf_ent, face_rec, plus, block_order;  // block_order: interior blocks first
-  int32_t n_interior = 0;
+  int32_t n_interior = 0, n_deep = 0;
 };
 }  // namespace
 
@@ -114,8 +114,21 @@ void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, c
     if (l >= N && r < N) ghosty[r] = 1;
     if (r >= N && l < N) ghosty[l] = 1;
   }
+  // three classes for the multi-rank step driver (as for plain tiles, tile_plan.cpp): deep interior blocks (no
+  // neighbour that touches a ghost block), near-boundary interior blocks, ghost-touching blocks
+  std::vector<uint8_t> near(static_cast<size_t>(N), 0);
+  for (int32_t f = 0; f < F; f++) {
+    const int32_t l = fn[2 * static_cast<size_t>(f)], r = fn[2 * static_cast<size_t>(f) + 1];
+    if (l < N && r < N) {
+      if (ghosty[l] && !ghosty[r]) near[r] = 1;
+      if (ghosty[r] && !ghosty[l]) near[l] = 1;
+    }
+  }
   for (int32_t e = 0; e < N; e++)
-    if (!ghosty[e]) P->block_order.push_back(e);
+    if (!ghosty[e] && !near[e]) P->block_order.push_back(e);
+  P->n_deep = static_cast<int32_t>(P->block_order.size());
+  for (int32_t e = 0; e < N; e++)
+    if (!ghosty[e] && near[e]) P->block_order.push_back(e);
   P->n_interior = static_cast<int32_t>(P->block_order.size());
   for (int32_t e = 0; e < N; e++)
     if (ghosty[e]) P->block_order.push_back(e);
@@ -124,13 +137,14 @@ void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, c
 
 void t8gpu_plan_subgrid_destroy(void* h) { delete static_cast<SubgridPlan*>(h); }
 
-/* sizes[4] = {n_entries, max faces per block, F + B, n_interior_blocks} */
+/* sizes[5] = {n_entries, max faces per block, F + B, n_interior_blocks, n_deep_blocks} */
 void t8gpu_plan_subgrid_sizes(const void* h, int64_t* sizes) {
   const SubgridPlan* P = static_cast<const SubgridPlan*>(h);
   sizes[0] = static_cast<int64_t>(P->bf_ent.size());
   sizes[1] = P->max_bf;
   sizes[2] = static_cast<int64_t>(P->F) + P->B;
   sizes[3] = P->n_interior;
+  sizes[4] = P->n_deep;
 }
 
 void t8gpu_plan_subgrid_order(const void* h, int32_t* block_order) {

@@ -39,9 +39,23 @@ struct TilePlan {
   int32_t lecap = 512;                                 // max own + halo elements per tile
   int32_t ell_width = 0;                               // padded per-element face-list width (multiple of 8)
   std::vector<uint16_t> ell;                           // [N][ell_width], 0xFFFF = padding
-  std::vector<uint16_t> geo_idx;                       // per tile face: index into geo_table (empty if > 65535 distinct)
+  std::vector<uint16_t> geo_idx;                       // per tile face: row of geo_table (13 bits) | direction code << 13
+                                                       // (empty if more than 8191 distinct rows)
   std::vector<double>   geo_table;                     // [n_geo][12]: n, area, t1, 0, t2, 0
 };
+
+// Direction code of a unit normal: 2 * axis + (1 if it points along +axis) for an EXACT axis normal (one component
+// +-1, the others +-0), 6 otherwise. Faces of Cartesian meshes all have codes < 6; the kernels evaluate such a face
+// without the rotation into the face frame when a whole wavefront shares the code.
+inline int direction_code(const double* n, int ndim) {
+  int axis = -1;
+  for (int k = 0; k < ndim; k++) {
+    if (n[k] == 0.0) continue;
+    if ((n[k] != 1.0 && n[k] != -1.0) || axis >= 0) return 6;
+    axis = k;
+  }
+  return axis < 0 ? 6 : 2 * axis + (n[axis] > 0.0 ? 1 : 0);
+}
 
 void build(TilePlan& P, const int32_t* fn, const double* normals, const double* areas) {
   const int32_t N = P.N, F = P.F, B = P.B;
@@ -194,7 +208,7 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
   P.csr_ent.resize(deg[N]);
 #pragma omp parallel
   {
-    std::vector<int32_t> tf, halo;
+    std::vector<int32_t> tf, halo, order, where;
 #pragma omp for schedule(static)
     for (int32_t t = 0; t < ntiles; t++) {
       const int32_t e0 = P.elem_off[t], e1 = P.elem_off[t + 1], ne = e1 - e0;
@@ -203,8 +217,23 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
         if (s >= e0 && s < e1) return static_cast<uint32_t>(s - e0);
         return static_cast<uint32_t>(ne + (std::lower_bound(halo.begin(), halo.end(), s) - halo.begin()));
       };
+      // Layout of the tile's faces: ascending original id, then inside every block of 256 (one pass of the two-pass
+      // kernels = the faces one lane index sees) a stable sort by direction code, so that a wavefront's 64 faces
+      // mostly share one direction. The per-element lists below keep ascending original order (only the positions
+      // they point at move, and never across a block), so every kernel sums in the same order as before.
+      const size_t nft = tf.size();
+      order.resize(nft);
+      where.resize(nft);
+      for (size_t j = 0; j < nft; j++) order[j] = static_cast<int32_t>(j);
+      for (size_t b = 0; b < nft; b += 256)
+        std::stable_sort(order.begin() + b, order.begin() + std::min(nft, b + 256), [&](int32_t x, int32_t y) {
+          return direction_code(normals + static_cast<size_t>(P.ndim) * tf[x], P.ndim) <
+                 direction_code(normals + static_cast<size_t>(P.ndim) * tf[y], P.ndim);
+        });
+      for (size_t j = 0; j < nft; j++) where[order[j]] = static_cast<int32_t>(j);
       size_t q = P.face_off[t];
-      for (int32_t f : tf) {
+      for (size_t jj = 0; jj < nft; jj++) {
+        const int32_t f = tf[order[jj]];
         const int32_t l = side(f, 0), r = side(f, 1);
         const uint32_t ll = loc(l), rr = r < 0 ? 0xFFFFu : loc(r);
         P.face_lr[q] = ll | (rr << 16);
@@ -219,7 +248,7 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
       for (int32_t e = e0; e < e1; e++)
         for (int32_t j = deg[e]; j < deg[e + 1]; j++) {
           const int32_t  f   = ef[j];
-          const uint16_t idx = static_cast<uint16_t>(std::lower_bound(tf.begin(), tf.end(), f) - tf.begin());
+          const uint16_t idx = static_cast<uint16_t>(where[std::lower_bound(tf.begin(), tf.end(), f) - tf.begin()]);
           const bool     right = side(f, 0) != e;
           P.csr_ent[j] = static_cast<uint16_t>(idx | (right ? 0x8000u : 0u));
         }
@@ -286,13 +315,13 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
       Key k;
       std::memcpy(k.w, &P.face_geo[4 * f], 32);
       set.insert(k);
-      too_many = set.size() > 65535;
+      too_many = set.size() > 8191;   // 13 bits of row index: the upper 3 bits of geo_idx carry the direction code
     }
     std::vector<Key> uniq;
     if (!too_many) uniq.assign(set.begin(), set.end());
     std::sort(uniq.begin(), uniq.end());
-    if (too_many) uniq.resize(65536);   // (only its size is looked at below)
-    if (uniq.size() <= 65535) {
+    if (too_many) uniq.resize(8192);   // (only its size is looked at below)
+    if (uniq.size() <= 8191) {
       // table row = {nx, ny, nz, area, t1x, t1y, t1z, 0, t2x, t2y, t2z, 0}: the face frame (the reference
       // rebuilds it per face and stage, kernels.cu:174-193) is computed once per distinct normal
       P.geo_table.assign(uniq.size() * 12, 0.0);
@@ -314,7 +343,9 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
       for (int64_t f = 0; f < static_cast<int64_t>(nfaces); f++) {
         Key k;
         std::memcpy(k.w, &P.face_geo[4 * static_cast<size_t>(f)], 32);
-        P.geo_idx[f] = static_cast<uint16_t>(std::lower_bound(uniq.begin(), uniq.end(), k) - uniq.begin());
+        const unsigned row  = static_cast<unsigned>(std::lower_bound(uniq.begin(), uniq.end(), k) - uniq.begin());
+        const unsigned code = static_cast<unsigned>(direction_code(&P.face_geo[4 * static_cast<size_t>(f)], 3));
+        P.geo_idx[f]        = static_cast<uint16_t>(row | (code << 13));
       }
     }
   }
@@ -367,6 +398,18 @@ void t8gpu_plan_plain_compressed(const void* h, uint16_t* ell, uint16_t* geo_idx
   if (ell && !P->ell.empty()) std::memcpy(ell, P->ell.data(), P->ell.size() * sizeof(uint16_t));
   if (geo_idx && !P->geo_idx.empty()) std::memcpy(geo_idx, P->geo_idx.data(), P->geo_idx.size() * sizeof(uint16_t));
   if (geo_table && !P->geo_table.empty()) std::memcpy(geo_table, P->geo_table.data(), P->geo_table.size() * sizeof(double));
+}
+
+void t8gpu_plan_plain_tile_desc(const void* h, int32_t* tile_desc) {
+  const TilePlan* P = static_cast<const TilePlan*>(h);
+  for (size_t k = 0; k < P->tile_order.size(); k++) {
+    const int32_t t = P->tile_order[k];
+    int32_t*      d = tile_desc + 8 * k;
+    d[0] = P->elem_off[t]; d[1] = P->elem_off[t + 1] - P->elem_off[t];
+    d[2] = P->halo_off[t]; d[3] = P->halo_off[t + 1] - P->halo_off[t];
+    d[4] = P->face_off[t]; d[5] = P->face_off[t + 1] - P->face_off[t];
+    d[6] = d[7] = 0;
+  }
 }
 
 void t8gpu_plan_plain_arrays(const void* h, int32_t* elem_off, int32_t* halo_off, int32_t* face_off,

@@ -13,7 +13,7 @@ class T8gpuPlainPlan(C.Structure):
         ("ntiles", C.c_int32), ("n_interior_tiles", C.c_int32), ("max_elems", C.c_int32), ("max_halo", C.c_int32),
         ("max_faces", C.c_int32), ("ell_width", C.c_int32), ("ell", C.c_void_p), ("geo_idx", C.c_void_p),
         ("geo_table", C.c_void_p), ("n_geo", C.c_int32), ("max_slots", C.c_int32), ("n_deep_tiles", C.c_int32),
-        ("reserved", C.c_int32)]
+        ("reserved", C.c_int32), ("tile_desc", C.c_void_p)]
 
 
 class PlainPlan:
@@ -56,7 +56,7 @@ class PlainPlan:
             setattr(c, name, t.data_ptr())
         npf = np.float32 if dtype == torch.float32 else np.float64
         if compressed:
-            extra = {"ell": self.host.ell.view(np.int16)}
+            extra = {"ell": self.host.ell.view(np.int16), "tile_desc": self.host.tile_desc}
             c.ell_width = self.host.ell_width
             if dictionary and self.host.geo_table.shape[0] > 0:
                 extra["geo_idx"] = self.host.geo_idx.view(np.int16)
@@ -75,16 +75,17 @@ class PlainPlan:
         from .solver import _timer_begin, _timer_end
         n = self.host.ntiles - tile_begin if tile_count is None else tile_count
         ev = _timer_begin(solver)
+        # speed estimates: rewritten by every stage in the reference, read only between steps -> written by stage 3 only
         hip.call("t8gpu_hip_plain_fused_stage", self.dtype, solver.kind, stage, C.byref(self.c), tile_begin, n,
                  solver.get_own_variables(solver.prev), solver.get_own_variables(src), solver.get_own_variables(dst),
-                 hip.ptr(solver.planes[25]), hip.fscalar(self.dtype, dt), hip.ptr(solver.speed), stream)
+                 hip.ptr(solver.planes[25]), hip.fscalar(self.dtype, dt), hip.ptr(solver.speed) if stage == 3 else None, stream)
         _timer_end(solver, ev)
 
 
 class T8gpuSubgridPlan(C.Structure):
     _fields_ = [("block_rec", C.c_void_p), ("bf_rec", C.c_void_p),
                 ("num_elements", C.c_int32), ("rank", C.c_int32), ("max_faces_per_block", C.c_int32),
-                ("n_interior_blocks", C.c_int32)]
+                ("n_interior_blocks", C.c_int32), ("n_deep_blocks", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SubgridPlan:
@@ -101,6 +102,7 @@ class SubgridPlan:
             setattr(c, k, t.data_ptr())
         c.num_elements, c.rank, c.max_faces_per_block = part.N, part.mesh.dim, self.host.max_bf
         c.n_interior_blocks = self.host.n_interior
+        c.n_deep_blocks = self.host.n_deep
         self.c = c
 
     def stage(self, solver, stage, src, dst, dt, stream, block_begin=0, block_count=None):

@@ -120,6 +120,13 @@ class NativeStepper:
                  C.c_size_t(solver.stride), prev, next, hip.fscalar(solver.dtype, delta_t), hip.ptr(solver.speed),
                  C.c_int(n_steps), hip.stream_ptr(stream))
 
+    # -- shared by both step drivers (one handle type in the library) --------------------------------------
+    def graph(self, enable=None):
+        """hipGraph replay of iterate_steps(); returns (captures, replays) so far."""
+        counts = (C.c_int * 2)()
+        hip.check(hip.lib().t8gpu_hip_plain_stepper_graph(self.handle, -1 if enable is None else int(bool(enable)), counts))
+        return counts[0], counts[1]
+
     def timing(self, enable):
         hip.check(hip.lib().t8gpu_hip_plain_stepper_timing(self.handle, int(enable)))
 
@@ -130,6 +137,25 @@ class NativeStepper:
         ms, n = C.c_double(), C.c_int()
         hip.check(hip.lib().t8gpu_hip_plain_stepper_elapsed(self.handle, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class NativeSubgridStepper(NativeStepper):
+    """t8gpu_hip_subgrid_stepper_*: SubgridCompressibleEulerSolver::iterate enqueued by one C call (block classes on
+    three streams, one RCCL exchange of whole ghost blocks per stage)."""
+
+    def __init__(self, plan, halo=None):
+        self.plan, self.halo = plan, halo
+        self.handle = C.c_void_p()
+        hip.check(hip.lib().t8gpu_hip_subgrid_stepper_create(C.byref(plan.c), C.byref(halo.c) if halo is not None else None,
+                                                             C.byref(self.handle)))
+
+    def iterate(self, solver, delta_t, stream=None):
+        self.iterate_steps(solver, delta_t, 1, solver.prev, solver.next, stream)
+
+    def iterate_steps(self, solver, delta_t, n_steps, prev, next, stream=None):
+        hip.call("t8gpu_hip_subgrid_stepper_iterate_steps", solver.dtype, self.handle, solver.kind, hip.ptr(solver.planes),
+                 C.c_size_t(solver.stride), hip.ptr(solver.volumes), prev, next, hip.fscalar(solver.dtype, delta_t),
+                 C.c_int(n_steps), hip.stream_ptr(stream))
 
 
 def stream_wait(stream, timeout_s):

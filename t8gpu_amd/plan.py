@@ -18,6 +18,7 @@ def _lib():
         lib.t8gpu_plan_plain_sizes.argtypes = [C.c_void_p, C.c_void_p]
         lib.t8gpu_plan_plain_arrays.argtypes = [C.c_void_p] * 11
         lib.t8gpu_plan_plain_compressed.argtypes = [C.c_void_p] * 4
+        lib.t8gpu_plan_plain_tile_desc.argtypes = [C.c_void_p] * 2
         _ready = True
     return lib
 
@@ -61,6 +62,9 @@ class HostPlainPlan:
             self.geo_table = np.zeros((n_geo, 12), np.float64)
             lib.t8gpu_plan_plain_compressed(h, p(self.ell), p(self.geo_idx) if n_geo else None,
                                             p(self.geo_table) if n_geo else None)
+            self.tile_desc = np.zeros((max(1, self.ntiles), 8), np.int32)
+            if self.ntiles:
+                lib.t8gpu_plan_plain_tile_desc(h, p(self.tile_desc))
         finally:
             lib.t8gpu_plan_plain_destroy(h)
 
@@ -88,9 +92,9 @@ class HostSubgridPlan:
         if not h:
             raise ValueError("subgrid plan needs axis-aligned unit normals (as the reference's subgrid kernels do)")
         self._h = h
-        sz = np.zeros(4, np.int64)
+        sz = np.zeros(8, np.int64)
         lib.t8gpu_plan_subgrid_sizes(h, p(sz))
-        self.N, self.rank, self.max_bf, self.n_interior = part.N, rank, int(sz[1]), int(sz[3])
+        self.N, self.rank, self.max_bf, self.n_interior, self.n_deep = part.N, rank, int(sz[1]), int(sz[3]), int(sz[4])
         self.n_entries = int(sz[0])
         lib.t8gpu_plan_subgrid_order.argtypes = [C.c_void_p, C.c_void_p]
         self.block_order = np.zeros(part.N, np.int32)

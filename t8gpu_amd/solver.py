@@ -293,8 +293,32 @@ class SubgridSolver:
                 halo.finish()
             self.plan.stage(self, k + 1, src, dst, delta_t, s, ni, nt - ni)
 
+    def use_native_stepper(self, native_halo=None):
+        """Drive iterate() through the C++ stepper (one C call per run of steps, RCCL called natively)."""
+        from . import native
+        assert self.mode == "fused"
+        self.stepper = native.NativeSubgridStepper(self.plan, native_halo)
+        return self.stepper
+
+    def iterate_steps(self, n_steps, delta_t, stream=None, halo=None):
+        """n_steps steps with a fixed delta_t; ONE call with the native stepper (csrc/hip/stepper.hip)."""
+        if n_steps <= 0:
+            return
+        if getattr(self, "stepper", None) is None:
+            for _ in range(n_steps):
+                self.iterate(delta_t, stream, halo)
+            return
+        self.begin_step()
+        first_prev, first_next = self.prev, self.next
+        for _ in range(n_steps - 1):
+            self.begin_step()
+        self.stepper.iterate_steps(self, delta_t, n_steps, first_prev, first_next, stream)
+
     def iterate(self, delta_t, stream=None, halo=None):
         """SubgridCompressibleEulerSolver::iterate; `halo` refreshes the ghost blocks of each stage's source."""
         self.begin_step()
+        if getattr(self, "stepper", None) is not None:
+            self.stepper.iterate(self, delta_t, stream)
+            return
         for k in range(3):
             self.run_stage(k, delta_t, stream, halo)

@@ -263,3 +263,122 @@ class UnstructuredPartition:
     def kh_initial_state(self):
         """(5, N + G) slice of the mesh's initial state (ghosts included)."""
         return self.mesh.initial_state()[:, self._global_ids]
+
+
+class TetHexMesh:
+    """Mixed tetrahedron / hexahedron mesh (BASELINE config 5's mesh class), in the reference's array formats and with
+    the attributes UnstructuredPartition reads. An nx x ny x nz grid of cells on the unit cube, walls all round; a cell
+    is either one hexahedron (6 faces) or its Kuhn triangulation into 6 tetrahedra (4 faces each, all sharing the
+    cell's main diagonal, every cell side cut along the diagonal from its lowest to its highest corner -- the same for
+    both cells that share the side, so tetrahedra conform). Where a hexahedron meets a tetrahedron cell its
+    quadrilateral side is listed as the two triangles of the neighbour (the finite-volume scheme only sees faces: such
+    a hexahedron simply has 7-12 of them, like an element next to a finer one in an AMR forest).
+
+    tets: "blocks" (2x2x2 blocks of cells alternate between the two kinds: many interfaces), "half" (x < 1/2),
+    "all", "none", or a boolean array [nx, ny, nz]. Faces are matched through their vertex sets, area vectors come
+    from the vertex loops of the mapped geometry (every element closed to rounding), volumes and the listing order as
+    in PrismHexMesh. Elements are numbered along the Morton curve of their cells."""
+
+    # Kuhn tetrahedra: one per permutation of the axes, vertices p0 = (0,0,0), p0 + e_a, p0 + e_a + e_b, (1,1,1)
+    _PERMS = [(0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0)]
+
+    def __init__(self, n, tets="blocks", mapping=shell_map):
+        nx, ny, nz = (n, n, n) if np.isscalar(n) else n
+        self.n, self.periodic, self.dim = (nx, ny, nz), False, 3
+        bits = int(np.ceil(np.log2(max(nx, ny, nz))))
+        self.finest_level = bits
+        I, J, K = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+        if isinstance(tets, str):
+            T = {"blocks": ((I // 2 + J // 2 + K // 2) % 2 == 0), "half": (I < nx // 2), "all": np.ones_like(I, bool),
+                 "none": np.zeros_like(I, bool)}[tets]
+        else:
+            T = np.asarray(tets, bool)
+        self.is_tet_cell = T
+        ci, cj, ck = I.ravel(), J.ravel(), K.ravel()
+        order = np.argsort(_morton3(ci, cj, ck, bits), kind="stable")
+        per_cell = np.where(T.ravel(), 6, 1)
+        first = np.zeros(nx * ny * nz, np.int64)
+        first[order] = np.concatenate([[0], np.cumsum(per_cell[order])[:-1]])
+        self.num_elements = int(per_cell.sum())
+        gx, gy, gz = np.meshgrid(np.arange(nx + 1) / nx, np.arange(ny + 1) / ny, np.arange(nz + 1) / nz, indexing="ij")
+        X = mapping(gx, gy, gz).reshape(-1, 3)
+
+        def vid(i, j, k):
+            return (i * (ny + 1) + j) * (nz + 1) + k
+
+        corner = lambda c, d: vid(ci[c] + d[0], cj[c] + d[1], ck[c] + d[2])
+        elem, loops = [], []          # one row per (element, face): element id, 4 vertex ids (triangles: last = -1)
+        elem_of_vertices = []         # (element id, its vertex ids) for the centres
+        tc, hc = np.nonzero(T.ravel())[0], np.nonzero(~T.ravel())[0]
+        e3 = np.eye(3, dtype=np.int64)
+        for t, perm in enumerate(self._PERMS):
+            p = [np.zeros(3, np.int64), e3[perm[0]], e3[perm[0]] + e3[perm[1]], np.ones(3, np.int64)]
+            v = [corner(tc, d) for d in p]
+            eid = first[tc] + t
+            elem_of_vertices.append((eid, np.stack(v, 1)))
+            for skip in range(4):
+                tri = [v[q] for q in range(4) if q != skip]
+                elem.append(eid)
+                loops.append(np.stack(tri + [np.full(tc.size, -1, np.int64)], 1))
+        # hexahedra: side d, position s (0 = low, 1 = high); a side shared with a tetrahedron cell is cut like that cell's
+        cube = np.array([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)], np.int64)
+        elem_of_vertices.append((first[hc], np.stack([corner(hc, d) for d in cube], 1)))
+        Tpad = np.zeros((nx + 2, ny + 2, nz + 2), bool)
+        Tpad[1:-1, 1:-1, 1:-1] = T
+        for d in range(3):
+            a, b = (d + 1) % 3, (d + 2) % 3
+            for s in (0, 1):
+                base = s * e3[d]
+                q = [base, base + e3[a], base + e3[a] + e3[b], base + e3[b]]      # the side's loop, lowest corner first
+                v = [corner(hc, x) for x in q]
+                off = e3[d] * (2 * s - 1)
+                nb_tet = Tpad[ci[hc] + 1 + off[0], cj[hc] + 1 + off[1], ck[hc] + 1 + off[2]]
+                whole = ~nb_tet
+                elem.append(first[hc][whole])
+                loops.append(np.stack([x[whole] for x in v], 1))
+                for tri in ((0, 1, 2), (0, 2, 3)):                                  # cut along lowest -> highest corner
+                    elem.append(first[hc][nb_tet])
+                    loops.append(np.stack([v[tri[0]][nb_tet], v[tri[1]][nb_tet], v[tri[2]][nb_tet], np.full(int(nb_tet.sum()), -1, np.int64)], 1))
+        E, Lp = np.concatenate(elem), np.concatenate(loops)
+        # element centres (mean of the vertices) -> orientation of every face loop: outward from its element
+        ctr = np.zeros((self.num_elements, 3))
+        for eid, vs in elem_of_vertices:
+            ctr[eid] = X[vs].mean(axis=1)
+        is_tri = Lp[:, 3] < 0
+        P0, P1, P2 = X[Lp[:, 0]], X[Lp[:, 1]], X[Lp[:, 2]]
+        P3 = X[np.where(is_tri, Lp[:, 0], Lp[:, 3])]
+        A = np.where(is_tri[:, None], 0.5 * np.cross(P1 - P0, P2 - P0), 0.5 * np.cross(P2 - P0, P3 - P1))
+        C = np.where(is_tri[:, None], (P0 + P1 + P2) / 3.0, 0.25 * (P0 + P1 + P2 + P3))
+        flip = np.einsum("ij,ij->i", A, C - ctr[E]) < 0
+        A = np.where(flip[:, None], -A, A)
+        # pair the two sides of every interior face through the sorted vertex set
+        key = np.sort(np.where(Lp < 0, np.iinfo(np.int64).max, Lp), axis=1)
+        order = np.lexsort(key.T[::-1])
+        ks, Es, As, Cs = key[order], E[order], A[order], C[order]
+        same = np.all(ks[1:] == ks[:-1], axis=1)
+        first_of_pair = np.concatenate([same, [False]])
+        second_of_pair = np.concatenate([[False], same])
+        assert not (first_of_pair & second_of_pair).any(), "a face is shared by more than two elements"
+        single = ~first_of_pair & ~second_of_pair
+        i0 = np.nonzero(first_of_pair)[0]
+        a, b = Es[i0], Es[i0 + 1]
+        lo_first = a < b
+        L = np.concatenate([np.where(lo_first, a, b), Es[single]])
+        R = np.concatenate([np.where(lo_first, b, a), np.full(int(single.sum()), -1, np.int64)])
+        Avec = np.concatenate([np.where(lo_first[:, None], As[i0], As[i0 + 1]), As[single]])   # outward from the listed element
+        Cen = np.concatenate([Cs[i0], Cs[single]])
+        self.F, self.B = int(i0.size), int(single.sum())
+        srt = np.argsort(np.where(R >= 0, L, L + self.num_elements), kind="stable")           # interior by left element, then walls
+        self.face_left, self.face_right, self.area_vec, self.face_centroid = L[srt], R[srt], Avec[srt], Cen[srt]
+        L, R, Avec, Cen = self.face_left, self.face_right, self.area_vec, self.face_centroid
+        # every wall face lies on the boundary of the unit cube (checked in index space through its vertices)
+        vol = np.zeros(self.num_elements)
+        np.add.at(vol, L, np.einsum("ij,ij->i", Cen, Avec) / 3.0)
+        np.add.at(vol, R[: self.F], -np.einsum("ij,ij->i", Cen[: self.F], Avec[: self.F]) / 3.0)
+        assert (vol > 0).all()
+        self.volumes, self.centres = vol, ctr
+        self.faces_per_element = (2 * self.F + self.B) / self.num_elements
+        self.num_tets = int(6 * T.sum())
+
+    partition = PrismHexMesh.partition
+    initial_state = PrismHexMesh.initial_state

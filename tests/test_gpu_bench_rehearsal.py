@@ -98,10 +98,8 @@ def test_bench_distributed_path_on_real_rccl_with_one_rank(workload):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["config"]["finite"] is True and rec["value"] > 0
     assert "unavailable" not in out.stderr, out.stderr[-3000:]          # no fall-back was taken
-    if workload == "c1":
-        assert rec["config"]["halo"] == "native rccl (C++ stepper)" and rec["config"]["driver"] == "native C++ stepper"
-    else:
-        assert rec["config"]["halo"] == "torch.distributed"            # Subgrid runs use the python-driven stages
+    # plain tiles (c1) and Subgrid blocks (c3q) both run on the C++ step driver with the native RCCL exchange
+    assert rec["config"]["halo"] == "native rccl (C++ stepper)" and rec["config"]["driver"] == "native C++ stepper"
 
 
 def test_bench_refuses_a_world_size_that_differs_from_gpus():

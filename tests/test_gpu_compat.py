@@ -227,5 +227,8 @@ def test_compat_flux_kernels_on_the_reference_vectors(dtype, tag, kind, name, wa
     torch.cuda.synchronize()
     # per-vector scale: the largest flux component of that vector (strong jumps span 6 decades across the set)
     scale = np.abs(want).max(axis=1, keepdims=True) + np.finfo(want.dtype).tiny
-    err = (np.abs(got.astype(np.float64) - want.astype(np.float64)) / scale).max()
-    assert err < (5e-13 if dtype == torch.float64 else 2e-5), err
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64)) / scale
+    # worst vector (near-equal and strong-jump pairs amplify the last ulp of the device's log / division sequences
+    # through cancellation, most visibly in fp32) and the bulk of the set
+    assert err.max() < (5e-13 if dtype == torch.float64 else 1e-4), err.max()
+    assert np.quantile(err.max(axis=1), 0.99) < (2e-14 if dtype == torch.float64 else 5e-6), np.quantile(err.max(axis=1), 0.99)

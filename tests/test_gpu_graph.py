@@ -1,0 +1,103 @@
+"""-m gpu: hipGraph replay of the native step driver (t8gpu_hip_plain_stepper_graph): a whole iterate_steps() call --
+tile / block launches, cross-stream events and, with a halo, the RCCL exchange -- captured once and replayed with one
+hipGraphLaunch must give bitwise the result of the direct enqueue."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from _gpu import perturbed_state
+from t8gpu_amd.solver import PlainSolver, SubgridSolver
+from t8gpu_amd.synth import SynthMesh
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("kind", ["plain", "subgrid"])
+def test_graph_replay_equals_direct_enqueue_single_rank(kind):
+    if kind == "plain":
+        mesh = SynthMesh(2, 4, 7, band=0.06)
+        part = mesh.partition()
+        st = perturbed_state(part, 3)
+        make = lambda: PlainSolver(part, torch.float64, mode="fused", state=st)
+        dt = 0.1 * 2.0 ** -mesh.finest_level
+    else:
+        mesh = SynthMesh(3, 3, 4, band=0.05)
+        part = mesh.partition(subgrid=True)
+        make = lambda: SubgridSolver(part, torch.float32, mode="fused")
+        dt = 0.1 * 2.0 ** -(mesh.finest_level + 2)
+    a, b = make(), make()
+    a.use_native_stepper()
+    b.use_native_stepper()
+    b.stepper.graph(True)
+    for n in (5, 5, 5, 2, 5):            # 5 captured once and replayed; 2 (another argument set) re-captures; 5 again re-captures
+        a.iterate_steps(n, dt)
+        b.iterate_steps(n, dt)
+    torch.cuda.synchronize()
+    captures, replays = b.stepper.graph()
+    # an odd step count swaps the roles of the Step0 / Step3 planes from call to call, which is a different argument set
+    assert replays == 5 and 2 <= captures <= 5
+    assert torch.equal(a.state(), b.state())
+    assert a.stepper.graph() == (0, 0)
+
+
+CHILD = r"""
+import sys, types
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from t8gpu_amd import native
+from t8gpu_amd.solver import PlainSolver
+from t8gpu_amd.synth import SynthMesh
+mesh = SynthMesh(2, 5, 8, band=0.05)
+whole, half = mesh.partition(), mesh.partition(0, 2)
+x, y = whole.centres[:, 0], whole.centres[:, 1]
+rho = 1.5 + 0.4 * np.sin(4 * np.pi * y) * np.cos(2 * np.pi * x)
+v1, v2 = 0.3 * np.cos(4 * np.pi * y), 0.2 * np.sin(2 * np.pi * x) * np.sin(4 * np.pi * y)
+st = np.stack([rho, rho * v1, rho * v2, 0 * rho, 2.5 / 0.4 + 0.5 * rho * (v1 * v1 + v2 * v2)])
+n2 = whole.N // 2
+st[:, n2:] = st[:, :n2]
+gidx = np.concatenate([np.arange(half.N), half.ghost_global])
+comm = native.NativeComm(0, 1, lambda b, src: b)
+fake = types.SimpleNamespace(N=half.N, G=half.G, cells_per_element=1, peers=np.zeros(1, np.int32), send_off=half.send_off,
+                             recv_off=half.recv_off, send_idx=half.send_idx)
+def run(graph):
+    local = st[:, gidx].copy()
+    g = PlainSolver(half, torch.float64, mode="fused", state=local, plan_options=dict(tmax=64, fcap=160))
+    g.use_native_stepper(native.NativeHalo(fake, torch.float64, comm))
+    g.stepper.graph(graph)
+    dt = 0.1 * 2.0 ** -mesh.finest_level
+    for _ in range(4):
+        g.iterate_steps(6, dt)
+    assert native.stream_wait(torch.cuda.current_stream(), 60.0) == 0
+    return g.state().clone(), g.stepper.graph()
+direct, _ = run(False)
+print("direct enqueue done", flush=True)
+replayed, counts = run(True)
+print("graph counts", counts, flush=True)
+assert counts[1] == 4 and counts[0] >= 1, counts
+assert torch.equal(direct, replayed)
+print("GRAPH WITH RCCL OK", flush=True)
+"""
+
+
+def test_graph_replay_of_the_multi_rank_pipeline_with_rccl_self_exchange(tmp_path):
+    """The three-stream pipeline INCLUDING the RCCL group inside the capture (one-rank communicator, rank 0 exchanging
+    with itself on a shift-symmetric problem). Run in a child process: round 1 recorded a crash inside the runtime for
+    a capture that contained the RCCL group, and a crash must not take the test session down. The outcome is asserted
+    either way -- what this stack does is written down in DESIGN.md section 6."""
+    script = tmp_path / "graph_rccl_child.py"
+    script.write_text(CHILD)
+    res = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=280,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    out = res.stdout + res.stderr
+    (open(os.path.join(ROOT, "gpurun_out", "graph_rccl_child.log"), "w") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else open(os.devnull, "w")).write(out)
+    assert "direct enqueue done" in res.stdout, out[-3000:]
+    if res.returncode == 0:
+        assert "GRAPH WITH RCCL OK" in res.stdout
+    else:
+        # the capture was refused or the runtime crashed: the direct path worked, the failure is reported, not hidden
+        pytest.xfail("RCCL inside a hipGraph capture is not usable on this stack: " + out[-600:].replace("\n", " | "))

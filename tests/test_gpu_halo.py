@@ -215,6 +215,61 @@ def test_native_stepper_with_rccl_self_exchange_on_a_symmetric_problem(dtype, ca
     comm.destroy()
 
 
+@pytest.mark.parametrize("dtype,dim", [(torch.float32, 2), (torch.float64, 2), (torch.float32, 3)])
+def test_native_subgrid_stepper_with_rccl_self_exchange_on_a_symmetric_problem(dtype, dim):
+    """The C++ step driver for Subgrid blocks (t8gpu_hip_subgrid_stepper_*: deep / near-boundary / ghost-touching
+    blocks on three streams, whole ghost blocks over RCCL), with real data dependencies on one GPU: mesh and state
+    are invariant under a shift by 1/2 along the last axis, which maps rank 0's half of the Morton curve onto rank
+    1's, so rank 0 exchanges with itself through a one-rank RCCL communicator and must reproduce the single-rank
+    run on its half (to rounding: a block and its image list their remaining coarse faces in different orders; a ghost
+    block that is one stage stale would be off by O(dt) ~ 1e-3)."""
+    import types
+    from t8gpu_amd import native
+    mesh = SynthMesh(dim, 3 if dim == 3 else 5, 4 if dim == 3 else 7, band=0.05)
+    whole, half = mesh.partition(subgrid=True), mesh.partition(0, 2, subgrid=True)
+    S = 4 ** dim
+    assert half.N * 2 == whole.N and half.peers.tolist() == [1]
+    assert np.array_equal(np.diff(half.send_off), np.diff(half.recv_off))
+    st = whole.kh_initial_state().copy()                                  # [5, N * S]; KH is periodic in x, not under the shift:
+    n2 = whole.N // 2 * S
+    rng = np.random.default_rng(5)
+    st[0, :n2] *= 1 + 0.05 * rng.standard_normal(n2)                      # perturb the lower half ...
+    st[4, :n2] += 0.3
+    st[:, n2:2 * n2] = st[:, :n2]                                         # ... and make the upper half its image
+    ref = SubgridSolver(whole, dtype, mode="fused", state=st)
+    blocks = np.concatenate([np.arange(half.N), half.ghost_global])
+    cells = (blocks[:, None] * S + np.arange(S)[None, :]).reshape(-1)
+    local = st[:, cells].copy()
+    local[:, half.N * S:] = np.nan                                        # ghost blocks must arrive through RCCL
+    g = SubgridSolver(half, dtype, mode="fused", state=local)
+    hp = g.plan.host
+    print("blocks deep / near / ghost-touching:", hp.n_deep, hp.n_interior - hp.n_deep, half.N - hp.n_interior)
+    assert 0 < hp.n_deep < hp.n_interior < half.N
+    comm = native.NativeComm(0, 1, lambda b, src: b)
+    fake = types.SimpleNamespace(N=half.N, G=half.G, cells_per_element=S, peers=np.zeros(1, np.int32), send_off=half.send_off,
+                                 recv_off=half.recv_off, send_idx=half.send_idx)
+    g.use_native_stepper(native.NativeHalo(fake, dtype, comm))
+    dt = 0.1 * 2.0 ** -(mesh.finest_level + 2)
+    for _ in range(1 + 3 + 2 + 7):
+        ref.iterate(dt)
+    g.iterate(dt)
+    g.iterate_steps(3, dt)
+    g.iterate_steps(2, dt)
+    g.iterate_steps(7, dt)
+    assert native.stream_wait(torch.cuda.current_stream(), 30.0) == 0
+    want, got = ref.state().cpu().numpy(), g.state().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_err(got, want[:, : half.N * S]) < (1e-12 if dtype == torch.float64 else 2e-6)
+    # single rank through the same driver (no halo): bitwise the python-driven stages
+    one = SubgridSolver(whole, dtype, mode="fused", state=st)
+    one.use_native_stepper()
+    one.iterate_steps(13, dt)
+    torch.cuda.synchronize()
+    assert torch.equal(one.state(), ref.state())
+    g.stepper = None
+    comm.destroy()
+
+
 def test_bench_native_bring_up_agreement_logic():
     """bench.bring_up_native_stepper with a stand-in process group: success keeps the C++ driver, a rank that
     votes 0 (here: the all-reduce is made to return 0) sends everybody back to the initial state."""
