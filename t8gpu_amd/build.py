@@ -46,7 +46,7 @@ def build_host(force=False):
     deps = srcs + _glob(os.path.join(CSRC, "host"), (".h", ".hpp")) + [os.path.join(ROOT, "include", "t8gpu_host.h")]
     if force or _newer(HOST_LIB, deps):
         os.makedirs(LIB, exist_ok=True)
-        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fopenmp", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", HOST_LIB] + srcs)
+        _run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-fopenmp", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", HOST_LIB] + srcs)
     return HOST_LIB
 
 

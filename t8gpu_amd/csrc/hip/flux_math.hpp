@@ -217,8 +217,11 @@ T8_DEV void axis_basis(int axis, bool positive, T n[3], T t1[3], T t2[3]) {
 }
 
 // face frame (n, t1, t2): kernels.cu:174-193 == kernels.inl:133-156
+// (No contraction: tile_plan.cpp computes the same frame on the host for the geometry dictionary, with separately rounded
+// products; a tile with a dictionary and one without must see the same bits.)
 template <class T>
 T8_DEV void face_basis(const T n[3], T t1[3], T t2[3]) {
+#pragma clang fp contract(off)
   t1[0] = n[1];
   t1[1] = n[2];
   t1[2] = -n[0];

@@ -133,21 +133,19 @@ __global__ __launch_bounds__(256) void k_plain_fused(T8gpuPlainPlan P, int tile_
 // tile are in the LDS flux buffer during that pass). Entries are in ascending face order, so visiting
 // pass 0 then pass 1 keeps the summation order of the single-pass form.
 template <class T>
-T8_DEV void ell_accumulate(uint4 w, int pass, const T* __restrict__ ff, T acc[5], bool& done) {
+T8_DEV bool ell_accumulate(uint4 w, int pass, const T* __restrict__ ff, T acc[5]) {
   const unsigned ent[8] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};
 #pragma unroll
   for (int j = 0; j < 8; j++) {
-    if (ent[j] == 0xFFFFu) done = true;
-    const int  f      = ent[j] & 0x7FFFu;
-    const bool active = !done && (f >> 8) == pass;
-    if (__any(active)) {  // wave-uniform skip: padding slots and the other pass cost nothing
-      // inactive lanes read slot 0 (always written in the current pass) with weight 0: one FMA per value
-      const int idx = active ? (f & 255) : 0;
-      const T   wgt = active ? ((ent[j] & 0x8000u) ? T(1) : T(-1)) : T(0);
+    // face index = (pass << 8) | slot; the padding 0xFFFF has pass field 127 and matches no pass
+    if (((ent[j] & 0x7FFFu) >> 8) == static_cast<unsigned>(pass)) {
+      const T* p   = ff + (ent[j] & 255u);
+      const T  wgt = (ent[j] & 0x8000u) ? T(1) : T(-1);
 #pragma unroll
-      for (int k = 0; k < 5; k++) acc[k] = __builtin_fma(wgt, ff[k * 256 + idx], acc[k]);
+      for (int k = 0; k < 5; k++) acc[k] = __builtin_fma(wgt, p[k * 256], acc[k]);
     }
   }
+  return (w.w >> 16) == 0xFFFFu;   // the row ends in this chunk
 }
 
 template <class T>
@@ -336,9 +334,8 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
     if (SCATTER) continue;   // the accumulators take every pass; one barrier after the loop
     __syncthreads();
     if (own) {
-      bool done = false;
-      ell_accumulate<T>(ell0, it, ff, acc, done);
-      for (int c = 1; c < P.ell_width / 8 && !done; c++) ell_accumulate<T>(ellrow[c], it, ff, acc, done);
+      bool done = ell_accumulate<T>(ell0, it, ff, acc);
+      for (int c = 1; c < P.ell_width / 8 && !done; c++) done = ell_accumulate<T>(ellrow[c], it, ff, acc);
     }
     if (!last) __syncthreads();   // the buffer is rewritten by the next pass
   }
@@ -388,7 +385,13 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
                          slots <= 512 && plan->max_faces <= 1024;
   const bool  four = plan->max_faces > 512;
   static const bool scatter = std::getenv("T8GPU_LDS_SCATTER") && std::getenv("T8GPU_LDS_SCATTER")[0] == '1';   // measured alternative
-  if (!scatter) {   // default for plans it takes: the persistent, software-pipelined kernel (kernels_fused_persistent.hip)
+  // The persistent, software-pipelined kernel (kernels_fused_persistent.hip) for launches that cover the whole plan.
+  // A multi-rank stage is split into tile classes on three streams beside the pack / RCCL / unpack kernels
+  // (stepper.hip): persistent workgroups would hold every register file and LDS slot of the chip until their class is
+  // done and keep those small kernels -- the exchange the split exists to overlap -- from starting, so partial
+  // ranges use the one-tile-per-workgroup kernels, whose slots free up continuously. Both give the same bits.
+  static const bool persistent_always = std::getenv("T8GPU_PERSISTENT") && std::getenv("T8GPU_PERSISTENT")[0] == '2';
+  if (!scatter && (persistent_always || (tile_begin == 0 && tile_count == plan->ntiles))) {
     const int rc = plain_persistent_stage<T>(kind, stage, plan, tile_begin, tile_count, fmk<T>(prev), fmk<T>(mid), fmk<T>(out), volume,
                                              dt, speed, s);
     if (rc >= 0) return rc;

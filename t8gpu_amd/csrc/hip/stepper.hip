@@ -9,6 +9,8 @@
 #include <rccl/rccl.h>
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -56,7 +58,31 @@ struct Stepper {
   hipGraphExec_t  graph_exec = nullptr;
   unsigned char   graph_key[96] = {0};
   int             graph_captures = 0, graph_replays = 0;
+  bool            capturing = false;    // iterate() is being recorded into a graph
+  int             capture_variant = 0;  // diagnostics (T8GPU_GRAPH_VARIANT): 1 = node before the fork, 2 = + global capture mode
+  void*           scratch = nullptr;
+  std::vector<hipEvent_t> capture_events;   // one event per (stage, role) of a captured call (see stage_event)
 };
+
+// Events that order the three streams. Direct enqueue: one event per role, re-recorded every stage. Inside a capture
+// every (stage, role) gets an event of its own: a captured wait refers to the record node it follows, and the HIP
+// runtime of this stack crashes when an event that captured waits already refer to is recorded again in the same
+// capture (segmentation fault at the end of the capture, with or without RCCL in it: tests/test_gpu_graph.py).
+enum EventRole { kDeep = 0, kGhost = 1, kInterior = 2, kJoin = 3 };
+static int stage_event(Stepper* S, int g, EventRole role, hipEvent_t* out) {
+  if (!S->capturing) {
+    *out = role == kDeep ? S->ev_deep : (role == kGhost ? S->ev_ghost : S->ev_interior);
+    return 0;
+  }
+  const size_t idx = static_cast<size_t>(g) * 4 + static_cast<size_t>(role);
+  while (S->capture_events.size() <= idx) {
+    hipEvent_t e;
+    T8_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    S->capture_events.push_back(e);
+  }
+  *out = S->capture_events[idx];
+  return 0;
+}
 
 template <class T>
 ncclDataType_t nccl_type();
@@ -77,7 +103,11 @@ int exchange(const T8gpuHalo& h, const int32_t* peers, const int32_t* send_off, 
   } else {
     T8_TRY(t8gpu_hip_halo_pack_f64(h.n_send, cells, h.send_idx, state, sb, s));
   }
+  // diagnostic only (tests/test_gpu_graph.py): leave the RCCL group out, to tell a capture that fails because of RCCL
+  // from one that fails because of the three-stream fork / join (the ghosts are then stale: results are wrong)
+  static const bool no_rccl = std::getenv("T8GPU_DEBUG_NO_RCCL") != nullptr;
   ncclComm_t comm = static_cast<ncclComm_t>(h.comm);
+  if (!no_rccl) {
   T8_TRY(nccl_code(ncclGroupStart()));
   for (int j = 0; j < h.n_peers; j++) {
     const size_t w  = 5 * static_cast<size_t>(cells);   // values per element on the wire
@@ -87,6 +117,7 @@ int exchange(const T8gpuHalo& h, const int32_t* peers, const int32_t* send_off, 
     if (sc) T8_TRY(nccl_code(ncclSend(sb + w * static_cast<size_t>(send_off[j]), sc, nccl_type<T>(), peers[j], comm, s)));
   }
   T8_TRY(nccl_code(ncclGroupEnd()));
+  }
   if constexpr (sizeof(T) == 4) {
     T8_TRY(t8gpu_hip_halo_unpack_f32(h.num_ghosts, h.num_elements, cells, rb, state, s));
   } else {
@@ -139,6 +170,7 @@ int iterate(Stepper* S, int kind, T* planes, size_t stride, const T* vol, int pr
   const bool comm = S->has_halo && S->halo.n_peers > 0;
   t8gpu_hip::Range whole(comm ? "t8gpu.iterate_steps (exchange + 3 tile classes)" : "t8gpu.iterate_steps");
   static const char* const stage_name[3] = {"t8gpu.rk_stage1", "t8gpu.rk_stage2", "t8gpu.rk_stage3"};
+  hipEvent_t last_ghost = nullptr, last_interior = nullptr;
   for (int g = 0; g < 3 * n_steps; g++) {
     const int k  = g % 3;
     t8gpu_hip::Range stage_range(stage_name[k]);
@@ -172,28 +204,52 @@ int iterate(Stepper* S, int kind, T* planes, size_t stride, const T* vol, int pr
       continue;
     }
     if (g == 0) {  // entry: the other streams must see everything the caller queued on s
+      if (S->capturing && S->scratch) T8_HIP_TRY(hipMemsetAsync(S->scratch, 0, 64, s));   // a first node for the fork event
       T8_HIP_TRY(hipEventRecord(S->ev_state, s));
       T8_HIP_TRY(hipStreamWaitEvent(S->comm_stream, S->ev_state, 0));
       T8_HIP_TRY(hipStreamWaitEvent(S->near_stream, S->ev_state, 0));
     }
     // every wait on an event of stage g-1 is issued before that event is re-recorded for stage g
+    hipEvent_t deep_p = nullptr, ghost_p = nullptr, inter_p = nullptr, deep_c, ghost_c, inter_c;
     if (g > 0) {
-      T8_HIP_TRY(hipStreamWaitEvent(S->near_stream, S->ev_deep, 0));       // B_g <- C_(g-1)
-      T8_HIP_TRY(hipStreamWaitEvent(S->near_stream, S->ev_ghost, 0));      // B_g <- A_(g-1)
-      T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_interior, 0));                // C_g <- B_(g-1)
+      T8_TRY(stage_event(S, g - 1, kDeep, &deep_p));
+      T8_TRY(stage_event(S, g - 1, kGhost, &ghost_p));
+      T8_TRY(stage_event(S, g - 1, kInterior, &inter_p));
+    }
+    T8_TRY(stage_event(S, g, kDeep, &deep_c));
+    T8_TRY(stage_event(S, g, kGhost, &ghost_c));
+    T8_TRY(stage_event(S, g, kInterior, &inter_c));
+    if (g > 0 && S->capturing) {
+      // Inside a capture every dependency goes through the origin stream: it joins the two other streams' previous
+      // stage, records one event, and they fork from that (forked streams waiting on each other's events -- what the
+      // direct enqueue below does -- is one of the things tried against the capture crash of this stack, see
+      // iterate_graph). Costs one edge the pipeline does not need: C_g now also follows A_(g-1).
+      hipEvent_t join;
+      T8_TRY(stage_event(S, g, kJoin, &join));
+      T8_HIP_TRY(hipStreamWaitEvent(s, inter_p, 0));
+      T8_HIP_TRY(hipStreamWaitEvent(s, ghost_p, 0));
+      T8_HIP_TRY(hipEventRecord(join, s));
+      T8_HIP_TRY(hipStreamWaitEvent(S->near_stream, join, 0));
+      T8_HIP_TRY(hipStreamWaitEvent(S->comm_stream, join, 0));
+    } else if (g > 0) {
+      T8_HIP_TRY(hipStreamWaitEvent(S->near_stream, deep_p, 0));           // B_g <- C_(g-1)
+      T8_HIP_TRY(hipStreamWaitEvent(S->near_stream, ghost_p, 0));          // B_g <- A_(g-1)
+      T8_HIP_TRY(hipStreamWaitEvent(s, inter_p, 0));                       // C_g <- B_(g-1)
     }
     T8_TRY(launch(0, nd, s));                                              // C_g
-    T8_HIP_TRY(hipEventRecord(S->ev_deep, s));
+    T8_HIP_TRY(hipEventRecord(deep_c, s));
     T8_TRY((exchange<T, V>(S->halo, S->peers.data(), S->send_off.data(), S->recv_off.data(), sv, S->comm_stream)));
-    if (g > 0) T8_HIP_TRY(hipStreamWaitEvent(S->comm_stream, S->ev_interior, 0));   // A_g <- B_(g-1)
+    if (g > 0 && !S->capturing) T8_HIP_TRY(hipStreamWaitEvent(S->comm_stream, inter_p, 0));   // A_g <- B_(g-1)
     T8_TRY(launch(ni, nt - ni, S->comm_stream));                           // A_g
-    T8_HIP_TRY(hipEventRecord(S->ev_ghost, S->comm_stream));
+    T8_HIP_TRY(hipEventRecord(ghost_c, S->comm_stream));
     T8_TRY(launch(nd, ni - nd, S->near_stream));                           // B_g
-    T8_HIP_TRY(hipEventRecord(S->ev_interior, S->near_stream));
+    T8_HIP_TRY(hipEventRecord(inter_c, S->near_stream));
+    last_ghost = ghost_c;
+    last_interior = inter_c;
   }
   if (comm && n_steps > 0) {  // exit: everything is ordered on s again
-    T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_ghost, 0));
-    T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_interior, 0));
+    T8_HIP_TRY(hipStreamWaitEvent(s, last_ghost, 0));
+    T8_HIP_TRY(hipStreamWaitEvent(s, last_interior, 0));
   }
   return 0;
 }
@@ -225,14 +281,31 @@ int iterate_graph(Stepper* S, int kind, T* planes, size_t stride, const T* vol, 
       S->graph_exec = nullptr;
     }
     hipGraph_t g = nullptr;
-    T8_HIP_TRY(hipStreamBeginCapture(S->graph_stream, hipStreamCaptureModeRelaxed));
+    static const bool trace = std::getenv("T8GPU_DEBUG_GRAPH") != nullptr;   // progress marks on stderr (diagnostics)
+#define T8_MARK(what) do { if (trace) { std::fprintf(stderr, "[t8gpu graph] %s\n", what); std::fflush(stderr); } } while (0)
+    T8_MARK("begin capture");
+    S->capture_variant = std::getenv("T8GPU_GRAPH_VARIANT") ? std::atoi(std::getenv("T8GPU_GRAPH_VARIANT")) : 0;
+    if (!S->scratch) T8_HIP_TRY(hipMalloc(&S->scratch, 64));
+    {   // every event a capture of this length needs exists before the capture starts
+      S->capturing = true;
+      hipEvent_t e;
+      for (int g2 = 0; g2 < 3 * n_steps; g2++)
+        for (int r = 0; r < 4; r++) T8_TRY(stage_event(S, g2, static_cast<EventRole>(r), &e));
+      S->capturing = false;
+    }
+    T8_HIP_TRY(hipStreamBeginCapture(S->graph_stream, S->capture_variant >= 2 ? hipStreamCaptureModeGlobal : hipStreamCaptureModeRelaxed));
+    S->capturing  = true;
     const int  rc = iterate<T, V>(S, kind, planes, stride, vol, prev, next, dt, speed, n_steps, S->graph_stream);
+    S->capturing  = false;
+    T8_MARK("enqueue recorded");
     hipError_t e  = hipStreamEndCapture(S->graph_stream, &g);
+    T8_MARK("capture ended");
     if (rc != 0 || e != hipSuccess || !g) {
       if (g) (void)hipGraphDestroy(g);
       return rc != 0 ? rc : static_cast<int>(e != hipSuccess ? e : hipErrorStreamCaptureInvalidated);
     }
     e = hipGraphInstantiate(&S->graph_exec, g, nullptr, nullptr, 0);
+    T8_MARK("instantiated");
     (void)hipGraphDestroy(g);
     if (e != hipSuccess) {
       S->graph_exec = nullptr;
@@ -245,6 +318,7 @@ int iterate_graph(Stepper* S, int kind, T* planes, size_t stride, const T* vol, 
   T8_HIP_TRY(hipEventRecord(S->ev_graph_in, s));                         // the graph starts behind the caller's work ...
   T8_HIP_TRY(hipStreamWaitEvent(S->graph_stream, S->ev_graph_in, 0));
   T8_HIP_TRY(hipGraphLaunch(S->graph_exec, S->graph_stream));
+  if (std::getenv("T8GPU_DEBUG_GRAPH")) { std::fprintf(stderr, "[t8gpu graph] launched\n"); std::fflush(stderr); }
   T8_HIP_TRY(hipEventRecord(S->ev_graph_out, S->graph_stream));
   T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_graph_out, 0));                 // ... and the caller's stream continues behind it
   S->graph_replays++;
@@ -373,6 +447,8 @@ int t8gpu_hip_plain_stepper_destroy(void* h) {
   if (S->comm_stream) (void)hipStreamDestroy(S->comm_stream);
   if (S->near_stream) (void)hipStreamDestroy(S->near_stream);
   if (S->graph_exec) (void)hipGraphExecDestroy(S->graph_exec);
+  for (hipEvent_t e : S->capture_events) (void)hipEventDestroy(e);
+  if (S->scratch) (void)hipFree(S->scratch);
   if (S->ev_graph_in) (void)hipEventDestroy(S->ev_graph_in);
   if (S->ev_graph_out) (void)hipEventDestroy(S->ev_graph_out);
   if (S->graph_stream) (void)hipStreamDestroy(S->graph_stream);

@@ -102,6 +102,26 @@ def test_bench_distributed_path_on_real_rccl_with_one_rank(workload):
     assert rec["config"]["halo"] == "native rccl (C++ stepper)" and rec["config"]["driver"] == "native C++ stepper"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_bench_adaptive_workload_small(world):
+    """bench.py --workload c5a (BASELINE config 5's loop: adapt + repartition every 20 steps inside the timed region) on a
+    small forest: one rank, and two ranks sharing the GPU over gloo (adapt_partitioned + new halo lists per cycle)."""
+    env = dict(os.environ, T8GPU_C5A_LEVELS="4,6", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    if world > 1:
+        env["T8GPU_REHEARSAL"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--workload", "c5a", "--steps", "45",
+                          "--warmup", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    cfg = rec["config"]
+    assert rec["n_gpus"] == world and rec["steps"] == 45 and cfg["adapt_cycles_timed"] == 2 and cfg["finite"] is True
+    assert cfg["step_ms"] > 0 and cfg["cycle_ms"] > 0 and rec["value"] > 0 and cfg["elements_at_end"] > 16 ** 3
+    assert rec["value"] <= cfg["stepping_only_M_cell_updates_per_s"]
+
+
 def test_bench_refuses_a_world_size_that_differs_from_gpus():
     """WORLD_SIZE != --gpus is an error, not a silently mislabelled run (needs no GPU: it exits before any GPU call)."""
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")

@@ -79,9 +79,35 @@ print("direct enqueue done", flush=True)
 replayed, counts = run(True)
 print("graph counts", counts, flush=True)
 assert counts[1] == 4 and counts[0] >= 1, counts
-assert torch.equal(direct, replayed)
-print("GRAPH WITH RCCL OK", flush=True)
+import os
+if os.environ.get("T8GPU_DEBUG_NO_RCCL"):      # ghosts never arrive in this mode: only "captured and replayed" counts
+    print("GRAPH WITHOUT RCCL CAPTURED AND REPLAYED", flush=True)
+else:
+    assert torch.equal(direct, replayed)
+    print("GRAPH WITH RCCL OK", flush=True)
 """
+
+
+def _child(tmp_path, env):
+    script = tmp_path / "graph_rccl_child.py"
+    script.write_text(CHILD)
+    res = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=280,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", T8GPU_DEBUG_GRAPH="1", **env))
+    out = res.stdout + res.stderr + f"\n[child exit code {res.returncode}]\n"
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        with open(os.path.join(ROOT, "gpurun_out", "graph_child" + ("_no_rccl" if env else "") + ".log"), "w") as f:
+            f.write(out)
+    return res, out
+
+
+def test_graph_capture_of_the_three_stream_pipeline_without_the_rccl_group(tmp_path):
+    """The multi-rank pipeline's capture with the RCCL group left out (T8GPU_DEBUG_NO_RCCL: pack, unpack, tile classes on
+    three streams joined through events; the ghosts never arrive then, so only `captured and replayed` is checked).
+    Separates a capture problem of the fork / join structure from one of RCCL: with forked streams waiting on each
+    other's events hipStreamEndCapture crashed on this stack; with every dependency routed through the origin stream
+    (stepper.hip) this capture works -- and the one below, which differs by the RCCL group only, still does not."""
+    res, out = _child(tmp_path, dict(T8GPU_DEBUG_NO_RCCL="1"))
+    assert res.returncode == 0 and "GRAPH WITHOUT RCCL CAPTURED AND REPLAYED" in res.stdout, out[-3000:]
 
 
 def test_graph_replay_of_the_multi_rank_pipeline_with_rccl_self_exchange(tmp_path):
@@ -89,12 +115,7 @@ def test_graph_replay_of_the_multi_rank_pipeline_with_rccl_self_exchange(tmp_pat
     with itself on a shift-symmetric problem). Run in a child process: round 1 recorded a crash inside the runtime for
     a capture that contained the RCCL group, and a crash must not take the test session down. The outcome is asserted
     either way -- what this stack does is written down in DESIGN.md section 6."""
-    script = tmp_path / "graph_rccl_child.py"
-    script.write_text(CHILD)
-    res = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=280,
-                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
-    out = res.stdout + res.stderr
-    (open(os.path.join(ROOT, "gpurun_out", "graph_rccl_child.log"), "w") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else open(os.devnull, "w")).write(out)
+    res, out = _child(tmp_path, {})
     assert "direct enqueue done" in res.stdout, out[-3000:]
     if res.returncode == 0:
         assert "GRAPH WITH RCCL OK" in res.stdout
