@@ -296,7 +296,7 @@ namespace t8gpu::hip {
       if (!h) T8GPU_ABORT("t8gpu_plan_subgrid_create failed (axis-aligned unit normals required, as in the reference)");
       int64_t sz[8];
       t8gpu_plan_subgrid_sizes(h, sz);
-      std::vector<int32_t> block_rec(16 * static_cast<size_t>(std::max<int32_t>(1, m.num_local_elements))),
+      std::vector<int32_t> block_rec(32 * static_cast<size_t>(std::max<int32_t>(1, m.num_local_elements))),
           bf_rec(4 * static_cast<size_t>(std::max<int64_t>(1, sz[0])));
       t8gpu_plan_subgrid_records(h, m.face_surfaces.data(), static_cast<int>(sizeof(ft)), block_rec.data(), bf_rec.data());
       t8gpu_plan_subgrid_destroy(h);

@@ -254,8 +254,9 @@ int t8gpu_hip_plain_stepper_timed_stages(void* stepper); /* RK stages covered by
 typedef struct T8gpuSubgridPlan {
   /* joined records, t8gpu_plan_subgrid_records(): one dependent load level between a wavefront's position
    * and all of its far-cell loads */
-  const int32_t* block_rec;     /* [num_elements][16], blocks that touch no ghost block first: {block, n generic
-                                   faces, first bf_rec entry, 0, 3 x {other block, code, area (2 words)}} (64-byte rows) */
+  const int32_t* block_rec;     /* [num_elements][32], blocks that touch no ghost block first: {block, n generic
+                                   faces, first bf_rec entry, 0, 3 x {other block, code, area (2 words)}, copies of the
+                                   block's first 4 bf_rec rows (other = -3: none)} (128-byte rows) */
   const int32_t* bf_rec;        /* [n_entries][4] generic faces in the same order: {other block (-1 wall), code
                                    (bit 12: the block is the face's RIGHT side), area (2 words)}; walls first */
   int32_t num_elements, rank, max_faces_per_block, n_interior_blocks;

@@ -80,7 +80,7 @@ void t8gpu_plan_subgrid_order(const void* plan, int32_t* block_order);
 void t8gpu_plan_subgrid_arrays(const void* plan, int32_t* bf_off, int32_t* bf_ent, int32_t* face_rec, int32_t* plus);
 
 /* The joined per-block records the fused Subgrid kernels read (layout: csrc/host/subgrid_plan.cpp):
- * block_rec[N][16] in block_order position order, bf_rec[n_entries][4]; areas = face_surfaces[F + B] (doubles),
+ * block_rec[N][32] in block_order position order (128-byte rows, see T8gpuSubgridPlan), bf_rec[n_entries][4]; areas = face_surfaces[F + B] (doubles),
  * float_size = 4 or 8 selects how the areas are stored in the records. */
 void t8gpu_plan_subgrid_records(const void* plan, const double* areas, int float_size, int32_t* block_rec, int32_t* bf_rec);
 

@@ -25,6 +25,8 @@
 // so the reference's unsynchronised LDS reuse has no counterpart here.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "flux_math.hpp"
 #include "t8gpu_hip.h"
 
@@ -116,17 +118,17 @@ struct FaceLane {
 T8_DEV float  area_of(int lo, int, float) { return __int_as_float(lo); }
 T8_DEV double area_of(int lo, int hi, double) { return __hiloint2double(hi, lo); }
 
+// lane data of one generic face from its row {other block, code, area}; `live_row` = the row exists
 template <class T, int S>
-T8_DEV FaceLane<T> load_face_lane(const T8gpuSubgridPlan& P, const SVars<T>& src, int first, int nbf, int idx, int si, int sj) {
+T8_DEV FaceLane<T> face_lane_from_row(const SVars<T>& src, int4 rec, bool live_row, int si, int sj) {
   FaceLane<T> L;
-  L.active = idx < nbf;
+  L.active = live_row;
   L.right = L.wall = false;
   L.axis = L.positive = L.myflat = 0;
   L.area = T(0);
 #pragma unroll
   for (int k = 0; k < 5; k++) L.sf[k] = T(1);
   if (L.active) {
-    const int4     rec = reinterpret_cast<const int4*>(P.bf_rec)[first + idx];   // {other block, code, area}
     const FaceCode fc  = decode(rec.y);
     L.right = fc.right();
     L.wall  = rec.x == -1;
@@ -142,6 +144,12 @@ T8_DEV FaceLane<T> load_face_lane(const T8gpuSubgridPlan& P, const SVars<T>& src
     }
   }
   return L;
+}
+template <class T, int S>
+T8_DEV FaceLane<T> load_face_lane(const T8gpuSubgridPlan& P, const SVars<T>& src, int first, int nbf, int idx, int si, int sj) {
+  int4 rec = make_int4(0, 0, 0, 0);
+  if (idx < nbf) rec = reinterpret_cast<const int4*>(P.bf_rec)[first + idx];   // {other block, code, area}
+  return face_lane_from_row<T, S>(src, rec, idx < nbf, si, sj);
 }
 
 // The +d coarse face of a block (wave-uniform for RANK 3: these are scalar loads, which keeps the
@@ -186,7 +194,7 @@ T8_DEV void load_plus_far(const SVars<T>& src, bool on, bool right, bool wall, i
 
 // RANK 3: one Subgrid<4,4,4> block per wavefront. RANK 2: four Subgrid<4,4> blocks per wavefront
 // (16 lanes each; every index below is relative to the lane's own block).
-template <class T, int KIND, int STAGE, int RANK>
+template <class T, int KIND, int STAGE, int RANK, bool EARLY_PREV>
 __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int block_begin, int block_count, SVars<T> prev,
                                                       SVars<T> src, SVars<T> out, const T* __restrict__ volumes, T dt) {
   constexpr int NW  = CellData<T, KIND>::words;
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
   const bool   live = pos < block_count;
   // ONE dependent level: the block's joined record (64 bytes; four scalar loads for RANK 3) names the block, its
   // generic face list and the far block, code and area of its three + faces
-  const int4* __restrict__ brec = reinterpret_cast<const int4*>(P.block_rec) + 4 * (size_t)(block_begin + (live ? pos : 0));
+  const int4* __restrict__ brec = reinterpret_cast<const int4*>(P.block_rec) + 8 * (size_t)(block_begin + (live ? pos : 0));
   const int4   r0 = brec[0];
   const int    e  = r0.x;
   const int    cc[3] = {cl & 3, (cl >> 2) & 3, RANK == 3 ? cl >> 4 : 0};   // compile-time indices only
@@ -226,8 +234,18 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
 
   // the far cells of the + faces and the first generic pass are fetched NOW, so that their dependent
   // loads (face list -> face record -> far cell) overlap the arithmetic
+  // (the record carries copies of the first four generic rows -- other = -3: none --, so their far cells are requested
+  //  together with everything else instead of one round trip later: record -> bf_rec rows -> far cells)
   const int slot = cl / SF, sub = cl % SF, si = sub & 3, sj = RANK == 3 ? sub >> 2 : 0;
-  const FaceLane<T> pre0 = load_face_lane<T, S>(P, src, b0, nbf, slot, si, sj);
+  const int4        row0 = brec[4 + slot];
+  const FaceLane<T> pre0 = face_lane_from_row<T, S>(src, row0, live && row0.x != -3, si, sj);
+  // previous-step state: requested with everything else (it used to be fetched last to save registers, which made
+  // it the fourth dependent round trip of a wavefront's life)
+  T pv[5] = {T(0), T(0), T(0), T(0), T(0)};
+  if (STAGE > 1 && EARLY_PREV) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) pv[k] = prev.p[k][o];
+  }
   const PlusFace<T> fx = plus_face<T>(brec[1], live), fy = plus_face<T>(brec[2], live),
                     fz = RANK == 3 ? plus_face<T>(brec[3], live) : PlusFace<T>{false, false, false, 0, 0, 0, T(0)};
   // lane cl < PF fetches far cell `cl % SF` of the block's +(cl / SF) face
@@ -344,8 +362,7 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
   // (the previous step's state is only needed here: fetched late, it does not occupy registers during the
   //  flux passes -- fp64 stays at 128 VGPRs = 4 waves per SIMD; other waves cover the latency)
   if (live) {
-    T pv[5];
-    if (STAGE > 1) {
+    if (STAGE > 1 && !EARLY_PREV) {
 #pragma unroll
       for (int k = 0; k < 5; k++) pv[k] = prev.p[k][o];
     }
@@ -373,9 +390,20 @@ int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, int b
   if (block_count == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3  grid(plan->rank == 3 ? block_count : (block_count + 3) / 4), block(64);
-#define T8_SG(K, S, R)                                                                                                   \
-  hipLaunchKernelGGL((k_subgrid_fused<T, K, S, R>), grid, block, 0, s, *plan, block_begin, block_count, smk<T>(prev), \
-                     smk<T>(mid), smk<T>(out), volumes, dt)
+  // fp32 requests the previous-step state up front (one round trip less per wavefront); fp64 keeps fetching it last:
+  // it is bound by DP instruction issue and the 10 extra registers would cost it a wavefront per SIMD. T8GPU_SG_EARLY_PREV
+  // = 0 / 1 overrides (measurements).
+  static const int early_env = std::getenv("T8GPU_SG_EARLY_PREV") ? std::atoi(std::getenv("T8GPU_SG_EARLY_PREV")) : -1;
+  const bool early = early_env >= 0 ? early_env != 0 : sizeof(T) == 4;
+#define T8_SG(K, S, R)                                                                                                          \
+  do {                                                                                                                          \
+    if (early)                                                                                                                  \
+      hipLaunchKernelGGL((k_subgrid_fused<T, K, S, R, true>), grid, block, 0, s, *plan, block_begin, block_count, smk<T>(prev),  \
+                         smk<T>(mid), smk<T>(out), volumes, dt);                                                                \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((k_subgrid_fused<T, K, S, R, false>), grid, block, 0, s, *plan, block_begin, block_count, smk<T>(prev), \
+                         smk<T>(mid), smk<T>(out), volumes, dt);                                                                \
+  } while (0)
 #define T8_SGR(K, S)     \
   do {                   \
     if (plan->rank == 3) \

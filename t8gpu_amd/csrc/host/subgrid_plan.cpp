@@ -163,8 +163,11 @@ void t8gpu_plan_subgrid_arrays(const void* h, int32_t* bf_off, int32_t* bf_ent, 
 
 // What the kernel reads, joined per block so that a wavefront needs ONE dependent level (its record) before it
 // can issue every far-cell load, instead of block_order -> face list -> face record -> far cell:
-//   block_rec[N][16] in block_order position order:
-//     {block, n generic faces, first entry in bf_rec, 0,  then for d = 0..2 the +d face: other, code, area (2 words)}
+//   block_rec[N][32] in block_order position order (128-byte rows):
+//     {block, n generic faces, first entry in bf_rec, 0,  then for d = 0..2 the +d face: other, code, area (2 words),
+//      then COPIES of the block's first four generic faces (other = -3: no such face)} -- with the copies a wavefront
+//     can request the far cells of its first generic pass as soon as it knows its position, instead of one round trip
+//     later (record -> bf_rec rows -> far cells)
 //   bf_rec[n_entries][4], the generic faces of the blocks in the same position order: other, code, area (2 words)
 // other = the block on the far side (left block if this block is the face's right side and vice versa), -1 = wall,
 // -2 (+ faces only) = not foldable (finer neighbours: those faces are in the generic list); code = the face code of
@@ -188,8 +191,8 @@ void t8gpu_plan_subgrid_records(const void* h, const double* areas, int float_si
   int32_t first = 0;
   for (int32_t pos = 0; pos < P->N; pos++) {
     const int32_t e   = P->block_order[pos];
-    int32_t*      rec = block_rec + 16 * static_cast<size_t>(pos);
-    std::memset(rec, 0, 64);
+    int32_t*      rec = block_rec + 32 * static_cast<size_t>(pos);
+    std::memset(rec, 0, 128);
     rec[0] = e;
     rec[1] = P->bf_off[e + 1] - P->bf_off[e];
     rec[2] = first;
@@ -200,6 +203,11 @@ void t8gpu_plan_subgrid_records(const void* h, const double* areas, int float_si
         const int32_t ent = P->plus[static_cast<size_t>(e) * P->rank + d];
         if (ent != -1) put(pd, ent);
       }
+    }
+    for (int q = 0; q < 4; q++) {
+      int32_t* pg = rec + 16 + 4 * q;
+      pg[0] = -3;
+      if (P->bf_off[e] + q < P->bf_off[e + 1]) put(pg, P->bf_ent[P->bf_off[e] + q]);
     }
     for (int32_t j = P->bf_off[e]; j < P->bf_off[e + 1]; j++) put(bf_rec + 4 * static_cast<size_t>(first++), P->bf_ent[j]);
   }

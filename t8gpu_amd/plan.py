@@ -106,11 +106,11 @@ class HostSubgridPlan:
         lib.t8gpu_plan_subgrid_arrays(h, p(self.bf_off), p(self.bf_ent), p(self.face_rec), p(self.plus))
 
     def records(self, areas, float_size):
-        """The joined records the kernels read: block_rec [N, 16], bf_rec [n_entries, 4] (int32 words)."""
+        """The joined records the kernels read: block_rec [N, 32], bf_rec [n_entries, 4] (int32 words)."""
         lib = _synth.lib()
         lib.t8gpu_plan_subgrid_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         ar = np.ascontiguousarray(areas, np.float64)
-        block_rec = np.zeros((max(1, self.N), 16), np.int32)
+        block_rec = np.zeros((max(1, self.N), 32), np.int32)
         bf_rec = np.zeros((max(1, self.n_entries), 4), np.int32)
         lib.t8gpu_plan_subgrid_records(self._h, _synth._p(ar), int(float_size), _synth._p(block_rec), _synth._p(bf_rec))
         return block_rec, bf_rec
