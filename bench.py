@@ -49,8 +49,8 @@ WORKLOADS = {
                 desc="3D tetrahedra + hexahedra on a curved shell, 96x96x128 cells in 2x2x2 blocks of either kind (~4.13 M elements), geometry-synthetic"),
     # c5a = BASELINE config 5's LOOP: adapt (+ repartition over the ranks) every 20 steps INSIDE the measured region,
     # on a 3D hexahedral forest refined by the reference's gradient indicator (handled by bench_adaptive below)
-    "c5a": dict(kind="plain", dim=3, adaptive=dict(every=20, min_level=5, max_level=8, threshold=10.0), dtype="f64",
-                desc="3D hex AMR levels 5-8 by the reference's indicator, adapt + repartition every 20 steps inside the timed loop"),
+    "c5a": dict(kind="plain", dim=3, adaptive=dict(every=20, min_level=5, max_level=9, threshold=10.0), dtype="f64",
+                desc="3D hex AMR levels 5-9 by the reference's indicator, adapt + repartition every 20 steps inside the timed loop"),
 }
 
 

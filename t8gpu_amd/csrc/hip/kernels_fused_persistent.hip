@@ -118,9 +118,9 @@ struct TileDesc {
   int e0, ne, h0, nh, f0, nf;
 };
 
-// (second launch bound = waves per SIMD the register allocation must allow: 3 workgroups per CU in fp64, 4 in fp32)
+// (second launch bound = waves per SIMD the register allocation must allow: 3 workgroups per CU in fp64, 5 in fp32)
 template <class T, int KIND, int STAGE>
-__global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 4) void k_plain_persistent(T8gpuPlainPlan P, int tile_begin, int tile_count, FVars<T> prev,
+__global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_persistent(T8gpuPlainPlan P, int tile_begin, int tile_count, FVars<T> prev,
                                                           FVars<T> src, FVars<T> out, const T* __restrict__ vol, T dt,
                                                           T* __restrict__ speed) {
   constexpr int NW  = KIND == 0 ? kPrimWords : 5;
@@ -398,19 +398,27 @@ int plain_persistent_stage(int kind, int stage, const T8gpuPlainPlan* plan, int 
   const int    rec = sizeof(T) == 8 ? (nw > 5 ? 10 : 6) : 12;
   const size_t lds = sizeof(T) * (static_cast<size_t>(5) * 512 + static_cast<size_t>(12) * plan->n_geo + static_cast<size_t>(rec) * slots);
   if (lds > 64 * 1024) return -1;
-  // persistent grid: enough workgroups to fill the chip at the occupancy the kernel reaches (3 per CU), never more
-  // than there are tiles. T8GPU_PERSISTENT_WGS overrides the per-CU count (tuning).
-  static int per_cu = 0, cus = 0;
+  // persistent grid: enough workgroups to fill the chip at the occupancy the kernel reaches, never more than there are
+  // tiles. T8GPU_PERSISTENT_WGS overrides the per-CU count (tuning).
+  static int per_cu_env = 0, cus = 0;
   if (cus == 0) {
     int            dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
     cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const char* env = std::getenv("T8GPU_PERSISTENT_WGS");
-    per_cu = env ? std::atoi(env) : 3;
-    if (per_cu < 1 || per_cu > 8) per_cu = 3;
+    per_cu_env = env ? std::atoi(env) : 0;
+    if (per_cu_env < 0 || per_cu_env > 8) per_cu_env = 0;
   }
-  const int  grid_size = tile_count < cus * per_cu ? tile_count : cus * per_cu;
+  // resident workgroups per CU: fp64 166 VGPRs -> 3 waves per SIMD; fp32 ~100 VGPRs and half the LDS -> 5
+  const int per_cu = per_cu_env > 0 ? per_cu_env : (sizeof(T) == 8 ? 3 : 5);
+  // Worth it when a workgroup walks many tiles (c4: 55) or when there is at most one tile per resident workgroup anyway
+  // (then this kernel is simply the cheaper one-tile kernel). In between (c2: 4.4 k tiles, < 6 per workgroup) the
+  // exposed first tile of every workgroup and the ragged last round cost more than the pipelining saves: measured
+  // 0.047 vs 0.044 ms per stage, so those launches go back to the one-tile kernel.
+  const int resident = cus * per_cu;
+  if (per_cu_env == 0 && tile_count > resident && tile_count < 8 * resident) return -1;
+  const int  grid_size = tile_count < resident ? tile_count : resident;
   const dim3 grid(grid_size), block(256);
 #define T8_P(K, S) hipLaunchKernelGGL((k_plain_persistent<T, K, S>), grid, block, lds, stream, *plan, tile_begin, tile_count, prev, mid, out, volume, dt, speed)
 #define T8_PS(K)             \
