@@ -342,7 +342,13 @@ T8_DEV double t8_div(double a, double b) {
 // is the classic reduction x = m 2^e, m in [sqrt(1/2), sqrt(2)), log m = 2 atanh(s), s = (m-1)/(m+1), with
 // the degree-7 minimax polynomial in s^2 of Sun's fdlibm e_log.c (error < 1 ulp; pinned against the
 // host libm in tests/test_gpu_fastmath.py): ~35 instructions.
-T8_DEV float  t8_log_fast(float x) { return logf(x); }
+// fp32: the hardware log2 (v_log_f32, ~1 ulp) times ln 2 in two pieces instead of the library logf (which wraps the same
+// instruction in scaling for denormals and a correction sequence: ~10 instructions, and a cell needs two logs, a face two
+// more). Inputs here are densities, pressures and their ratios: O(1), never denormal (pinned in tests/test_gpu_fastmath.py).
+T8_DEV float  t8_log_fast(float x) {
+  const float l2 = __builtin_amdgcn_logf(x);
+  return __builtin_fmaf(l2, 9.0580015e-06f, l2 * 6.9313812256e-01f);   // ln 2 = 0.69313812 + 9.0580015e-06 (fdlibm's split)
+}
 T8_DEV double t8_log_fast(double x) {
 #pragma clang fp contract(off)
   double     m  = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
@@ -409,7 +415,7 @@ T8_DEV float ln_mean_dlog(float aL, float aR, float /*dlog*/) {
   const float u = f * f;
   const bool  small = u < 1.0e-4f;
   const float num = small ? s * 52.50f : d;
-  const float den = small ? t8_fma(u, t8_fma(u, t8_fma(u, 15.0f, 21.0f), 35.0f), 105.0f) : logf(t8_div(aR, aL));
+  const float den = small ? t8_fma(u, t8_fma(u, t8_fma(u, 15.0f, 21.0f), 35.0f), 105.0f) : t8_log_fast(t8_div(aR, aL));
   return t8_div(num, den);
 }
 

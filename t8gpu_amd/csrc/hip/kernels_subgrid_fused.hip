@@ -79,6 +79,12 @@ struct CellData {  // what a flux evaluation needs from one cell: primitives (KE
 template <class T, int KIND>
 T8_DEV CellData<T, KIND> cell_from_state(const T s[5]) {
   CellData<T, KIND> c;
+#ifdef T8GPU_EXP_NOMATH   // experiment builds only: loads, LDS traffic, barriers and stores as in the product, no arithmetic
+  if (KIND == 0) {
+    c.v[0] = s[0]; c.v[1] = s[1]; c.v[2] = s[2]; c.v[3] = s[3]; c.v[4] = s[4]; c.v[5] = s[0]; c.v[6] = s[1]; c.v[7] = s[2]; c.v[8] = s[3];
+    return c;
+  }
+#endif
   if (KIND == 0) {
     const Prim<T> q = prim_from_state<T>(s);
     c.v[0] = q.rho; c.v[1] = q.vx; c.v[2] = q.vy; c.v[3] = q.vz; c.v[4] = q.p;
@@ -93,6 +99,13 @@ T8_DEV CellData<T, KIND> cell_from_state(const T s[5]) {
 // area-scaled xyz flux from L to R through a face with unit normal n
 template <class T, int KIND>
 T8_DEV void cell_flux(const CellData<T, KIND>& L, const CellData<T, KIND>& R, bool wall, int axis, bool positive, T area, T g[5]) {
+#ifdef T8GPU_EXP_NOMATH
+  if (KIND == 0) {
+    g[0] = L.v[0] + R.v[0] + area; g[1] = L.v[1] + R.v[1] + L.v[5]; g[2] = L.v[2] + R.v[2] + R.v[6]; g[3] = L.v[3] + R.v[3] + L.v[7];
+    g[4] = L.v[4] + R.v[4] + R.v[8] + T(axis + (wall ? 1 : 0) + (positive ? 2 : 0));
+    return;
+  }
+#endif
   if (KIND == 0) {
     T spd;
     Prim<T> a, b;
@@ -208,7 +221,12 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
   const int    base = (c / S) * S, cl = c - base;
   // RANK 3: the block index is wave-uniform -- say so explicitly (blockIdx arithmetic only), so that the
   // per-block loads (volume, face lists, face records) stay scalar loads and their branches scalar branches
+#ifdef T8GPU_EXP_TILEMOD   // experiment builds only: every wavefront works on one of the first few blocks (no HBM traffic)
+  const int    pos  = RANK == 3 ? sg_xcd_position(blockIdx.x, gridDim.x) % T8GPU_EXP_TILEMOD
+                                : (sg_xcd_position(blockIdx.x, gridDim.x) % T8GPU_EXP_TILEMOD) * BPW + c / S;
+#else
   const int    pos  = RANK == 3 ? sg_xcd_position(blockIdx.x, gridDim.x) : sg_xcd_position(blockIdx.x, gridDim.x) * BPW + c / S;
+#endif
   const bool   live = pos < block_count;
   // ONE dependent level: the block's joined record (64 bytes; four scalar loads for RANK 3) names the block, its
   // generic face list and the far block, code and area of its three + faces
