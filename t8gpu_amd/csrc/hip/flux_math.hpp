@@ -12,6 +12,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "log_table.hpp"
+
 namespace t8gpu_hip {
 
 #define T8_DEV __device__ __forceinline__
@@ -368,14 +370,36 @@ T8_DEV double t8_log_fast(double x) {
   return __builtin_fma(dk, 6.93147180369123816490e-01, -((hfsq - __builtin_fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f));
 }
 
+// Table-driven fp64 logarithm for the plain tile kernels (x > 0, normal range): x = m 2^e with m in [1, 2); the top 7
+// mantissa bits pick an interval whose midpoint c has rc = 1/c and lc = -log(rc) tabulated (log_table.hpp: 128 x 16 B);
+// r = m rc - 1 is exact to an FMA and |r| < 2^-8, so log1p(r) needs a degree-7 Taylor polynomial, and
+// log x = e ln2 + lc + log1p(r). ~14 DP instructions and one 16-byte table read instead of the ~35 DP instructions of
+// t8_log_fast (one division, a degree-7 polynomial in s^2): a cell needs two logarithms, which were 3/4 of its
+// per-element work. `tab` points at a copy of kLogTab in LDS (the tile kernels copy it once per workgroup).
+// Accuracy ~1 ulp, pinned against the host libm in tests/test_gpu_fastmath.py.
+T8_DEV double t8_log_tab(double x, const double* __restrict__ tab) {
+#pragma clang fp contract(off)
+  const double m  = __builtin_amdgcn_frexp_mant(x) * 2.0;              // [1, 2)
+  const int    e  = __builtin_amdgcn_frexp_exp(x) - 1;
+  const int    i  = (__double2hiint(m) >> 13) & 127;                    // top 7 bits of the mantissa
+  const double2 t = reinterpret_cast<const double2*>(tab)[i];           // {rc, lc}
+  const double r  = __builtin_fma(m, t.x, -1.0);
+  const double q  = __builtin_fma(r, __builtin_fma(r, __builtin_fma(r, __builtin_fma(r, __builtin_fma(r, __builtin_fma(r,
+                        1.0 / 7.0, -1.0 / 6.0), 0.2), -0.25), 1.0 / 3.0), -0.5), 1.0);
+  const double dk = static_cast<double>(e);
+  return __builtin_fma(dk, 6.93147180369123816490e-01, __builtin_fma(dk, 1.90821492927058770002e-10, __builtin_fma(r, q, t.y)));
+}
+T8_DEV float t8_log_tab(float x, const double*) { return t8_log_fast(x); }
+
 template <class T>
 struct Prim {
   T rho, vx, vy, vz, p, beta, lrho, lbeta, v0;
 };
 constexpr int kPrimWords = 9;
 
-template <class T>
-T8_DEV Prim<T> prim_from_state(const T s[5]) {
+// logtab: LDS copy of kLogTab (plain tile kernels in fp64: table-driven logarithms), or null (polynomial logarithm)
+template <class T, bool TAB = false>
+T8_DEV Prim<T> prim_from_state(const T s[5], const double* logtab = nullptr) {
 #pragma clang fp contract(off)
   const T one = T(1), half = T(0.5), kappa = T(1.4);
   const T km1 = kappa - one;
@@ -389,8 +413,8 @@ T8_DEV Prim<T> prim_from_state(const T s[5]) {
   q.p        = km1 * t8_fma(-s[0], ke, s[4]);
   const T rp = t8_div(s[0], q.p);
   q.beta     = half * rp;
-  q.lrho     = t8_log_fast(s[0]);
-  const T lp = t8_log_fast(q.p);
+  q.lrho     = TAB ? t8_log_tab(s[0], logtab) : t8_log_fast(s[0]);
+  const T lp = TAB ? t8_log_tab(q.p, logtab) : t8_log_fast(q.p);
   q.lbeta    = q.lrho - lp;
   q.v0       = t8_fma(-rp, ke, (kappa - t8_fma(-kappa, q.lrho, lp)) * (one / km1));
   return q;

@@ -29,6 +29,12 @@ __global__ __launch_bounds__(256) void k_plain_fused(T8gpuPlainPlan P, int tile_
   const int     LF  = P.max_faces;
   T* const      pe  = lds;                         // [NW][LE]
   T* const      ff  = lds + (size_t)NW * LE;       // [5][LF]
+  constexpr bool kTab = sizeof(T) == 8 && KIND == 0;   // fp64 KEPES: table-driven logarithms (flux_math.hpp: t8_log_tab)
+  double* const lt  = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(ff + (size_t)5 * LF) + 15) & ~uintptr_t(15));   // 16-byte rows
+  if (kTab) {
+    lt[threadIdx.x] = kLogTab[threadIdx.x];
+    __syncthreads();
+  }
 
   const int tile = P.tile_order[tile_begin + xcd_position(blockIdx.x, gridDim.x)];
   const int e0 = P.elem_off[tile], ne = P.elem_off[tile + 1] - e0;
@@ -43,7 +49,7 @@ __global__ __launch_bounds__(256) void k_plain_fused(T8gpuPlainPlan P, int tile_
 #pragma unroll
     for (int k = 0; k < 5; k++) s[k] = src.p[k][slot];
     if (KIND == 0) {
-      const Prim<T> q = prim_from_state<T>(s);
+      const Prim<T> q = prim_from_state<T, kTab>(s, lt);
       pe[0 * LE + i]  = q.rho;
       pe[1 * LE + i]  = q.vx;
       pe[2 * LE + i]  = q.vy;
@@ -149,12 +155,12 @@ T8_DEV bool ell_accumulate(uint4 w, int pass, const T* __restrict__ ff, T acc[5]
 }
 
 template <class T>
-T8_DEV void store_prim(T* pe, int LE, int i, const T s[5]) {
+T8_DEV void store_prim(T* pe, int LE, int i, const T s[5], const double* logtab) {
 #ifdef T8GPU_EXP_NOMATH    // experiment builds only: same loads, LDS traffic, barriers and stores, (almost) no arithmetic
   Prim<T> q;
   q.rho = s[0]; q.vx = s[1]; q.vy = s[2]; q.vz = s[3]; q.p = s[4]; q.beta = s[0]; q.lrho = s[1]; q.lbeta = s[2]; q.v0 = s[3];
 #else
-  const Prim<T> q = prim_from_state<T>(s);
+  const Prim<T> q = prim_from_state<T, sizeof(T) == 8>(s, logtab);
 #endif
   pe[0 * LE + i] = q.rho;
   pe[1 * LE + i] = q.vx;
@@ -191,6 +197,8 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
   const int     LE  = P.max_slots > 0 ? P.max_slots : P.max_elems + P.max_halo;
   T* const      pe  = lds;
   T* const      ff  = lds + (size_t)NW * LE;  // [5][256]: one pass of 256 faces at a time
+  constexpr bool kTab = sizeof(T) == 8 && KIND == 0;   // fp64 KEPES: table-driven logarithms, table behind the flux buffer
+  double* const lt  = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(ff + 5 * 256) + 15) & ~uintptr_t(15));   // 16-byte rows
 
 #ifdef T8GPU_EXP_TILEMOD   // experiment builds only (build.py variants): every workgroup works on one of the first few tiles,
                            // so all traffic stays in the caches -- what remains is the kernel's instruction time
@@ -244,13 +252,17 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
   const uint4 ell0 = ellrow[0];
 
   // ---- phase 1 -----------------------------------------------------------------------------------
+  if (kTab) {   // (requested with the loads above; the barrier costs one per tile -- the persistent kernel pays it once)
+    lt[tid] = kLogTab[tid];
+    __syncthreads();
+  }
   if (SCATTER) {
 #pragma unroll
     for (int k = 0; k < 5; k++) ff[k * 256 + tid] = T(0);
   }
   if (a0) {
     if (KIND == 0) {
-      store_prim<T>(pe, LE, tid, s0);
+      store_prim<T>(pe, LE, tid, s0, lt);
     } else {
 #pragma unroll
       for (int k = 0; k < 5; k++) pe[k * LE + tid] = s0[k];
@@ -258,7 +270,7 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
   }
   if (a1) {
     if (KIND == 0) {
-      store_prim<T>(pe, LE, i1, s1);
+      store_prim<T>(pe, LE, i1, s1, lt);
     } else {
 #pragma unroll
       for (int k = 0; k < 5; k++) pe[k * LE + i1] = s1[k];
@@ -396,7 +408,8 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
                                              dt, speed, s);
     if (rc >= 0) return rc;
   }
-  size_t lds = sizeof(T) * ((size_t)nw * slots + (size_t)5 * (pipelined ? 256 : plan->max_faces));
+  size_t lds = sizeof(T) * ((size_t)nw * slots + (size_t)5 * (pipelined ? 256 : plan->max_faces)) +
+               ((sizeof(T) == 8 && kind == 0) ? 2 * kLogTabEntries * sizeof(double) + 16 : 0);
 #ifdef T8GPU_EXP_LDS_PAD   // experiment builds only: fewer workgroups per CU, to measure how much the kernel leans on occupancy
   if (const char* pad = std::getenv("T8GPU_EXP_LDS_PAD")) lds += static_cast<size_t>(std::atoi(pad));
 #endif

@@ -83,12 +83,12 @@ T8_DEV void rec_load(const T* rec, T* w) {
 }
 
 template <class T>
-T8_DEV void prim_words(const T s[5], T w[kPrimWords]) {
+T8_DEV void prim_words(const T s[5], T w[kPrimWords], const double* logtab) {
 #ifdef T8GPU_EXP_NOMATH    // experiment builds only: same loads, LDS traffic, barriers and stores, (almost) no arithmetic
   Prim<T> q;
   q.rho = s[0]; q.vx = s[1]; q.vy = s[2]; q.vz = s[3]; q.p = s[4]; q.beta = s[0]; q.lrho = s[1]; q.lbeta = s[2]; q.v0 = s[3];
 #else
-  const Prim<T> q = prim_from_state<T>(s);
+  const Prim<T> q = prim_from_state<T, sizeof(T) == 8>(s, logtab);   // fp64: table-driven logarithms (flux_math.hpp)
 #endif
   w[0] = q.rho; w[1] = q.vx; w[2] = q.vy; w[3] = q.vz; w[4] = q.p; w[5] = q.beta; w[6] = q.lrho; w[7] = q.lbeta; w[8] = q.v0;
 }
@@ -130,6 +130,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_persisten
   T* const  ff = reinterpret_cast<T*>(lds_raw);                       // [5][512] the tile's face fluxes
   V4* const gt = reinterpret_cast<V4*>(ff + 5 * 512);                 // [n_geo][3] {n, area} {t1, .} {t2, .}
   T* const  pe = reinterpret_cast<T*>(gt + 3 * P.n_geo);              // [max_slots][REC] primitives (or states) per slot
+  constexpr bool kTab = sizeof(T) == 8 && KIND == 0;                  // fp64 KEPES: the logarithm table, behind the records
+  double* const lt = reinterpret_cast<double*>(pe + static_cast<size_t>(REC) * P.max_slots);
   const int tid = threadIdx.x;
 
   // This workgroup's tiles. Workgroups b, b + 8, ... share an XCD (and its L2): XCD x gets one contiguous eighth of
@@ -146,6 +148,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_persisten
   if (xcd >= nxcd || t >= tend) return;
 
   for (int i = tid; i < 3 * P.n_geo; i += 256) gt[i] = reinterpret_cast<const V4*>(P.geo_table)[i];   // visible after the first barrier
+  if (kTab) {
+    lt[tid] = kLogTab[tid];   // 2 x 128 doubles, one per lane; phase 1 of the first tile reads it: barrier below
+    __syncthreads();
+  }
 
   // Tile descriptors: one 32-byte record per tile (plan.tile_desc, in execution order), read two tiles ahead. The
   // plan is read-only for the kernel's lifetime, so the record is read through the constant address space: a scalar
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_persisten
     if (a0) {
       T w[NW];
       if (KIND == 0) {
-        prim_words<T>(cur.s0, w);
+        prim_words<T>(cur.s0, w, lt);
       } else {
 #pragma unroll
         for (int k = 0; k < 5; k++) w[k] = cur.s0[k];
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_persisten
     if (a1) {
       T w[NW];
       if (KIND == 0) {
-        prim_words<T>(cur.s1, w);
+        prim_words<T>(cur.s1, w, lt);
       } else {
 #pragma unroll
         for (int k = 0; k < 5; k++) w[k] = cur.s1[k];
@@ -396,7 +402,8 @@ int plain_persistent_stage(int kind, int stage, const T8gpuPlainPlan* plan, int 
     return -1;
   const int    nw  = kind == 0 ? kPrimWords : 5;
   const int    rec = sizeof(T) == 8 ? (nw > 5 ? 10 : 6) : 12;
-  const size_t lds = sizeof(T) * (static_cast<size_t>(5) * 512 + static_cast<size_t>(12) * plan->n_geo + static_cast<size_t>(rec) * slots);
+  const size_t lds = sizeof(T) * (static_cast<size_t>(5) * 512 + static_cast<size_t>(12) * plan->n_geo + static_cast<size_t>(rec) * slots) +
+                     ((sizeof(T) == 8 && kind == 0) ? 2 * kLogTabEntries * sizeof(double) : 0);
   if (lds > 64 * 1024) return -1;
   // persistent grid: enough workgroups to fill the chip at the occupancy the kernel reaches, never more than there are
   // tiles. T8GPU_PERSISTENT_WGS overrides the per-CU count (tuning).

@@ -209,6 +209,7 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
 #pragma omp parallel
   {
     std::vector<int32_t> tf, halo, order, where;
+    std::vector<uint8_t> codes;
 #pragma omp for schedule(static)
     for (int32_t t = 0; t < ntiles; t++) {
       const int32_t e0 = P.elem_off[t], e1 = P.elem_off[t + 1], ne = e1 - e0;
@@ -224,12 +225,14 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
       const size_t nft = tf.size();
       order.resize(nft);
       where.resize(nft);
-      for (size_t j = 0; j < nft; j++) order[j] = static_cast<int32_t>(j);
+      codes.resize(nft);
+      for (size_t j = 0; j < nft; j++) {
+        order[j] = static_cast<int32_t>(j);
+        codes[j] = static_cast<uint8_t>(direction_code(normals + static_cast<size_t>(P.ndim) * tf[j], P.ndim));
+      }
       for (size_t b = 0; b < nft; b += 256)
-        std::stable_sort(order.begin() + b, order.begin() + std::min(nft, b + 256), [&](int32_t x, int32_t y) {
-          return direction_code(normals + static_cast<size_t>(P.ndim) * tf[x], P.ndim) <
-                 direction_code(normals + static_cast<size_t>(P.ndim) * tf[y], P.ndim);
-        });
+        std::stable_sort(order.begin() + b, order.begin() + std::min(nft, b + 256),
+                         [&](int32_t x, int32_t y) { return codes[x] < codes[y]; });
       for (size_t j = 0; j < nft; j++) where[order[j]] = static_cast<int32_t>(j);
       size_t q = P.face_off[t];
       for (size_t jj = 0; jj < nft; jj++) {
@@ -285,10 +288,13 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
   int32_t maxdeg = 0;
   for (int32_t e = 0; e < N; e++) maxdeg = std::max(maxdeg, P.csr_off[e + 1] - P.csr_off[e]);
   P.ell_width = std::max(8, (maxdeg + 7) / 8 * 8);
-  P.ell.assign(static_cast<size_t>(N) * P.ell_width, 0xFFFFu);
-  for (int32_t e = 0; e < N; e++)
-    for (int32_t c = P.csr_off[e]; c < P.csr_off[e + 1]; c++)
-      P.ell[static_cast<size_t>(e) * P.ell_width + (c - P.csr_off[e])] = P.csr_ent[c];
+  P.ell.resize(static_cast<size_t>(N) * P.ell_width);
+#pragma omp parallel for schedule(static)
+  for (int32_t e = 0; e < N; e++) {
+    uint16_t*     row = &P.ell[static_cast<size_t>(e) * P.ell_width];
+    const int32_t n   = P.csr_off[e + 1] - P.csr_off[e];
+    for (int32_t c = 0; c < P.ell_width; c++) row[c] = c < n ? P.csr_ent[P.csr_off[e] + c] : static_cast<uint16_t>(0xFFFFu);
+  }
 
   lap("ELL rows");
   // dictionary of distinct {nx, ny, nz, area} tuples (exact bit patterns): Cartesian AMR meshes have a

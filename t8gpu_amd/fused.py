@@ -33,7 +33,8 @@ class PlainPlan:
         # own + halo element and two passes of 512 faces (-5 ... -7 %: fewer instructions, but 8 waves per barrier
         # and 2 workgroups per CU), so 512 stays the default for every mesh.
         fcap = int(os.environ.get("T8GPU_FCAP", 512)) if fcap is None else fcap
-        self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap)
+        # the per-face geometry rows are only read by the kernels without a dictionary (generic kernel, dictionary=False)
+        self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary))
         self.dtype = dtype
         self._keep = {}
         c = T8gpuPlainPlan()
@@ -41,6 +42,8 @@ class PlainPlan:
         # the pipelined kernel with a geometry dictionary never reads the per-face rows (32 B per face: 700 MB at c4)
         skip_geo = (compressed and dictionary and h.geo_table.shape[0] > 0 and h.max_elems <= 256 and h.max_slots <= 512
                     and h.max_faces <= 1024)
+        if not skip_geo and h.face_geo.shape[0] == 0 and h.face_lr.size:     # the kernels this plan gets do read the rows
+            self.host = h = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=True)
         for name in HostPlainPlan.FIELDS:
             a = getattr(self.host, name)
             if name == "face_geo":

@@ -29,7 +29,9 @@ class HostPlainPlan:
     FIELDS = ("elem_off", "halo_off", "face_off", "halo_ids", "face_lr", "face_geo", "face_orig", "csr_off",
               "csr_ent", "tile_order")
 
-    def __init__(self, N, G, F, B, ndim, face_neighbors, normals, areas, tmax=256, fcap=512):
+    def __init__(self, N, G, F, B, ndim, face_neighbors, normals, areas, tmax=256, fcap=512, want_face_geo=True):
+        """want_face_geo=False: leave `face_geo` (32 bytes per tile face, only read by the kernels that have no geometry
+        dictionary) empty when the plan has a dictionary -- at c4 size that is 700 MB of host copying per plan."""
         lib = _lib()
         fn = np.ascontiguousarray(face_neighbors, np.int32)
         nr = np.ascontiguousarray(normals, np.float64)
@@ -50,12 +52,13 @@ class HostPlainPlan:
             self.face_off = np.zeros(self.ntiles + 1, np.int32)
             self.halo_ids = np.zeros(n_halo, np.int32)
             self.face_lr = np.zeros(n_faces, np.uint32)
-            self.face_geo = np.zeros((n_faces, 4), np.float64)
+            n_geo_rows = int(sz[11])
+            self.face_geo = np.zeros((0 if (n_geo_rows and not want_face_geo) else n_faces, 4), np.float64)
             self.face_orig = np.zeros(n_faces, np.int32)
             self.csr_off = np.zeros(N + 1, np.int32)
             self.csr_ent = np.zeros(n_csr, np.uint16)
             self.tile_order = np.zeros(self.ntiles, np.int32)
-            lib.t8gpu_plan_plain_arrays(h, *(p(getattr(self, f)) for f in self.FIELDS))
+            lib.t8gpu_plan_plain_arrays(h, *(p(getattr(self, f)) if getattr(self, f).size else None for f in self.FIELDS))
             self.ell_width, n_geo, self.max_slots, self.n_deep = int(sz[10]), int(sz[11]), int(sz[12]), int(sz[13])
             self.ell = np.zeros((N, self.ell_width), np.uint16)
             self.geo_idx = np.zeros(n_faces if n_geo else 0, np.uint16)

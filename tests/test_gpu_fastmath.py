@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-RCP, DIV, SQRT, LOG, LN_MEAN, LN_MEAN_REF = range(6)
+RCP, DIV, SQRT, LOG, LN_MEAN, LN_MEAN_REF, LOG_TAB = range(7)
 
 
 def probe(op, a, b=None):
@@ -40,14 +40,15 @@ def test_division_sqrt_within_ulps(dtype, limit):
     assert ulps(probe(SQRT, b), np.sqrt(b.astype(np.longdouble)).astype(dtype)).max() <= limit
 
 
-@pytest.mark.parametrize("dtype,k", [(np.float64, 1.5), (np.float32, 4.0)])   # fp32: hardware log2 x ln 2 (two-piece)
-def test_log_matches_libm(dtype, k):
+@pytest.mark.parametrize("dtype,k,op", [(np.float64, 1.5, LOG), (np.float32, 4.0, LOG),   # fp32: hardware log2 x ln 2
+                                        (np.float64, 2.0, LOG_TAB)])   # fp64 in the plain tile kernels: 128-entry table
+def test_log_matches_libm(dtype, k, op):
     rng = np.random.default_rng(4)
     span = 40 if dtype == np.float64 else 20      # (fp32: the range of densities / pressures / ratios with a wide margin)
     x = np.concatenate([np.exp(rng.uniform(-span, span, 300000)), rng.uniform(0.5, 2.0, 300000),
                         1.0 + rng.uniform(-1e-6, 1e-6, 1000), [1.0, 0.5, 2.0, np.sqrt(0.5), np.sqrt(2.0)]]).astype(dtype)
     want = np.log(x.astype(np.longdouble))
-    got = probe(LOG, x).astype(np.longdouble)
+    got = probe(op, x).astype(np.longdouble)
     # relative to max(|log x|, ulp-scale of the argument error): 1 ulp of the result, or 1 ulp of x near x = 1
     tol = k * np.maximum(np.spacing(np.abs(want).astype(dtype)).astype(np.longdouble), np.finfo(dtype).eps / 2)
     assert (np.abs(got - want) <= tol).all(), float((np.abs(got - want) / tol).max())
