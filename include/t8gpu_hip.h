@@ -255,10 +255,11 @@ typedef struct T8gpuSubgridPlan {
   /* joined records, t8gpu_plan_subgrid_records(): one dependent load level between a wavefront's position
    * and all of its far-cell loads */
   const int32_t* block_rec;     /* [num_elements][32], blocks that touch no ghost block first: {block, n generic
-                                   faces, first bf_rec entry, 0, 3 x {other block, code, area (2 words)}, copies of the
-                                   block's first 4 bf_rec rows (other = -3: none)} (128-byte rows) */
-  const int32_t* bf_rec;        /* [n_entries][4] generic faces in the same order: {other block (-1 wall), code
-                                   (bit 12: the block is the face's RIGHT side), area (2 words)}; walls first */
+                                   faces, first bf_rec entry, 0, 3 x the +d face {other block (-1 wall, -2 none / in
+                                   the generic list), code, area (2 words)}, 3 x the -d face likewise, 4 spare words}
+                                   (128-byte rows) */
+  const int32_t* bf_rec;        /* [n_entries][4] generic faces (towards finer blocks) in the same order: {other block,
+                                   code (bit 12: the block is the face's RIGHT side), area (2 words)} */
   int32_t num_elements, rank, max_faces_per_block, n_interior_blocks;
   int32_t n_deep_blocks;        /* leading blocks that have no neighbour touching a ghost block (0: unknown) */
   int32_t reserved;

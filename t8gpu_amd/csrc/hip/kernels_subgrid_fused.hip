@@ -13,10 +13,13 @@
 //      < 3 have their + neighbour in the block, lanes with coordinate 3 sit on the block surface and read
 //      the far cell's primitives from the appended part, so these passes run with all 64 lanes busy and
 //      no divergence (the wave exchanges the flux through LDS: -own, +lower);
-//   3. the block's remaining coarse faces (-d sides, and faces towards finer blocks: 4 sub-faces per
-//      cell), four at a time: lane = (face slot, sub-face), far cell gathered through the 2:1 hanging
-//      map of kernels.inl:752-758, sub-face fluxes to LDS, every cell picks up the ones that end on it;
-//   4. RK stage on the accumulated flux, coalesced store.
+//   3. - faces (same level, coarser neighbour or wall): ONE pass for the three of them, lane = side * 16 +
+//      sub-face (lanes 0..47), far cell fetched up front like those of the + faces, fluxes to LDS, the
+//      cells with coordinate 0 pick theirs up;
+//   4. the faces towards finer blocks (4 sub-faces per cell), four at a time from the block's face list:
+//      lane = (face slot, sub-face), far cell gathered through the 2:1 hanging map of kernels.inl:752-758,
+//      sub-face fluxes to LDS, every cell picks up the ones that end on it;
+//   5. RK stage on the accumulated flux, coalesced store.
 // An outer sub-face is evaluated by both blocks that share it, both in the GEOMETRIC orientation (left =
 // the block on the low side, normal +e_d; walls: left = the block, outward normal) rather than the one the
 // face list happens to store: same arguments, same result, no operand swapping in the + passes, and the
@@ -86,7 +89,11 @@ T8_DEV CellData<T, KIND> cell_from_state(const T s[5]) {
   }
 #endif
   if (KIND == 0) {
+#ifdef T8GPU_EXP_SG_LOGTAB   // experiment builds: table-driven fp64 log, table read from global memory
+    const Prim<T> q = prim_from_state<T, true>(s, kLogTab);
+#else
     const Prim<T> q = prim_from_state<T>(s);
+#endif
     c.v[0] = q.rho; c.v[1] = q.vx; c.v[2] = q.vy; c.v[3] = q.vz; c.v[4] = q.p;
     c.v[5] = q.beta; c.v[6] = q.lrho; c.v[7] = q.lbeta; c.v[8] = q.v0;
   } else {
@@ -170,36 +177,36 @@ T8_DEV FaceLane<T> load_face_lane(const T8gpuSubgridPlan& P, const SVars<T>& src
 template <class T>
 struct PlusFace {
   bool on, right, wall;   // on: listed as ONE coarse face (faces towards finer blocks are in the generic list)
-  int  lblock, rblock, code;
+  int  other, code;   // other: the block on the far side, whichever side that is
   T    area;
 };
 template <class T>
 T8_DEV PlusFace<T> plus_face(int4 w, bool live) {   // w = the four words of the block record for this face
   PlusFace<T> f;
   f.on = f.right = f.wall = false;
-  f.lblock = f.rblock = f.code = 0;
+  f.other = f.code = 0;
   f.area = T(0);
   if (live && w.x != -2) {
     f.on     = true;
     f.code   = w.y;
     f.right  = (w.y >> 12) & 1;
     f.wall   = w.x == -1;
-    f.lblock = f.rblock = w.x;   // the block on the far side, whichever side that is
+    f.other  = w.x;
     f.area   = area_of(w.z, w.w, T(0));
   }
   return f;
 }
 // state of the far cell behind sub-face (ti, tj) of that face: in the left block on its face plane, or in
-// the right block at the stored anchor (kernels.inl:710-758)
+// the right block at the stored anchor (kernels.inl:710-758); a wall face reads cell `wall_cell` (pass -1: nothing)
 template <class T, int S>
-T8_DEV void load_plus_far(const SVars<T>& src, bool on, bool right, bool wall, int lblock, int rblock, int code, int ti, int tj,
-                          T sf[5]) {
+T8_DEV void load_far(const SVars<T>& src, bool on, bool right, bool wall, int other, int code, int ti, int tj, ptrdiff_t wall_cell,
+                     T sf[5]) {
 #pragma unroll
   for (int k = 0; k < 5; k++) sf[k] = T(1);
-  if (on && !wall) {
+  if (on && !(wall && wall_cell < 0)) {
     const FaceCode fc    = decode(code);
     const int      fcell = right ? left_cell(fc, ti, tj) : right_cell(fc, ti, tj);
-    const size_t   far   = (size_t)(right ? lblock : rblock) * S + fcell;
+    const size_t   far   = wall ? (size_t)wall_cell : (size_t)other * S + fcell;
 #pragma unroll
     for (int k = 0; k < 5; k++) sf[k] = src.p[k][far];
   }
@@ -245,18 +252,17 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
   const T   edge    = (RANK == 3 ? t8_cbrt(vol) : t8_sqrt(vol)) / T(4);
   const T   surface = RANK == 3 ? edge * edge : edge;
   int       npass   = nbf;  // generic passes run until the busiest block of the wave is done
+#ifdef T8GPU_EXP_NOGENERIC   // experiment builds only (wrong results): no generic passes / no far cells of the + faces
+  npass = 0;
+#endif
   if (RANK == 2) {
     npass = max(npass, __shfl_xor(npass, 16, 64));
     npass = max(npass, __shfl_xor(npass, 32, 64));
   }
 
-  // the far cells of the + faces and the first generic pass are fetched NOW, so that their dependent
-  // loads (face list -> face record -> far cell) overlap the arithmetic
-  // (the record carries copies of the first four generic rows -- other = -3: none --, so their far cells are requested
-  //  together with everything else instead of one round trip later: record -> bf_rec rows -> far cells)
+  // the far cells of the + and - faces are fetched NOW, so that their dependent loads (block record -> far cell)
+  // overlap the arithmetic
   const int slot = cl / SF, sub = cl % SF, si = sub & 3, sj = RANK == 3 ? sub >> 2 : 0;
-  const int4        row0 = brec[4 + slot];
-  const FaceLane<T> pre0 = face_lane_from_row<T, S>(src, row0, live && row0.x != -3, si, sj);
   // previous-step state: requested with everything else (it used to be fetched last to save registers, which made
   // it the fourth dependent round trip of a wavefront's life)
   T pv[5] = {T(0), T(0), T(0), T(0), T(0)};
@@ -265,19 +271,41 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
     for (int k = 0; k < 5; k++) pv[k] = prev.p[k][o];
   }
   const PlusFace<T> fx = plus_face<T>(brec[1], live), fy = plus_face<T>(brec[2], live),
-                    fz = RANK == 3 ? plus_face<T>(brec[3], live) : PlusFace<T>{false, false, false, 0, 0, 0, T(0)};
+                    fz = RANK == 3 ? plus_face<T>(brec[3], live) : PlusFace<T>{false, false, false, 0, 0, T(0)};
   // lane cl < PF fetches far cell `cl % SF` of the block's +(cl / SF) face
   const int  pd = cl / SF, psub = cl % SF;
+#ifdef T8GPU_EXP_NOFAR
+  const bool p_on = false;
+#else
   const bool p_on = cl < PF && (pd == 0 ? fx.on : (pd == 1 ? fy.on : fz.on));
+#endif
   T          pfar[5];
-  load_plus_far<T, S>(src, p_on, pd == 0 ? fx.right : (pd == 1 ? fy.right : fz.right), pd == 0 ? fx.wall : (pd == 1 ? fy.wall : fz.wall),
-                      pd == 0 ? fx.lblock : (pd == 1 ? fy.lblock : fz.lblock), pd == 0 ? fx.rblock : (pd == 1 ? fy.rblock : fz.rblock),
-                      pd == 0 ? fx.code : (pd == 1 ? fy.code : fz.code), psub & 3, RANK == 3 ? psub >> 2 : 0, pfar);
+  load_far<T, S>(src, p_on, pd == 0 ? fx.right : (pd == 1 ? fy.right : fz.right), pd == 0 ? fx.wall : (pd == 1 ? fy.wall : fz.wall),
+                 pd == 0 ? fx.other : (pd == 1 ? fy.other : fz.other), pd == 0 ? fx.code : (pd == 1 ? fy.code : fz.code), psub & 3,
+                 RANK == 3 ? psub >> 2 : 0, -1, pfar);
+
+  // - faces: lane cl < PF owns sub-face `cl % SF` of the block's -(cl / SF) face. A wall lane fetches its OWN cell
+  // again: the mirrored flux wants two copies of the same primitives, and this way no select is needed later.
+  const PlusFace<T> mx = plus_face<T>(brec[4], live), my = plus_face<T>(brec[5], live),
+                    mz = RANK == 3 ? plus_face<T>(brec[6], live) : PlusFace<T>{false, false, false, 0, 0, T(0)};
+  const bool m_on   = cl < PF && (pd == 0 ? mx.on : (pd == 1 ? my.on : mz.on));
+  const bool m_wall = pd == 0 ? mx.wall : (pd == 1 ? my.wall : mz.wall);
+  const T    m_area = pd == 0 ? mx.area : (pd == 1 ? my.area : mz.area);
+  // the cell of this block behind that sub-face: coordinate 0 along the axis, (ti, tj) across
+  const int  mflat = (psub & 3) * (pd == 0 ? 4 : 1) + (RANK == 3 ? (psub >> 2) * (pd == 2 ? 4 : 16) : 0);
+  T          mfar[5];
+  load_far<T, S>(src, m_on, pd == 0 ? mx.right : (pd == 1 ? my.right : mz.right), m_wall,
+                 pd == 0 ? mx.other : (pd == 1 ? my.other : mz.other), pd == 0 ? mx.code : (pd == 1 ? my.code : mz.code),
+                 psub & 3, RANK == 3 ? psub >> 2 : 0, (size_t)e * S + mflat, mfar);
 
   const CellData<T, KIND> mine = cell_from_state<T, KIND>(s0);
 #pragma unroll
   for (int w = 0; w < NW; w++) pe[w][c] = mine.v[w];
+#ifdef T8GPU_EXP_NOFAR
+  if (false) {
+#else
   if (cl < PF) {
+#endif
     const CellData<T, KIND> far = cell_from_state<T, KIND>(pfar);
 #pragma unroll
     for (int w = 0; w < NW; w++) pe[w][64 + (c / S) * PF + cl] = far.v[w];
@@ -315,10 +343,39 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
     }
   }
 
-  // ---- remaining coarse faces: walls (kernels.inl:913-1107), then outer faces (:664-911) ---------------
+  // ---- - faces (same level, coarser neighbour or wall): ONE pass for the three of them, lane = side * SF + sub-face.
+  //      Geometric orientation as everywhere: left = the far cell (low side), normal +e_d; walls: left = this cell,
+  //      outward normal -e_d, and the flux LEAVES the cell.
+  {
+    T g[5] = {T(0), T(0), T(0), T(0), T(0)};
+    if (m_on) {
+      CellData<T, KIND> here;
+#pragma unroll
+      for (int w = 0; w < NW; w++) here.v[w] = pe[w][base + mflat];
+      const CellData<T, KIND> there = cell_from_state<T, KIND>(mfar);
+      cell_flux<T, KIND>(there, here, m_wall, pd, !m_wall, m_area / T(SF), g);
+      const T sgn = m_wall ? T(-1) : T(1);
+#pragma unroll
+      for (int k = 0; k < 5; k++) g[k] *= sgn;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; k++) xb[k][c] = g[k];
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < RANK; d++) {
+      const int tsub = d == 0 ? cc[1] + 4 * cc[2] : (d == 1 ? cc[0] + 4 * cc[2] : cc[0] + 4 * cc[1]);
+      if (cc[d] == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) acc[k] += xb[k][base + d * SF + tsub];
+      }
+    }
+  }
+
+  // ---- remaining coarse faces (towards finer blocks: four sub-faces per surface cell; kernels.inl:664-911) ----------
   for (int p0 = 0; p0 < npass; p0 += 4) {
     T                 g[5] = {T(0), T(0), T(0), T(0), T(0)};
-    const FaceLane<T> fl = p0 == 0 ? pre0 : load_face_lane<T, S>(P, src, b0, nbf, p0 + slot, si, sj);
+    const FaceLane<T> fl = load_face_lane<T, S>(P, src, b0, nbf, p0 + slot, si, sj);
     if (fl.active) {
       CellData<T, KIND> here, there;
 #pragma unroll

@@ -10,8 +10,10 @@
 //                            cells sees exactly ONE sub-face of it (same level, wall, or the block is the
 //                            fine side of a hanging face): the kernel folds these into its inner-face passes;
 //                            -1 otherwise. Bit 31 = the block is the face's RIGHT side.
-//   bf_off[N+1], bf_ent[]  : per owned block its remaining faces (wall faces first, then interior faces in
-//                            original order); bit 31 set when the block is the face's RIGHT side
+//   minus[N][rank]         : the same for the -x/-y/-z side: one pass of the kernel evaluates the three of them
+//                            (lane = side * sub-faces + sub-face), with no face list to walk
+//   bf_off[N+1], bf_ent[]  : per owned block its remaining faces, i.e. those towards FINER blocks (four sub-faces
+//                            per surface cell), in original order; bit 31 set when the block is the face's RIGHT side
 //   face_rec[F+B][4]       : {left slot, right slot (-1: wall), code, 0} with
 //                            code = axis | positive<<2 | hanging<<3 | off0<<4 | off1<<6 | off2<<8
 // Normals must be exact +-unit axis vectors -- the reference's kernels require the same
@@ -23,7 +25,7 @@
 namespace {
 struct SubgridPlan {
   int32_t N = 0, F = 0, B = 0, rank = 3, max_bf = 0;
-  std::vector<int32_t> bf_off, bf_ent, face_rec, plus, block_order;  // block_order: interior blocks first
+  std::vector<int32_t> bf_off, bf_ent, face_rec, plus, minus, block_order;  // block_order: interior blocks first
   int32_t n_interior = 0, n_deep = 0;
 };
 }  // namespace
@@ -64,22 +66,25 @@ void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, c
     int32_t* rec = &P->face_rec[4 * static_cast<size_t>(f)];
     rec[0] = l; rec[1] = r; rec[2] = code; rec[3] = 0;
   }
-  // pass 1: which faces fold into the +side passes
+  // pass 1: which faces fold into the +side passes / the -side pass
   P->plus.assign(static_cast<size_t>(N) * rank, -1);
+  P->minus.assign(static_cast<size_t>(N) * rank, -1);
   std::vector<uint8_t> folded_l(static_cast<size_t>(F) + B, 0), folded_r(static_cast<size_t>(F) + B, 0);
   for (int32_t f = 0; f < F + B; f++) {
     const int32_t* rec = &P->face_rec[4 * static_cast<size_t>(f)];
     const int32_t  l = rec[0], r = rec[1], code = rec[2];
     const int      axis = code & 3, positive = (code >> 2) & 1, hanging = (code >> 3) & 1;
     // left block: the face is on its +axis side iff the normal (outward from left) is positive
-    if (l < N && positive && P->plus[static_cast<size_t>(l) * rank + axis] < 0) {
-      P->plus[static_cast<size_t>(l) * rank + axis] = f;
+    std::vector<int32_t>& lside = positive ? P->plus : P->minus;
+    if (l < N && lside[static_cast<size_t>(l) * rank + axis] == -1) {
+      lside[static_cast<size_t>(l) * rank + axis] = f;
       folded_l[f] = 1;
     }
     // right block (never a wall, never finer than left): on ITS +axis side iff the normal is negative;
     // foldable only at equal level (as the coarse side of a hanging face it sees 4 sub-faces per cell)
-    if (r >= 0 && r < N && r != l && !positive && !hanging && P->plus[static_cast<size_t>(r) * rank + axis] < 0) {
-      P->plus[static_cast<size_t>(r) * rank + axis] = f | static_cast<int32_t>(0x80000000u);
+    std::vector<int32_t>& rside = positive ? P->minus : P->plus;
+    if (r >= 0 && r < N && r != l && !hanging && rside[static_cast<size_t>(r) * rank + axis] == -1) {
+      rside[static_cast<size_t>(r) * rank + axis] = f | static_cast<int32_t>(0x80000000u);
       folded_r[f] = 1;
     }
   }
@@ -165,12 +170,11 @@ void t8gpu_plan_subgrid_arrays(const void* h, int32_t* bf_off, int32_t* bf_ent, 
 // can issue every far-cell load, instead of block_order -> face list -> face record -> far cell:
 //   block_rec[N][32] in block_order position order (128-byte rows):
 //     {block, n generic faces, first entry in bf_rec, 0,  then for d = 0..2 the +d face: other, code, area (2 words),
-//      then COPIES of the block's first four generic faces (other = -3: no such face)} -- with the copies a wavefront
-//     can request the far cells of its first generic pass as soon as it knows its position, instead of one round trip
-//     later (record -> bf_rec rows -> far cells)
+//      then for d = 0..2 the -d face likewise, then four spare words} -- a wavefront can request every far cell of
+//     these six faces as soon as it knows its position
 //   bf_rec[n_entries][4], the generic faces of the blocks in the same position order: other, code, area (2 words)
 // other = the block on the far side (left block if this block is the face's right side and vice versa), -1 = wall,
-// -2 (+ faces only) = not foldable (finer neighbours: those faces are in the generic list); code = the face code of
+// -2 (+ / - faces only) = not foldable (finer neighbours: those faces are in the generic list); code = the face code of
 // face_rec | 1 << 12 when this block is the face's RIGHT side; area = face_surfaces[f] as float (word 0) or double.
 void t8gpu_plan_subgrid_records(const void* h, const double* areas, int float_size, int32_t* block_rec, int32_t* bf_rec) {
   const SubgridPlan* P = static_cast<const SubgridPlan*>(h);
@@ -204,10 +208,13 @@ void t8gpu_plan_subgrid_records(const void* h, const double* areas, int float_si
         if (ent != -1) put(pd, ent);
       }
     }
-    for (int q = 0; q < 4; q++) {
-      int32_t* pg = rec + 16 + 4 * q;
-      pg[0] = -3;
-      if (P->bf_off[e] + q < P->bf_off[e + 1]) put(pg, P->bf_ent[P->bf_off[e] + q]);
+    for (int d = 0; d < 3; d++) {
+      int32_t* pd = rec + 16 + 4 * d;
+      pd[0] = -2;
+      if (d < P->rank) {
+        const int32_t ent = P->minus[static_cast<size_t>(e) * P->rank + d];
+        if (ent != -1) put(pd, ent);
+      }
     }
     for (int32_t j = P->bf_off[e]; j < P->bf_off[e + 1]; j++) put(bf_rec + 4 * static_cast<size_t>(first++), P->bf_ent[j]);
   }

@@ -1,0 +1,71 @@
+"""Host plan of the fused Subgrid kernels (csrc/host/subgrid_plan.cpp): every coarse face must reach each owned
+block it touches exactly once -- in the block record's + slot, its - slot, or the block's generic list (faces towards
+finer blocks only) -- on the right side of the block and with the right orientation flag."""
+import numpy as np
+import pytest
+
+from t8gpu_amd.plan import HostSubgridPlan
+from t8gpu_amd.synth import SynthMesh
+
+
+@pytest.mark.parametrize("dim,args,parts", [(2, dict(base_level=3, max_level=3), 1), (2, dict(base_level=3, max_level=6, band=0.03), 1),
+                                            (2, dict(base_level=3, max_level=5, band=0.03, periodic=False), 3),
+                                            (3, dict(base_level=2, max_level=2), 1), (3, dict(base_level=3, max_level=4, band=0.03), 2),
+                                            (3, dict(base_level=2, max_level=4, band=0.05, periodic=False), 1)])
+def test_every_face_reaches_each_of_its_blocks_once(dim, args, parts):
+    mesh = SynthMesh(dim, **args)
+    for rank in range(parts):
+        part = mesh.partition(rank, parts, subgrid=True) if parts > 1 else mesh.partition(subgrid=True)
+        plan = HostSubgridPlan(part)
+        block_rec, bf_rec = plan.records(part.areas, 8)
+        N, F, B = part.N, part.F, part.B
+        fn = np.asarray(part.face_neighbors, np.int64).reshape(-1)
+        left = np.concatenate([fn[0:2 * F:2], fn[2 * F:2 * F + B]])
+        right = np.concatenate([fn[1:2 * F:2], np.full(B, -1)])
+        normals = np.asarray(part.normals, np.float64).reshape(F + B, dim)
+        axis = np.abs(normals).argmax(1)
+        positive = normals[np.arange(F + B), axis] > 0
+        hanging = np.concatenate([np.asarray(part.level_diff).reshape(-1)[:F] != 0, np.zeros(B, bool)])
+        areas = np.asarray(part.areas, np.float64)
+        # expected (block, side axis, side sign, other block, is right side, area) per (face, adjacent owned block)
+        want = {}
+        for f in range(F + B):
+            l, r = int(left[f]), int(right[f])
+            if l < N:
+                want.setdefault((l, int(axis[f]), bool(positive[f])), []).append((r, False, areas[f], bool(hanging[f])))
+            if 0 <= r < N and r != l:
+                want.setdefault((r, int(axis[f]), not bool(positive[f])), []).append((l, True, areas[f], bool(hanging[f])))
+        got = {}
+        assert sorted(block_rec[:N, 0].tolist()) == list(range(N))          # a permutation of the owned blocks
+        first = 0
+        for pos in range(N):
+            rec = block_rec[pos]
+            e, nbf = int(rec[0]), int(rec[1])
+            assert int(rec[2]) == first
+            for side, base in ((True, 4), (False, 16)):
+                for d in range(3):
+                    w = rec[base + 4 * d:base + 4 * d + 4]
+                    if d >= dim or w[0] == -2:
+                        assert w[0] == -2
+                        continue
+                    code = int(w[1])
+                    assert (code & 3) == d
+                    is_right = bool((code >> 12) & 1)
+                    # the side the face lies on, seen from this block: the normal points away from the LEFT block
+                    assert (bool((code >> 2) & 1) != is_right) == side
+                    area = np.frombuffer(w[2:4].tobytes(), np.float64)[0]
+                    got.setdefault((e, d, side), []).append((int(w[0]), is_right, area, bool((code >> 3) & 1)))
+                    assert not (is_right and (code >> 3) & 1)               # the coarse side of a hanging face is never folded
+            for j in range(first, first + nbf):
+                w = bf_rec[j]
+                code = int(w[1])
+                is_right = bool((code >> 12) & 1)
+                side = bool((code >> 2) & 1) != is_right
+                area = np.frombuffer(w[2:4].tobytes(), np.float64)[0]
+                got.setdefault((e, code & 3, side), []).append((int(w[0]), is_right, area, bool((code >> 3) & 1)))
+                assert is_right and (code >> 3) & 1                          # generic rows: towards finer blocks only
+            first += nbf
+        assert first == plan.n_entries
+        assert set(got) == set(want)
+        for key in want:
+            assert sorted(got[key]) == sorted(want[key]), key
