@@ -311,6 +311,7 @@ namespace t8gpu::hip {
       m_plan.max_faces_per_block = static_cast<int32_t>(sz[1]);
       m_plan.n_interior_blocks   = static_cast<int32_t>(sz[3]);
       m_plan.n_deep_blocks       = static_cast<int32_t>(sz[4]);
+      m_plan.n_blocks_addressed  = static_cast<int32_t>(sz[5]);
     }
     ~SubgridFusedPlan() {
       (void)hipFree(m_block_rec);

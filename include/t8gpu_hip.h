@@ -262,7 +262,9 @@ typedef struct T8gpuSubgridPlan {
                                    code (bit 12: the block is the face's RIGHT side), area (2 words)} */
   int32_t num_elements, rank, max_faces_per_block, n_interior_blocks;
   int32_t n_deep_blocks;        /* leading blocks that have no neighbour touching a ghost block (0: unknown) */
-  int32_t reserved;
+  int32_t n_blocks_addressed;   /* 1 + the largest block index any record refers to (owned and ghost blocks; sizes[5] of
+                                   t8gpu_plan_subgrid_sizes): lets the kernel use 32-bit byte offsets into the state planes
+                                   when a plane is shorter than 4 GiB. 0 = unknown (64-bit addressing) */
 } T8gpuSubgridPlan;
 
 /* block_begin/block_count select a range of block_order (0, num_elements = everything; [0, n_interior_blocks)

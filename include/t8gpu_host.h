@@ -72,7 +72,8 @@ void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, c
                                 const int32_t* face_level_difference, const int32_t* face_neighbor_offset,
                                 const double* normals);
 void  t8gpu_plan_subgrid_destroy(void* plan);
-/* sizes[8] = {n_entries, max faces per block, F + B, n_interior_blocks, n_deep_blocks, 0, 0, 0} */
+/* sizes[8] = {n_entries, max faces per block, F + B, n_interior_blocks, n_deep_blocks, 1 + largest block index referred to
+ * (owned and ghost blocks), 0, 0} */
 void t8gpu_plan_subgrid_sizes(const void* plan, int64_t* sizes);
 /* block_order[N]: blocks that touch no ghost block first (they can run during the halo exchange) */
 void t8gpu_plan_subgrid_order(const void* plan, int32_t* block_order);

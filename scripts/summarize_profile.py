@@ -86,6 +86,15 @@ def main(out):
     for k in sorted(sq):
         vals = [sq[k][n][0] / sq[k][n][1] if sq[k][n][1] else 0.0 for n in names]
         print(f"| {k} | " + " | ".join(f"{v:.3g}" for v in vals) + " |")
+    mix = counters(os.path.join(out, "mix"))
+    if mix:
+        print("\n## instruction mix per wavefront (SQ_INSTS_* / SQ_WAVES, averages over launches)\n")
+        mn = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"]
+        print("| kernel | waves | " + " | ".join(n.replace("SQ_INSTS_", "") for n in mn[1:]) + " |\n|---|" + "---|" * len(mn))
+        for k in sorted(mix):
+            v = {n: (mix[k][n][0] / mix[k][n][1] if mix[k][n][1] else 0.0) for n in mn}
+            w = v["SQ_WAVES"] or 1.0
+            print(f"| {k} | {v['SQ_WAVES']:.0f} | " + " | ".join(f"{v[n] / w:.0f}" for n in mn[1:]) + " |")
 
 
 if __name__ == "__main__":

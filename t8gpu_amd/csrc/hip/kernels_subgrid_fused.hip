@@ -40,6 +40,20 @@ struct SVars {
   T* p[5];
 };
 
+// Element `i` of a state plane. NARROW (every plane of the rank, ghost blocks included, is shorter than 4 GiB -- the
+// launcher checks): the byte offset fits 32 bits, so the five planes share ONE offset register and the loads take the
+// "uniform base + 32-bit lane offset" form instead of five 64-bit address computations per cell.
+template <bool WIDE, class T>
+T8_DEV const T& at(const T* p, size_t i) {
+  if (WIDE) return p[i];
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + static_cast<uint32_t>(i * sizeof(T)));
+}
+template <bool WIDE, class T>
+T8_DEV T& at(T* p, size_t i) {
+  if (WIDE) return p[i];
+  return *reinterpret_cast<T*>(reinterpret_cast<char*>(p) + static_cast<uint32_t>(i * sizeof(T)));
+}
+
 T8_DEV int sg_xcd_position(int b, int nb) {
   const int q = nb >> 3, rem = nb & 7, x = b & 7, k = b >> 3;
   return x * q + (x < rem ? x : rem) + k;
@@ -63,15 +77,6 @@ T8_DEV FaceCode decode(int code) {
   return f;
 }
 T8_DEV int cell_coord(int flat, int a) { return (flat >> (2 * a)) & 3; }   // flat = i + 4 j + 16 k
-T8_DEV int cell_stride(int a) { return 1 << (2 * a); }
-// left / right cell of sub-face (si, sj): kernels.inl:710-758
-T8_DEV int left_cell(const FaceCode& fc, int si, int sj) {
-  return (fc.positive ? 3 : 0) * cell_stride(fc.axis) + si * cell_stride(fc.ta()) + sj * cell_stride(fc.tb());
-}
-T8_DEV int right_cell(const FaceCode& fc, int si, int sj) {
-  return fc.off(fc.axis) * cell_stride(fc.axis) + (fc.off(fc.ta()) + (fc.hanging ? si / 2 : si)) * cell_stride(fc.ta()) +
-         (fc.off(fc.tb()) + (fc.hanging ? sj / 2 : sj)) * cell_stride(fc.tb());
-}
 
 template <class T, int KIND>
 struct CellData {  // what a flux evaluation needs from one cell: primitives (KEPES) or the raw state (HLL)
@@ -89,11 +94,9 @@ T8_DEV CellData<T, KIND> cell_from_state(const T s[5]) {
   }
 #endif
   if (KIND == 0) {
-#ifdef T8GPU_EXP_SG_LOGTAB   // experiment builds: table-driven fp64 log, table read from global memory
+    // fp64: table-driven logarithm, the 2 KB table read from global memory (it stays in the L1 / K$; an LDS copy per
+    // one-wave workgroup would cost the kernel a wavefront per SIMD). fp32: hardware log2.
     const Prim<T> q = prim_from_state<T, true>(s, kLogTab);
-#else
-    const Prim<T> q = prim_from_state<T>(s);
-#endif
     c.v[0] = q.rho; c.v[1] = q.vx; c.v[2] = q.vy; c.v[3] = q.vz; c.v[4] = q.p;
     c.v[5] = q.beta; c.v[6] = q.lrho; c.v[7] = q.lbeta; c.v[8] = q.v0;
   } else {
@@ -139,7 +142,7 @@ T8_DEV float  area_of(int lo, int, float) { return __int_as_float(lo); }
 T8_DEV double area_of(int lo, int hi, double) { return __hiloint2double(hi, lo); }
 
 // lane data of one generic face from its row {other block, code, area}; `live_row` = the row exists
-template <class T, int S>
+template <class T, int S, bool WIDE>
 T8_DEV FaceLane<T> face_lane_from_row(const SVars<T>& src, int4 rec, bool live_row, int si, int sj) {
   FaceLane<T> L;
   L.active = live_row;
@@ -149,72 +152,71 @@ T8_DEV FaceLane<T> face_lane_from_row(const SVars<T>& src, int4 rec, bool live_r
 #pragma unroll
   for (int k = 0; k < 5; k++) L.sf[k] = T(1);
   if (L.active) {
-    const FaceCode fc  = decode(rec.y);
-    L.right = fc.right();
+    const int code = rec.y;
+    L.right = (code >> 12) & 1;
     L.wall  = rec.x == -1;
     L.area  = area_of(rec.z, rec.w, T(0));
-    const int lflat = left_cell(fc, si, sj), rflat = right_cell(fc, si, sj);
-    L.myflat   = L.right ? rflat : lflat;
-    L.axis     = fc.axis;
-    L.positive = fc.positive;
+    // cell(i, j) = c0 + ((i >> h) << la) + ((j >> h) << lb) on either side (subgrid_plan.cpp)
+    const int la = (code >> 20) & 2, lb = 4 - ((code >> 21) & 2);
+    const int hf = (code >> 19) & 1, ho = (code >> 20) & 1;
+    L.myflat   = ((code >> 13) & 63) + ((si >> ho) << la) + ((sj >> ho) << lb);
+    L.axis     = code & 3;
+    L.positive = (code >> 2) & 1;
     if (!L.wall) {
-      const size_t far = (size_t)rec.x * S + (L.right ? lflat : rflat);
+      const size_t far = (size_t)(rec.x + ((si >> hf) << la) + ((sj >> hf) << lb));
 #pragma unroll
-      for (int k = 0; k < 5; k++) L.sf[k] = src.p[k][far];
+      for (int k = 0; k < 5; k++) L.sf[k] = at<WIDE>(src.p[k], far);
     }
   }
   return L;
 }
-template <class T, int S>
+template <class T, int S, bool WIDE>
 T8_DEV FaceLane<T> load_face_lane(const T8gpuSubgridPlan& P, const SVars<T>& src, int first, int nbf, int idx, int si, int sj) {
   int4 rec = make_int4(0, 0, 0, 0);
   if (idx < nbf) rec = reinterpret_cast<const int4*>(P.bf_rec)[first + idx];   // {other block, code, area}
-  return face_lane_from_row<T, S>(src, rec, idx < nbf, si, sj);
+  return face_lane_from_row<T, S, WIDE>(src, rec, idx < nbf, si, sj);
 }
 
 // The +d coarse face of a block (wave-uniform for RANK 3: these are scalar loads, which keeps the
 // dependent chain face list -> face record -> far cell short).
 template <class T>
 struct PlusFace {
-  bool on, right, wall;   // on: listed as ONE coarse face (faces towards finer blocks are in the generic list)
-  int  other, code;   // other: the block on the far side, whichever side that is
+  bool on, wall;   // on: listed as ONE coarse face (faces towards finer blocks are in the generic list)
+  int  far, hf;    // far cell of sub-face (0, 0); hf: two sub-faces share a far cell (the block is the fine side)
   T    area;
 };
 template <class T>
 T8_DEV PlusFace<T> plus_face(int4 w, bool live) {   // w = the four words of the block record for this face
   PlusFace<T> f;
-  f.on = f.right = f.wall = false;
-  f.other = f.code = 0;
+  f.on = f.wall = false;
+  f.far = f.hf = 0;
   f.area = T(0);
   if (live && w.x != -2) {
-    f.on     = true;
-    f.code   = w.y;
-    f.right  = (w.y >> 12) & 1;
-    f.wall   = w.x == -1;
-    f.other  = w.x;
-    f.area   = area_of(w.z, w.w, T(0));
+    f.on   = true;
+    f.wall = w.x == -1;
+    f.far  = w.x;
+    f.hf   = (w.y >> 19) & 1;
+    f.area = area_of(w.z, w.w, T(0));
   }
   return f;
 }
-// state of the far cell behind sub-face (ti, tj) of that face: in the left block on its face plane, or in
-// the right block at the stored anchor (kernels.inl:710-758); a wall face reads cell `wall_cell` (pass -1: nothing)
-template <class T, int S>
-T8_DEV void load_far(const SVars<T>& src, bool on, bool right, bool wall, int other, int code, int ti, int tj, ptrdiff_t wall_cell,
+// state of the far cell behind sub-face (ti, tj) of a + / - face with tangential strides 1 << la, 1 << lb; a wall face
+// reads cell `wall_cell` instead (pass -1: nothing)
+template <class T, bool WIDE>
+T8_DEV void load_far(const SVars<T>& src, bool on, bool wall, int far0, int hf, int la, int lb, int ti, int tj, ptrdiff_t wall_cell,
                      T sf[5]) {
 #pragma unroll
   for (int k = 0; k < 5; k++) sf[k] = T(1);
   if (on && !(wall && wall_cell < 0)) {
-    const FaceCode fc    = decode(code);
-    const int      fcell = right ? left_cell(fc, ti, tj) : right_cell(fc, ti, tj);
-    const size_t   far   = wall ? (size_t)wall_cell : (size_t)other * S + fcell;
+    const size_t far = wall ? (size_t)wall_cell : (size_t)(far0 + ((ti >> hf) << la) + ((tj >> hf) << lb));
 #pragma unroll
-    for (int k = 0; k < 5; k++) sf[k] = src.p[k][far];
+    for (int k = 0; k < 5; k++) sf[k] = at<WIDE>(src.p[k], far);
   }
 }
 
 // RANK 3: one Subgrid<4,4,4> block per wavefront. RANK 2: four Subgrid<4,4> blocks per wavefront
 // (16 lanes each; every index below is relative to the lane's own block).
-template <class T, int KIND, int STAGE, int RANK, bool EARLY_PREV>
+template <class T, int KIND, int STAGE, int RANK, bool EARLY_PREV, bool WIDE>
 __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int block_begin, int block_count, SVars<T> prev,
                                                       SVars<T> src, SVars<T> out, const T* __restrict__ volumes, T dt) {
   constexpr int NW  = CellData<T, KIND>::words;
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
 
   T s0[5];
 #pragma unroll
-  for (int k = 0; k < 5; k++) s0[k] = src.p[k][o];
+  for (int k = 0; k < 5; k++) s0[k] = at<WIDE>(src.p[k], o);
   const T   vol     = volumes[e];
   const int b0      = r0.z;
   const int nbf     = live ? r0.y : 0;
@@ -268,10 +270,10 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
   T pv[5] = {T(0), T(0), T(0), T(0), T(0)};
   if (STAGE > 1 && EARLY_PREV) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) pv[k] = prev.p[k][o];
+    for (int k = 0; k < 5; k++) pv[k] = at<WIDE>(prev.p[k], o);
   }
   const PlusFace<T> fx = plus_face<T>(brec[1], live), fy = plus_face<T>(brec[2], live),
-                    fz = RANK == 3 ? plus_face<T>(brec[3], live) : PlusFace<T>{false, false, false, 0, 0, T(0)};
+                    fz = RANK == 3 ? plus_face<T>(brec[3], live) : PlusFace<T>{false, false, 0, 0, T(0)};
   // lane cl < PF fetches far cell `cl % SF` of the block's +(cl / SF) face
   const int  pd = cl / SF, psub = cl % SF;
 #ifdef T8GPU_EXP_NOFAR
@@ -279,24 +281,24 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
 #else
   const bool p_on = cl < PF && (pd == 0 ? fx.on : (pd == 1 ? fy.on : fz.on));
 #endif
+  // (the tangential strides of side pd: 4 / 16 across x, 1 / 16 across y, 1 / 4 across z)
+  const int  pla = pd == 0 ? 2 : 0, plb = pd == 2 ? 2 : 4, pti = psub & 3, ptj = RANK == 3 ? psub >> 2 : 0;
   T          pfar[5];
-  load_far<T, S>(src, p_on, pd == 0 ? fx.right : (pd == 1 ? fy.right : fz.right), pd == 0 ? fx.wall : (pd == 1 ? fy.wall : fz.wall),
-                 pd == 0 ? fx.other : (pd == 1 ? fy.other : fz.other), pd == 0 ? fx.code : (pd == 1 ? fy.code : fz.code), psub & 3,
-                 RANK == 3 ? psub >> 2 : 0, -1, pfar);
+  load_far<T, WIDE>(src, p_on, pd == 0 ? fx.wall : (pd == 1 ? fy.wall : fz.wall), pd == 0 ? fx.far : (pd == 1 ? fy.far : fz.far),
+              pd == 0 ? fx.hf : (pd == 1 ? fy.hf : fz.hf), pla, plb, pti, ptj, -1, pfar);
 
   // - faces: lane cl < PF owns sub-face `cl % SF` of the block's -(cl / SF) face. A wall lane fetches its OWN cell
   // again: the mirrored flux wants two copies of the same primitives, and this way no select is needed later.
   const PlusFace<T> mx = plus_face<T>(brec[4], live), my = plus_face<T>(brec[5], live),
-                    mz = RANK == 3 ? plus_face<T>(brec[6], live) : PlusFace<T>{false, false, false, 0, 0, T(0)};
+                    mz = RANK == 3 ? plus_face<T>(brec[6], live) : PlusFace<T>{false, false, 0, 0, T(0)};
   const bool m_on   = cl < PF && (pd == 0 ? mx.on : (pd == 1 ? my.on : mz.on));
   const bool m_wall = pd == 0 ? mx.wall : (pd == 1 ? my.wall : mz.wall);
   const T    m_area = pd == 0 ? mx.area : (pd == 1 ? my.area : mz.area);
   // the cell of this block behind that sub-face: coordinate 0 along the axis, (ti, tj) across
-  const int  mflat = (psub & 3) * (pd == 0 ? 4 : 1) + (RANK == 3 ? (psub >> 2) * (pd == 2 ? 4 : 16) : 0);
+  const int  mflat = (pti << pla) + (ptj << plb);
   T          mfar[5];
-  load_far<T, S>(src, m_on, pd == 0 ? mx.right : (pd == 1 ? my.right : mz.right), m_wall,
-                 pd == 0 ? mx.other : (pd == 1 ? my.other : mz.other), pd == 0 ? mx.code : (pd == 1 ? my.code : mz.code),
-                 psub & 3, RANK == 3 ? psub >> 2 : 0, (size_t)e * S + mflat, mfar);
+  load_far<T, WIDE>(src, m_on, m_wall, pd == 0 ? mx.far : (pd == 1 ? my.far : mz.far), pd == 0 ? mx.hf : (pd == 1 ? my.hf : mz.hf), pla, plb,
+              pti, ptj, (size_t)e * S + mflat, mfar);
 
   const CellData<T, KIND> mine = cell_from_state<T, KIND>(s0);
 #pragma unroll
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
   // ---- remaining coarse faces (towards finer blocks: four sub-faces per surface cell; kernels.inl:664-911) ----------
   for (int p0 = 0; p0 < npass; p0 += 4) {
     T                 g[5] = {T(0), T(0), T(0), T(0), T(0)};
-    const FaceLane<T> fl = load_face_lane<T, S>(P, src, b0, nbf, p0 + slot, si, sj);
+    const FaceLane<T> fl = load_face_lane<T, S, WIDE>(P, src, b0, nbf, p0 + slot, si, sj);
     if (fl.active) {
       CellData<T, KIND> here, there;
 #pragma unroll
@@ -439,12 +441,12 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
   if (live) {
     if (STAGE > 1 && !EARLY_PREV) {
 #pragma unroll
-      for (int k = 0; k < 5; k++) pv[k] = prev.p[k][o];
+      for (int k = 0; k < 5; k++) pv[k] = at<WIDE>(prev.p[k], o);
     }
     const T scale = dt / (vol / T(S));
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-      out.p[k][o] = rk_stage_update<T, STAGE>(pv[k], s0[k], scale, acc[k]);
+      at<WIDE>(out.p[k], o) = rk_stage_update<T, STAGE>(pv[k], s0[k], scale, acc[k]);
     }
   }
 }
@@ -466,18 +468,19 @@ int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, int b
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3  grid(plan->rank == 3 ? block_count : (block_count + 3) / 4), block(64);
   // fp32 requests the previous-step state up front (one round trip less per wavefront); fp64 keeps fetching it last:
-  // it is bound by DP instruction issue and the 10 extra registers would cost it a wavefront per SIMD. T8GPU_SG_EARLY_PREV
-  // = 0 / 1 overrides (measurements).
-  static const int early_env = std::getenv("T8GPU_SG_EARLY_PREV") ? std::atoi(std::getenv("T8GPU_SG_EARLY_PREV")) : -1;
-  const bool early = early_env >= 0 ? early_env != 0 : sizeof(T) == 4;
+  // it is bound by DP instruction issue and the 10 extra registers would cost it a wavefront per SIMD (measured both ways).
+  constexpr bool early = sizeof(T) == 4;
+  // 32-bit byte offsets into the state planes when every plane (owned + ghost blocks) is shorter than 4 GiB
+  const int64_t cells = static_cast<int64_t>(plan->n_blocks_addressed) * (plan->rank == 3 ? 64 : 16);
+  const bool    wide  = plan->n_blocks_addressed <= 0 || cells * static_cast<int64_t>(sizeof(T)) >= (int64_t(1) << 32);
 #define T8_SG(K, S, R)                                                                                                          \
   do {                                                                                                                          \
-    if (early)                                                                                                                  \
-      hipLaunchKernelGGL((k_subgrid_fused<T, K, S, R, true>), grid, block, 0, s, *plan, block_begin, block_count, smk<T>(prev),  \
-                         smk<T>(mid), smk<T>(out), volumes, dt);                                                                \
+    if (wide)                                                                                                                   \
+      hipLaunchKernelGGL((k_subgrid_fused<T, K, S, R, early, true>), grid, block, 0, s, *plan, block_begin, block_count,        \
+                         smk<T>(prev), smk<T>(mid), smk<T>(out), volumes, dt);                                                  \
     else                                                                                                                        \
-      hipLaunchKernelGGL((k_subgrid_fused<T, K, S, R, false>), grid, block, 0, s, *plan, block_begin, block_count, smk<T>(prev), \
-                         smk<T>(mid), smk<T>(out), volumes, dt);                                                                \
+      hipLaunchKernelGGL((k_subgrid_fused<T, K, S, R, early, false>), grid, block, 0, s, *plan, block_begin, block_count,       \
+                         smk<T>(prev), smk<T>(mid), smk<T>(out), volumes, dt);                                                  \
   } while (0)
 #define T8_SGR(K, S)     \
   do {                   \

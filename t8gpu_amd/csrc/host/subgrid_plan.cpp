@@ -24,7 +24,7 @@
 
 namespace {
 struct SubgridPlan {
-  int32_t N = 0, F = 0, B = 0, rank = 3, max_bf = 0;
+  int32_t N = 0, F = 0, B = 0, rank = 3, max_bf = 0, n_addressed = 0;
   std::vector<int32_t> bf_off, bf_ent, face_rec, plus, minus, block_order;  // block_order: interior blocks first
   int32_t n_interior = 0, n_deep = 0;
 };
@@ -65,6 +65,8 @@ void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, c
     }
     int32_t* rec = &P->face_rec[4 * static_cast<size_t>(f)];
     rec[0] = l; rec[1] = r; rec[2] = code; rec[3] = 0;
+    if (l + 1 > P->n_addressed) P->n_addressed = l + 1;
+    if (r + 1 > P->n_addressed) P->n_addressed = r + 1;
   }
   // pass 1: which faces fold into the +side passes / the -side pass
   P->plus.assign(static_cast<size_t>(N) * rank, -1);
@@ -142,7 +144,7 @@ void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, c
 
 void t8gpu_plan_subgrid_destroy(void* h) { delete static_cast<SubgridPlan*>(h); }
 
-/* sizes[5] = {n_entries, max faces per block, F + B, n_interior_blocks, n_deep_blocks} */
+/* sizes[6] = {n_entries, max faces per block, F + B, n_interior_blocks, n_deep_blocks, 1 + largest block index referred to} */
 void t8gpu_plan_subgrid_sizes(const void* h, int64_t* sizes) {
   const SubgridPlan* P = static_cast<const SubgridPlan*>(h);
   sizes[0] = static_cast<int64_t>(P->bf_ent.size());
@@ -150,6 +152,7 @@ void t8gpu_plan_subgrid_sizes(const void* h, int64_t* sizes) {
   sizes[2] = static_cast<int64_t>(P->F) + P->B;
   sizes[3] = P->n_interior;
   sizes[4] = P->n_deep;
+  sizes[5] = P->n_addressed > P->N ? P->n_addressed : P->N;
 }
 
 void t8gpu_plan_subgrid_order(const void* h, int32_t* block_order) {
@@ -172,18 +175,36 @@ void t8gpu_plan_subgrid_arrays(const void* h, int32_t* bf_off, int32_t* bf_ent, 
 //     {block, n generic faces, first entry in bf_rec, 0,  then for d = 0..2 the +d face: other, code, area (2 words),
 //      then for d = 0..2 the -d face likewise, then four spare words} -- a wavefront can request every far cell of
 //     these six faces as soon as it knows its position
-//   bf_rec[n_entries][4], the generic faces of the blocks in the same position order: other, code, area (2 words)
-// other = the block on the far side (left block if this block is the face's right side and vice versa), -1 = wall,
-// -2 (+ / - faces only) = not foldable (finer neighbours: those faces are in the generic list); code = the face code of
-// face_rec | 1 << 12 when this block is the face's RIGHT side; area = face_surfaces[f] as float (word 0) or double.
+//   bf_rec[n_entries][4], the generic faces of the blocks in the same position order: far, code, area (2 words)
+// far = index of the far cell of sub-face (0, 0) in the state arrays (far block * cells per block + its cell there; the
+// far block is the left block if this block is the face's right side and vice versa), -1 = wall, -2 (+ / - faces only) =
+// not foldable (finer neighbours: those faces are in the generic list);
+// code = the face code of face_rec | 1 << 12 when this block is the face's RIGHT side | this block's cell behind
+// sub-face (0, 0) << 13 | (two sub-faces per far cell) << 19 | (two sub-faces per own cell) << 20 | (stride of the first
+// tangential axis is 4 instead of 1) << 21 | (stride of the second is 4 instead of 16) << 22, so that
+//   cell(i, j) = c0 + ((i >> h) << la) + ((j >> h) << lb)
+// on either side needs no decoding of the anchor; area = face_surfaces[f] as float (word 0) or double.
+// (32-bit cell indices: a rank holds fewer than 2^31 subcells including its ghost blocks.)
 void t8gpu_plan_subgrid_records(const void* h, const double* areas, int float_size, int32_t* block_rec, int32_t* bf_rec) {
   const SubgridPlan* P = static_cast<const SubgridPlan*>(h);
+  const int32_t S = P->rank == 3 ? 64 : 16;
   auto put = [&](int32_t* dst, int32_t ent) {
     const int32_t  f     = ent & 0x7FFFFFFF;
     const bool     right = ent < 0;
     const int32_t* rec   = &P->face_rec[4 * static_cast<size_t>(f)];
-    dst[0] = right ? rec[0] : rec[1];
-    dst[1] = rec[2] | (right ? 1 << 12 : 0);
+    const int32_t  code  = rec[2];
+    const int      axis = code & 3, positive = (code >> 2) & 1, hanging = (code >> 3) & 1;
+    // the two cells of sub-face (i, j): cell = c0 + ((i >> h) << la) + ((j >> h) << lb), with la / lb the strides of the
+    // two tangential axes. On the LEFT block it is the face plane (coordinate 3 or 0 along the axis), on the RIGHT block
+    // the stored anchor, and on the coarse (right) side of a hanging face two sub-faces share a cell (kernels.inl:710-758)
+    int32_t c0_anchor = 0;
+    for (int a = 0; a < 3; a++) c0_anchor += ((code >> (4 + 2 * a)) & 3) << (2 * a);
+    const int32_t c0_plane = (positive ? 3 : 0) << (2 * axis);
+    const int32_t far_c0 = right ? c0_plane : c0_anchor, own_c0 = right ? c0_anchor : c0_plane;
+    const int32_t far_h = right ? 0 : hanging, own_h = right ? hanging : 0;
+    const int32_t other = right ? rec[0] : rec[1];
+    dst[0] = other < 0 ? -1 : other * S + far_c0;
+    dst[1] = code | (right ? 1 << 12 : 0) | own_c0 << 13 | far_h << 19 | own_h << 20 | (axis == 0 ? 1 << 21 : 0) | (axis == 2 ? 1 << 22 : 0);
     dst[2] = dst[3] = 0;
     if (float_size == 4) {
       const float a = static_cast<float>(areas[f]);

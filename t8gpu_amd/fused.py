@@ -88,7 +88,7 @@ class PlainPlan:
 class T8gpuSubgridPlan(C.Structure):
     _fields_ = [("block_rec", C.c_void_p), ("bf_rec", C.c_void_p),
                 ("num_elements", C.c_int32), ("rank", C.c_int32), ("max_faces_per_block", C.c_int32),
-                ("n_interior_blocks", C.c_int32), ("n_deep_blocks", C.c_int32), ("reserved", C.c_int32)]
+                ("n_interior_blocks", C.c_int32), ("n_deep_blocks", C.c_int32), ("n_blocks_addressed", C.c_int32)]
 
 
 class SubgridPlan:
@@ -106,6 +106,7 @@ class SubgridPlan:
         c.num_elements, c.rank, c.max_faces_per_block = part.N, part.mesh.dim, self.host.max_bf
         c.n_interior_blocks = self.host.n_interior
         c.n_deep_blocks = self.host.n_deep
+        c.n_blocks_addressed = self.host.n_addressed
         self.c = c
 
     def stage(self, solver, stage, src, dst, dt, stream, block_begin=0, block_count=None):

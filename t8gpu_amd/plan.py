@@ -99,6 +99,7 @@ class HostSubgridPlan:
         lib.t8gpu_plan_subgrid_sizes(h, p(sz))
         self.N, self.rank, self.max_bf, self.n_interior, self.n_deep = part.N, rank, int(sz[1]), int(sz[3]), int(sz[4])
         self.n_entries = int(sz[0])
+        self.n_addressed = int(sz[5])     # 1 + largest block index any face refers to (owned and ghost blocks)
         lib.t8gpu_plan_subgrid_order.argtypes = [C.c_void_p, C.c_void_p]
         self.block_order = np.zeros(part.N, np.int32)
         lib.t8gpu_plan_subgrid_order(h, p(self.block_order))

@@ -35,6 +35,29 @@ def test_every_face_reaches_each_of_its_blocks_once(dim, args, parts):
                 want.setdefault((l, int(axis[f]), bool(positive[f])), []).append((r, False, areas[f], bool(hanging[f])))
             if 0 <= r < N and r != l:
                 want.setdefault((r, int(axis[f]), not bool(positive[f])), []).append((l, True, areas[f], bool(hanging[f])))
+        S = 4 ** dim
+        offs = np.asarray(part.nb_offset, np.int64).reshape(F, dim)
+
+        def check_cells(w, e_is_right, f_axis, f_positive, f_hanging, anchor):
+            """The two cell recipes of a row against kernels.inl:710-758 spelled out for every sub-face."""
+            code, base = int(w[1]), int(w[0])
+            la, lb = ((code >> 21) & 1) * 2, 4 - ((code >> 22) & 1) * 2
+            hf, ho, c0 = (code >> 19) & 1, (code >> 20) & 1, (code >> 13) & 63
+            ta, tb = (1 if f_axis == 0 else 0), (1 if f_axis == 2 else 2)
+            for sj in range(4 if dim == 3 else 1):
+                for si in range(4):
+                    left = (3 if f_positive else 0) * 4 ** f_axis + si * 4 ** ta + sj * 4 ** tb
+                    hs = (lambda x: x // 2) if f_hanging else (lambda x: x)
+                    rgt = anchor[f_axis] * 4 ** f_axis + (anchor[ta] + hs(si)) * 4 ** ta + ((anchor[tb] if tb < dim else 0) + hs(sj)) * 4 ** tb
+                    own, far = (rgt, left) if e_is_right else (left, rgt)
+                    assert c0 + ((si >> ho) << la) + ((sj >> ho) << lb) == own
+                    if base >= 0:
+                        assert (base % S) + ((si >> hf) << la) + ((sj >> hf) << lb) == far
+
+        # (face, side) -> anchor, to look the offsets up again from what a row says
+        anchor_of = {}
+        for f in range(F):
+            anchor_of[(int(left[f]), int(right[f]), int(axis[f]), bool(positive[f]))] = [int(x) for x in offs[f]] + [0] * (3 - dim)
         got = {}
         assert sorted(block_rec[:N, 0].tolist()) == list(range(N))          # a permutation of the owned blocks
         first = 0
@@ -54,16 +77,22 @@ def test_every_face_reaches_each_of_its_blocks_once(dim, args, parts):
                     # the side the face lies on, seen from this block: the normal points away from the LEFT block
                     assert (bool((code >> 2) & 1) != is_right) == side
                     area = np.frombuffer(w[2:4].tobytes(), np.float64)[0]
-                    got.setdefault((e, d, side), []).append((int(w[0]), is_right, area, bool((code >> 3) & 1)))
+                    other = int(w[0]) // S if w[0] >= 0 else int(w[0])
+                    got.setdefault((e, d, side), []).append((other, is_right, area, bool((code >> 3) & 1)))
                     assert not (is_right and (code >> 3) & 1)               # the coarse side of a hanging face is never folded
+                    lr = (other, e) if is_right else (e, other)
+                    check_cells(w, is_right, d, bool((code >> 2) & 1), bool((code >> 3) & 1),
+                                anchor_of.get((lr[0], lr[1], d, bool((code >> 2) & 1)), [0, 0, 0]))
             for j in range(first, first + nbf):
                 w = bf_rec[j]
                 code = int(w[1])
                 is_right = bool((code >> 12) & 1)
                 side = bool((code >> 2) & 1) != is_right
                 area = np.frombuffer(w[2:4].tobytes(), np.float64)[0]
-                got.setdefault((e, code & 3, side), []).append((int(w[0]), is_right, area, bool((code >> 3) & 1)))
+                other = int(w[0]) // S
+                got.setdefault((e, code & 3, side), []).append((other, is_right, area, bool((code >> 3) & 1)))
                 assert is_right and (code >> 3) & 1                          # generic rows: towards finer blocks only
+                check_cells(w, True, code & 3, bool((code >> 2) & 1), True, anchor_of[(other, e, code & 3, bool((code >> 2) & 1))])
             first += nbf
         assert first == plan.n_entries
         assert set(got) == set(want)
