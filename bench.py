@@ -42,6 +42,8 @@ WORKLOADS = {
     # c5p = conforming prisms + hexahedra on a curved shell sector (5 / 6 faces, a different oblique normal on every
     # face: the mesh class of the reference's own example, examples/compressible_euler/main.cu:20-24).
     "c5": dict(kind="plain", dim=3, base=6, lmax=8, band=0.05, dtype="f64", desc="3D hex AMR levels 6-8 (~3.93 M elements), geometry-synthetic"),
+    # (diagnostic: the uniform 3D case -- 6 faces per element, one geometry per direction)
+    "c5u": dict(kind="plain", dim=3, base=7, lmax=7, band=0.0, dtype="f64", desc="3D hex uniform 128^3 (~2.10 M elements), geometry-synthetic"),
     "c5p": dict(kind="plain", dim=3, prism=(128, 128, 160), dtype="f64",
                 desc="3D prisms + hexahedra on a curved shell, 128x128x160 cells half split (~3.93 M elements), geometry-synthetic"),
     # c5t = mixed tetrahedra / hexahedra (4 faces / 6-12 faces where the two kinds meet), curved shell, walls

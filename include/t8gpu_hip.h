@@ -375,7 +375,9 @@ enum {
   T8GPU_PROBE_LOG = 3,
   T8GPU_PROBE_LN_MEAN = 4,    /* fast tier: from the two values and the difference of their logs */
   T8GPU_PROBE_LN_MEAN_REF = 5, /* compat tier: the reference formula, IEEE division and library log */
-  T8GPU_PROBE_LOG_TAB = 6      /* the table-driven fp64 log of the plain tile kernels (fp32: same as LOG) */
+  T8GPU_PROBE_LOG_TAB = 6,     /* the table-driven fp64 log of the plain tile kernels (fp32: same as LOG) */
+  T8GPU_PROBE_SQRT_RATIO = 7,  /* sqrt(a / b) through one reciprocal square root (the sound speed of the KEPES flux) */
+  T8GPU_PROBE_DIV_SHARED = 8   /* a / b from a reciprocal that several quotients share */
 };
 int t8gpu_hip_math_probe_f32(int op, int n, const float* a, const float* b, float* out, void* stream);
 int t8gpu_hip_math_probe_f64(int op, int n, const double* a, const double* b, double* out, void* stream);

@@ -339,6 +339,31 @@ T8_DEV double t8_div(double a, double b) {
   return __builtin_fma(__builtin_fma(-b, q, a), r, q);
 }
 
+// A reciprocal that serves SEVERAL quotients with the same denominator, and the quotient from it (fp64: residual step as
+// in t8_div; one v_rcp_f64 = 16 issue cycles, four times a DP multiply -- scripts/microbench/valu_rate.hip).
+T8_DEV float  t8_rcp_shared(float b) { return __builtin_amdgcn_rcpf(b); }
+T8_DEV double t8_rcp_shared(double b) {
+  const double r = __builtin_amdgcn_rcp(b);
+  return __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+}
+T8_DEV float  t8_div_by(float a, float /*b*/, float rb) { return a * rb; }
+T8_DEV double t8_div_by(double a, double b, double rb) {
+  const double q = a * rb;
+  return __builtin_fma(__builtin_fma(-b, q, a), rb, q);
+}
+// sqrt(y / x) = y * rsqrt(y * x) for x, y > 0 (normal range): one v_rsq instead of a division and a square root
+T8_DEV float t8_sqrt_ratio(float y, float x) { return y * __builtin_amdgcn_rsqf(y * x); }
+T8_DEV double t8_sqrt_ratio(double y, double x) {
+  const double z  = y * x;
+  const double r0 = __builtin_amdgcn_rsq(z);
+  const double g  = z * r0;                              // ~ sqrt(z)
+  double       h  = 0.5 * r0;                            // ~ 1 / (2 sqrt(z)); one Goldschmidt step -> ~2^-51
+  h               = __builtin_fma(h, __builtin_fma(-h, g, 0.5), h);
+  const double a  = (y + y) * h;                         // y / sqrt(y x)
+  const double d  = __builtin_fma(-a, a * x, y);         // residual y - a^2 x; 1 / (2 a x) = h
+  return __builtin_fma(d, h, a);
+}
+
 // log for the fast tier (x > 0, normal range). fp64: the library routine is ~95 VALU instructions (special
 // cases, double-double reduction); per element and stage two of them dominated the per-cell work. This
 // is the classic reduction x = m 2^e, m in [sqrt(1/2), sqrt(2)), log m = 2 atanh(s), s = (m-1)/(m+1), with
@@ -431,11 +456,33 @@ T8_DEV double ln_mean_dlog(double aL, double aR, double dlog) {
   const double den = small ? t8_fma(u, t8_fma(u, t8_fma(u, 15.0, 21.0), 35.0), 105.0) : dlog;
   return t8_div(num, den);
 }
+// the same with s = aR + aL and its (shared) reciprocal handed in
+T8_DEV double ln_mean_dlog_rs(double aL, double aR, double dlog, double s, double rs) {
+#pragma clang fp contract(off)
+  const double d = aR - aL;
+  const double f = t8_div_by(d, s, rs);
+  const double u = f * f;
+  const bool   small = u < 1.0e-4;
+  const double num = small ? s * 52.50 : d;
+  const double den = small ? t8_fma(u, t8_fma(u, t8_fma(u, 15.0, 21.0), 35.0), 105.0) : dlog;
+  return t8_div(num, den);
+}
 // fp32: a difference of stored logs would cost accuracy near the branch switch; v_log_f32 is cheap.
 T8_DEV float ln_mean_dlog(float aL, float aR, float /*dlog*/) {
 #pragma clang fp contract(off)
   const float d = aR - aL, s = aR + aL;
   const float f = t8_div(d, s);
+  const float u = f * f;
+  const bool  small = u < 1.0e-4f;
+  const float num = small ? s * 52.50f : d;
+  const float den = small ? t8_fma(u, t8_fma(u, t8_fma(u, 15.0f, 21.0f), 35.0f), 105.0f) : t8_log_fast(t8_div(aR, aL));
+  return t8_div(num, den);
+}
+
+T8_DEV float ln_mean_dlog_rs(float aL, float aR, float /*dlog*/, float s, float rs) {
+#pragma clang fp contract(off)
+  const float d = aR - aL;
+  const float f = d * rs;
   const float u = f * f;
   const bool  small = u < 1.0e-4f;
   const float num = small ? s * 52.50f : d;
@@ -451,18 +498,18 @@ T8_DEV void kepes_core(const Prim<T>& L, const Prim<T>& R, T uL, T vL, T wL, T u
 #pragma clang fp contract(off)
   const T one = T(1), half = T(0.5), kappa = T(1.4);
   const T km1 = kappa - one, skm1 = one / km1, ikappa = one / kappa;
-  const T qL = half * t8_fma(uL, uL, t8_fma(vL, vL, wL * wL));
-  const T qR = half * t8_fma(uR, uR, t8_fma(vR, vR, wR * wR));
+  // (|vL|^2 + |vR|^2) / 2 as ONE scaling of the sum: halving is exact, so this is the sum of the two halves bit for bit
+  const T q2 = half * (t8_fma(uL, uL, t8_fma(vL, vL, wL * wL)) + t8_fma(uR, uR, t8_fma(vR, vR, wR * wR)));
 
+  const T bsum = L.beta + R.beta, rbs = t8_rcp_shared(bsum);   // serves the log mean of beta and the pressure mean
   const T rho  = ln_mean_dlog(L.rho, R.rho, R.lrho - L.lrho);
-  const T bhat = ln_mean_dlog(L.beta, R.beta, R.lbeta - L.lbeta);
+  const T bhat = ln_mean_dlog_rs(L.beta, R.beta, R.lbeta - L.lbeta, bsum, rbs);
   const T ib   = t8_rcp(bhat);
   const T rho_mean = half * (L.rho + R.rho);
   const T u = half * (uL + uR), v = half * (vL + vR), w = half * (wL + wR);
-  const T a  = t8_sqrt_fast(t8_div(kappa * half * (L.p + R.p), rho));
+  const T a  = t8_sqrt_ratio(kappa * half * (L.p + R.p), rho);
   const T h  = t8_fma(kappa / (T(2) * km1), ib, half * t8_fma(uL, uR, t8_fma(vL, vR, wL * wR)));
-  const T p1 = t8_div(rho_mean, L.beta + R.beta);
-  const T q2 = qL + qR;
+  const T p1 = t8_div_by(rho_mean, bsum, rbs);
 
   const T Fs0 = rho * u;
   const T Fs1 = t8_fma(Fs0, u, p1);
@@ -473,10 +520,11 @@ T8_DEV void kepes_core(const Prim<T>& L, const Prim<T>& R, T uL, T vL, T wL, T u
   speed = t8_abs(u) + a;
 
   const T au = t8_abs(u);
-  const T D0 = half * t8_abs(u - a) * rho * ikappa;
-  const T D1 = au * (km1 * ikappa) * rho;
+  const T ra = rho * (half * ikappa), re = rho * (km1 * ikappa);   // |lambda| rho / (2 gamma), |lambda| rho (gamma - 1) / gamma
+  const T D0 = t8_abs(u - a) * ra;
+  const T D1 = au * re;
   const T D2 = au * p1;
-  const T D4 = half * t8_abs(u + a) * rho * ikappa;
+  const T D4 = t8_abs(u + a) * ra;
 
   const T rpL = L.beta + L.beta, rpR = R.beta + R.beta;
   const T J0 = R.v0 - L.v0;

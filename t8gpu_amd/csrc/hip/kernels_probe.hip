@@ -19,6 +19,8 @@ __global__ void k_math_probe(int op, int n, const T* __restrict__ a, const T* __
     case T8GPU_PROBE_SQRT: r = t8_sqrt_fast(x); break;
     case T8GPU_PROBE_LOG: r = t8_log_fast(x); break;
     case T8GPU_PROBE_LOG_TAB: r = t8_log_tab(x, kLogTab); break;   // (the tile kernels read an LDS copy of the table)
+    case T8GPU_PROBE_SQRT_RATIO: r = t8_sqrt_ratio(x, y); break;
+    case T8GPU_PROBE_DIV_SHARED: r = t8_div_by(x, y, t8_rcp_shared(y)); break;
     case T8GPU_PROBE_LN_MEAN: r = ln_mean_dlog(x, y, t8_log_fast(y) - t8_log_fast(x)); break;
     case T8GPU_PROBE_LN_MEAN_REF: r = ln_mean_ref<T>(x, y); break;
     default: r = T(0); break;
@@ -28,7 +30,7 @@ __global__ void k_math_probe(int op, int n, const T* __restrict__ a, const T* __
 
 template <class T>
 int math_probe(int op, int n, const T* a, const T* b, T* out, void* stream) {
-  if (op < 0 || op > T8GPU_PROBE_LOG_TAB || n < 0 || !a || !out) return static_cast<int>(hipErrorInvalidValue);
+  if (op < 0 || op > T8GPU_PROBE_DIV_SHARED || n < 0 || !a || !out) return static_cast<int>(hipErrorInvalidValue);
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_math_probe<T>, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), op, n, a, b, out);
   return static_cast<int>(hipGetLastError());

@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-RCP, DIV, SQRT, LOG, LN_MEAN, LN_MEAN_REF, LOG_TAB = range(7)
+RCP, DIV, SQRT, LOG, LN_MEAN, LN_MEAN_REF, LOG_TAB, SQRT_RATIO, DIV_SHARED = range(9)
 
 
 def probe(op, a, b=None):
@@ -38,6 +38,10 @@ def test_division_sqrt_within_ulps(dtype, limit):
     assert ulps(probe(DIV, a, b), exact_div.astype(dtype)).max() <= limit
     assert ulps(probe(RCP, b), (1 / b.astype(np.longdouble)).astype(dtype)).max() <= limit
     assert ulps(probe(SQRT, b), np.sqrt(b.astype(np.longdouble)).astype(dtype)).max() <= limit
+    assert ulps(probe(DIV_SHARED, a, b), exact_div.astype(dtype)).max() <= limit
+    c = np.exp(rng.uniform(-12, 12, 200000)).astype(dtype)
+    ratio = np.sqrt(c.astype(np.longdouble) / b.astype(np.longdouble))
+    assert ulps(probe(SQRT_RATIO, c, b), ratio.astype(dtype)).max() <= limit + 1.0
 
 
 @pytest.mark.parametrize("dtype,k,op", [(np.float64, 1.5, LOG), (np.float32, 4.0, LOG),   # fp32: hardware log2 x ln 2
