@@ -19,6 +19,7 @@ run --workload c3q --dtype f64
 run --workload c5
 run --workload c5p
 run --workload c5t
+run --workload c5u
 run --workload c5a --steps 60
 python3 - "$OUT" <<'PY'
 import json, sys

@@ -71,7 +71,9 @@ def main(out):
         for k in dom:
             gui = mean(k, "GRBM_GUI_ACTIVE") / 8.0
             if gui > 0:
-                busy.append(mean(k, "SQ_ACTIVE_INST_VALU") * 4.0 / 1024.0 / gui)
+                # (the counter ticks in quad-cycles: an fp32 instruction that occupies the VALU for 2 cycles still counts
+                #  one tick, so fp32 kernels read high -- capped at 1; fp64 instructions take the full 4 cycles or more)
+                busy.append(min(1.0, mean(k, "SQ_ACTIVE_INST_VALU") * 4.0 / 1024.0 / gui))
             if mean(k, "SQ_LDS_IDX_ACTIVE") > 0:
                 confl.append(mean(k, "SQ_LDS_BANK_CONFLICT") / mean(k, "SQ_LDS_IDX_ACTIVE"))
         with open(os.path.join(out, "traffic.json"), "w") as fjs:

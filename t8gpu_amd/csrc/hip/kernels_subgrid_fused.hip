@@ -472,7 +472,8 @@ int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, int b
   constexpr bool early = sizeof(T) == 4;
   // 32-bit byte offsets into the state planes when every plane (owned + ghost blocks) is shorter than 4 GiB
   const int64_t cells = static_cast<int64_t>(plan->n_blocks_addressed) * (plan->rank == 3 ? 64 : 16);
-  const bool    wide  = plan->n_blocks_addressed <= 0 || cells * static_cast<int64_t>(sizeof(T)) >= (int64_t(1) << 32);
+  static const bool force_wide = std::getenv("T8GPU_SG_WIDE") && std::getenv("T8GPU_SG_WIDE")[0] == '1';   // (tests)
+  const bool    wide  = force_wide || plan->n_blocks_addressed <= 0 || cells * static_cast<int64_t>(sizeof(T)) >= (int64_t(1) << 32);
 #define T8_SG(K, S, R)                                                                                                          \
   do {                                                                                                                          \
     if (wide)                                                                                                                   \

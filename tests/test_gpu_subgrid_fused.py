@@ -88,3 +88,40 @@ def test_long_run_stays_physical_and_conservative(kind):
         assert float((m - m0 * (0.33333333333333 + 0.66666666666666) ** steps).abs().max()) < 2.3e-16 * steps * float(m0.abs().max())
         assert e >= e_prev - 1e-12 * abs(e_prev)
         e_prev = e
+
+
+_ADDRESSING_CHILD = """
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from _gpu import perturbed_state
+from t8gpu_amd.solver import SubgridSolver
+from t8gpu_amd.synth import SynthMesh
+out = []
+for dim, args in ((3, dict(base_level=3, max_level=4, band=0.03, periodic=False)), (2, dict(base_level=3, max_level=6, band=0.03))):
+    mesh = SynthMesh(dim, **args)
+    part = mesh.partition(subgrid=True)
+    for dtype in (torch.float32, torch.float64):
+        g = SubgridSolver(part, dtype, mode="fused", state=perturbed_state(part, 7))
+        for _ in range(3):
+            g.iterate(0.1 * 2.0 ** -(mesh.finest_level + 2))
+        out.append(g.state().double().cpu().numpy().ravel())
+np.save(sys.argv[1], np.concatenate(out))
+"""
+
+
+def test_32_bit_and_64_bit_plane_addressing_agree_bitwise(tmp_path):
+    """The block kernel addresses planes shorter than 4 GiB by 32-bit byte offsets; the 64-bit form (T8GPU_SG_WIDE=1,
+    what a larger rank gets) must give the same bits. Child processes: the switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    script = tmp_path / "child.py"
+    script.write_text(_ADDRESSING_CHILD.format(root=os.path.dirname(here), tests=here))
+    res = []
+    for wide in ("0", "1"):
+        out = tmp_path / f"state_{wide}.npy"
+        subprocess.run([sys.executable, str(script), str(out)], env=dict(os.environ, T8GPU_SG_WIDE=wide), check=True, timeout=300)
+        res.append(np.load(out))
+    assert np.isfinite(res[0]).all()
+    assert np.array_equal(res[0], res[1])
