@@ -299,11 +299,23 @@ namespace t8gpu::hip {
       std::vector<int32_t> block_rec(32 * static_cast<size_t>(std::max<int32_t>(1, m.num_local_elements))),
           bf_rec(4 * static_cast<size_t>(std::max<int64_t>(1, sz[0])));
       t8gpu_plan_subgrid_records(h, m.face_surfaces.data(), static_cast<int>(sizeof(ft)), block_rec.data(), bf_rec.data());
+      std::vector<int32_t> fam_rec(160 * static_cast<size_t>(std::max<int64_t>(1, sz[6]))), rest_rec(32 * static_cast<size_t>(std::max<int64_t>(1, sz[7])));
+      if (sz[6] > 0) t8gpu_plan_subgrid_family_records(h, m.face_surfaces.data(), static_cast<int>(sizeof(ft)), fam_rec.data(), rest_rec.data());
       t8gpu_plan_subgrid_destroy(h);
       T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_block_rec, sizeof(int32_t) * block_rec.size()));
       T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_bf_rec, sizeof(int32_t) * bf_rec.size()));
       T8GPU_CUDA_CHECK_ERROR(hipMemcpy(m_block_rec, block_rec.data(), sizeof(int32_t) * block_rec.size(), hipMemcpyHostToDevice));
       T8GPU_CUDA_CHECK_ERROR(hipMemcpy(m_bf_rec, bf_rec.data(), sizeof(int32_t) * bf_rec.size(), hipMemcpyHostToDevice));
+      if (sz[6] > 0) {
+        T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_fam_rec, sizeof(int32_t) * fam_rec.size()));
+        T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_rest_rec, sizeof(int32_t) * rest_rec.size()));
+        T8GPU_CUDA_CHECK_ERROR(hipMemcpy(m_fam_rec, fam_rec.data(), sizeof(int32_t) * fam_rec.size(), hipMemcpyHostToDevice));
+        T8GPU_CUDA_CHECK_ERROR(hipMemcpy(m_rest_rec, rest_rec.data(), sizeof(int32_t) * rest_rec.size(), hipMemcpyHostToDevice));
+        m_plan.fam_rec    = m_fam_rec;
+        m_plan.rest_rec   = m_rest_rec;
+        m_plan.n_families = static_cast<int32_t>(sz[6]);
+        m_plan.n_rest     = static_cast<int32_t>(sz[7]);
+      }
       m_plan.block_rec = m_block_rec;
       m_plan.bf_rec    = m_bf_rec;
       m_plan.num_elements = m.num_local_elements;
@@ -316,6 +328,8 @@ namespace t8gpu::hip {
     ~SubgridFusedPlan() {
       (void)hipFree(m_block_rec);
       (void)hipFree(m_bf_rec);
+      (void)hipFree(m_fam_rec);
+      (void)hipFree(m_rest_rec);
     }
     SubgridFusedPlan(SubgridFusedPlan const&)            = delete;
     SubgridFusedPlan& operator=(SubgridFusedPlan const&) = delete;
@@ -323,7 +337,7 @@ namespace t8gpu::hip {
 
    private:
     T8gpuSubgridPlan m_plan{};
-    int32_t *        m_block_rec = nullptr, *m_bf_rec = nullptr;
+    int32_t *        m_block_rec = nullptr, *m_bf_rec = nullptr, *m_fam_rec = nullptr, *m_rest_rec = nullptr;
   };
 
   /// SubgridCompressibleEulerSolver::iterate (examples/subgrid/solver.inl:152-266) after its std::swap: three fused

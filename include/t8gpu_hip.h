@@ -265,6 +265,13 @@ typedef struct T8gpuSubgridPlan {
   int32_t n_blocks_addressed;   /* 1 + the largest block index any record refers to (owned and ghost blocks; sizes[5] of
                                    t8gpu_plan_subgrid_sizes): lets the kernel use 32-bit byte offsets into the state planes
                                    when a plane is shorter than 4 GiB. 0 = unknown (64-bit addressing) */
+  /* optional (RANK 3, t8gpu_plan_subgrid_family_records()): 2x2x2 cubes of consecutive same-level blocks take the family
+   * kernel (one workgroup of 8 wavefronts per cube) when a launch covers the whole plan; the blocks outside every family
+   * then run through rest_rec. n_families = 0: every block through block_rec. */
+  const int32_t* fam_rec;       /* [n_families][160]: {first block, 0, 0, 0, 36 rows {far, code, area (2 words)}}: the 12
+                                   outward + faces, the 12 outward - faces, the 12 inner faces (layout: subgrid_plan.cpp) */
+  const int32_t* rest_rec;      /* [n_rest][32]: block_rec rows of the blocks outside every family */
+  int32_t n_families, n_rest;
 } T8gpuSubgridPlan;
 
 /* block_begin/block_count select a range of block_order (0, num_elements = everything; [0, n_interior_blocks)

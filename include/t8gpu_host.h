@@ -73,7 +73,7 @@ void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, c
                                 const double* normals);
 void  t8gpu_plan_subgrid_destroy(void* plan);
 /* sizes[8] = {n_entries, max faces per block, F + B, n_interior_blocks, n_deep_blocks, 1 + largest block index referred to
- * (owned and ghost blocks), 0, 0} */
+ * (owned and ghost blocks), n_families, n_rest} */
 void t8gpu_plan_subgrid_sizes(const void* plan, int64_t* sizes);
 /* block_order[N]: blocks that touch no ghost block first (they can run during the halo exchange) */
 void t8gpu_plan_subgrid_order(const void* plan, int32_t* block_order);
@@ -84,6 +84,9 @@ void t8gpu_plan_subgrid_arrays(const void* plan, int32_t* bf_off, int32_t* bf_en
  * block_rec[N][32] in block_order position order (128-byte rows, see T8gpuSubgridPlan), bf_rec[n_entries][4]; areas = face_surfaces[F + B] (doubles),
  * float_size = 4 or 8 selects how the areas are stored in the records. */
 void t8gpu_plan_subgrid_records(const void* plan, const double* areas, int float_size, int32_t* block_rec, int32_t* bf_rec);
+/* RANK 3: the 2x2x2 families of consecutive same-level blocks (sizes[6] of them) and the remaining blocks (sizes[7]):
+ * fam_rec[n_families][160], rest_rec[n_rest][32] (layout: csrc/host/subgrid_plan.cpp; T8gpuSubgridPlan::fam_rec / rest_rec) */
+void t8gpu_plan_subgrid_family_records(const void* plan, const double* areas, int float_size, int32_t* fam_rec, int32_t* rest_rec);
 
 /* ---- connectivity from forest queries (the t8code-independent part) -------------------------
  * What MeshManager::compute_connectivity_information (mesh_manager.inl:333-481) asks of t8code, as callbacks;

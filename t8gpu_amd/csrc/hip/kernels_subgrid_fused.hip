@@ -216,26 +216,36 @@ T8_DEV void load_far(const SVars<T>& src, bool on, bool wall, int far0, int hf, 
 
 // RANK 3: one Subgrid<4,4,4> block per wavefront. RANK 2: four Subgrid<4,4> blocks per wavefront
 // (16 lanes each; every index below is relative to the lane's own block).
-template <class T, int KIND, int STAGE, int RANK, bool EARLY_PREV, bool WIDE>
-__global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int block_begin, int block_count, SVars<T> prev,
-                                                      SVars<T> src, SVars<T> out, const T* __restrict__ volumes, T dt) {
+// Synchronisation between the rounds of ONE wavefront's LDS exchange. As a one-wavefront workgroup the block runs in
+// lock-step and the barrier is free; inside the family launch (eight wavefronts per workgroup, each on its own block and
+// its own LDS slice, different numbers of generic passes) it must not be a workgroup barrier: a wavefront-scope fence.
+template <bool WAVE_ONLY>
+T8_DEV void block_sync() {
+  if (WAVE_ONLY) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+
+// One wavefront's work on its block(s): `pos_base` = the wavefront's position in the launch (RANK 3: the block record;
+// RANK 2: four records), c = lane, pe / xb = the wavefront's LDS slices ([NW][64 + BPW * PF] cells of the block(s) then
+// the far cells of their + faces; [5][64] flux exchange buffer).
+template <class T, int KIND, int STAGE, int RANK, bool EARLY_PREV, bool WIDE, bool WAVE_ONLY>
+T8_DEV void subgrid_block(const T8gpuSubgridPlan& P, int block_begin, int block_count, int pos_base, int c, const SVars<T>& prev,
+                          const SVars<T>& src, const SVars<T>& out, const T* __restrict__ volumes, T dt, T* pe, T* xb) {
+  // (pe / xb carry no __restrict__: other lanes write what this lane reads, and a no-alias pointer would let the
+  //  compiler keep values across the synchronisation points)
   constexpr int NW  = CellData<T, KIND>::words;
   constexpr int S   = RANK == 3 ? 64 : 16;  // cells per block
   constexpr int SF  = RANK == 3 ? 16 : 4;   // sub-faces per coarse face
   constexpr int BPW = 64 / S;               // blocks per wavefront
   constexpr int PF  = RANK * SF;            // far cells of a block's + faces
-  __shared__ T  pe[NW][64 + BPW * PF];  // cells of the wave's block(s), then the far cells of their + faces
-  __shared__ T  xb[5][64];   // flux exchange buffer (+ passes: per cell; generic passes: [slot * SF + sub-face])
-  const int    c    = threadIdx.x;
+  constexpr int PEL = 64 + BPW * PF;        // row length of pe
   const int    base = (c / S) * S, cl = c - base;
-  // RANK 3: the block index is wave-uniform -- say so explicitly (blockIdx arithmetic only), so that the
-  // per-block loads (volume, face lists, face records) stay scalar loads and their branches scalar branches
-#ifdef T8GPU_EXP_TILEMOD   // experiment builds only: every wavefront works on one of the first few blocks (no HBM traffic)
-  const int    pos  = RANK == 3 ? sg_xcd_position(blockIdx.x, gridDim.x) % T8GPU_EXP_TILEMOD
-                                : (sg_xcd_position(blockIdx.x, gridDim.x) % T8GPU_EXP_TILEMOD) * BPW + c / S;
-#else
-  const int    pos  = RANK == 3 ? sg_xcd_position(blockIdx.x, gridDim.x) : sg_xcd_position(blockIdx.x, gridDim.x) * BPW + c / S;
-#endif
+  const int    pos  = RANK == 3 ? pos_base : pos_base * BPW + c / S;
   const bool   live = pos < block_count;
   // ONE dependent level: the block's joined record (64 bytes; four scalar loads for RANK 3) names the block, its
   // generic face list and the far block, code and area of its three + faces
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
 
   const CellData<T, KIND> mine = cell_from_state<T, KIND>(s0);
 #pragma unroll
-  for (int w = 0; w < NW; w++) pe[w][c] = mine.v[w];
+  for (int w = 0; w < NW; w++) pe[(w) * PEL + (c)] = mine.v[w];
 #ifdef T8GPU_EXP_NOFAR
   if (false) {
 #else
@@ -310,9 +320,9 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
 #endif
     const CellData<T, KIND> far = cell_from_state<T, KIND>(pfar);
 #pragma unroll
-    for (int w = 0; w < NW; w++) pe[w][64 + (c / S) * PF + cl] = far.v[w];
+    for (int w = 0; w < NW; w++) pe[(w) * PEL + (64 + (c / S) * PF + cl)] = far.v[w];
   }
-  __syncthreads();
+  block_sync<WAVE_ONLY>();
 
   T acc[5] = {T(0), T(0), T(0), T(0), T(0)};
 
@@ -329,19 +339,19 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
     const int  oidx = inner ? c + str : (wall ? c : 64 + (c / S) * PF + d * SF + tsub);
     CellData<T, KIND> other;
 #pragma unroll
-    for (int w = 0; w < NW; w++) other.v[w] = pe[w][oidx];
+    for (int w = 0; w < NW; w++) other.v[w] = pe[(w) * PEL + (oidx)];
     const T    ar   = inner ? surface : pl.area / T(SF);
     T g[5] = {T(0), T(0), T(0), T(0), T(0)};
     if (inner || pl.on) cell_flux<T, KIND>(mine, other, wall, d, true, ar, g);   // left = this cell, normal +e_d
-    __syncthreads();
+    block_sync<WAVE_ONLY>();
 #pragma unroll
-    for (int k = 0; k < 5; k++) xb[k][c] = g[k];
-    __syncthreads();
+    for (int k = 0; k < 5; k++) xb[(k) * 64 + (c)] = g[k];
+    block_sync<WAVE_ONLY>();
 #pragma unroll
     for (int k = 0; k < 5; k++) acc[k] -= g[k];
     if (cc[d] > 0) {
 #pragma unroll
-      for (int k = 0; k < 5; k++) acc[k] += xb[k][c - str];
+      for (int k = 0; k < 5; k++) acc[k] += xb[(k) * 64 + (c - str)];
     }
   }
 
@@ -353,23 +363,23 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
     if (m_on) {
       CellData<T, KIND> here;
 #pragma unroll
-      for (int w = 0; w < NW; w++) here.v[w] = pe[w][base + mflat];
+      for (int w = 0; w < NW; w++) here.v[w] = pe[(w) * PEL + (base + mflat)];
       const CellData<T, KIND> there = cell_from_state<T, KIND>(mfar);
       cell_flux<T, KIND>(there, here, m_wall, pd, !m_wall, m_area / T(SF), g);
       const T sgn = m_wall ? T(-1) : T(1);
 #pragma unroll
       for (int k = 0; k < 5; k++) g[k] *= sgn;
     }
-    __syncthreads();
+    block_sync<WAVE_ONLY>();
 #pragma unroll
-    for (int k = 0; k < 5; k++) xb[k][c] = g[k];
-    __syncthreads();
+    for (int k = 0; k < 5; k++) xb[(k) * 64 + (c)] = g[k];
+    block_sync<WAVE_ONLY>();
 #pragma unroll
     for (int d = 0; d < RANK; d++) {
       const int tsub = d == 0 ? cc[1] + 4 * cc[2] : (d == 1 ? cc[0] + 4 * cc[2] : cc[0] + 4 * cc[1]);
       if (cc[d] == 0) {
 #pragma unroll
-        for (int k = 0; k < 5; k++) acc[k] += xb[k][base + d * SF + tsub];
+        for (int k = 0; k < 5; k++) acc[k] += xb[(k) * 64 + (base + d * SF + tsub)];
       }
     }
   }
@@ -381,7 +391,7 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
     if (fl.active) {
       CellData<T, KIND> here, there;
 #pragma unroll
-      for (int w = 0; w < NW; w++) here.v[w] = pe[w][base + fl.myflat];
+      for (int w = 0; w < NW; w++) here.v[w] = pe[(w) * PEL + (base + fl.myflat)];
       there = fl.wall ? here : cell_from_state<T, KIND>(fl.sf);
       // geometric orientation: the low-side cell is the left one (walls: this cell, outward normal)
       const bool low = fl.wall || (fl.right != (fl.positive != 0));
@@ -397,10 +407,10 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
 #pragma unroll
       for (int k = 0; k < 5; k++) g[k] *= sgn;
     }
-    __syncthreads();
+    block_sync<WAVE_ONLY>();
 #pragma unroll
-    for (int k = 0; k < 5; k++) xb[k][c] = g[k];
-    __syncthreads();
+    for (int k = 0; k < 5; k++) xb[(k) * 64 + (c)] = g[k];
+    block_sync<WAVE_ONLY>();
     // every cell collects the sub-face fluxes that end on it, slot by slot (list order)
     for (int s = 0; s < 4; s++) {
       if (p0 + s < nbf) {
@@ -412,14 +422,14 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
           if (ca == (fc.positive ? 3 : 0)) {
             const int q = q0 + ci + 4 * cj;
 #pragma unroll
-            for (int k = 0; k < 5; k++) acc[k] += xb[k][q];
+            for (int k = 0; k < 5; k++) acc[k] += xb[(k) * 64 + (q)];
           }
         } else if (ca == fc.off(fc.axis)) {
           const int di = ci - fc.off(fc.ta()), dj = RANK == 3 ? cj - fc.off(fc.tb()) : 0;
           if (!fc.hanging) {
             const int q = q0 + di + 4 * dj;
 #pragma unroll
-            for (int k = 0; k < 5; k++) acc[k] += xb[k][q];
+            for (int k = 0; k < 5; k++) acc[k] += xb[(k) * 64 + (q)];
           } else if (di >= 0 && di < 2 && dj >= 0 && dj < 2) {
 #pragma unroll
             for (int jj = 0; jj < (RANK == 3 ? 2 : 1); jj++)
@@ -427,7 +437,7 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
               for (int ii = 0; ii < 2; ii++) {
                 const int q = q0 + (2 * di + ii) + (RANK == 3 ? 4 * (2 * dj + jj) : 0);
 #pragma unroll
-                for (int k = 0; k < 5; k++) acc[k] += xb[k][q];
+                for (int k = 0; k < 5; k++) acc[k] += xb[(k) * 64 + (q)];
               }
           }
         }
@@ -451,6 +461,189 @@ __global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int bl
   }
 }
 
+
+// RANK 3: one Subgrid<4,4,4> block per wavefront. RANK 2: four Subgrid<4,4> blocks per wavefront
+// (16 lanes each; every index is relative to the lane's own block).
+template <class T, int KIND, int STAGE, int RANK, bool EARLY_PREV, bool WIDE>
+__global__ __launch_bounds__(64) void k_subgrid_fused(T8gpuSubgridPlan P, int block_begin, int block_count, SVars<T> prev,
+                                                      SVars<T> src, SVars<T> out, const T* __restrict__ volumes, T dt) {
+  constexpr int NW = CellData<T, KIND>::words;
+  constexpr int PEL = 64 + (RANK == 3 ? 1 : 4) * RANK * (RANK == 3 ? 16 : 4);
+  __shared__ T pe[NW * PEL];  // cells of the wave's block(s), then the far cells of their + faces
+  __shared__ T xb[5 * 64];    // flux exchange buffer (+ passes: per cell; generic passes: [slot * SF + sub-face])
+  // (RANK 3: the block index is wave-uniform -- blockIdx arithmetic only --, so the per-block loads (volume, face lists,
+  //  face records) stay scalar loads and their branches scalar branches)
+#ifdef T8GPU_EXP_TILEMOD   // experiment builds only: every wavefront works on one of the first few blocks (no HBM traffic)
+  const int pos_base = sg_xcd_position(blockIdx.x, gridDim.x) % T8GPU_EXP_TILEMOD;
+#else
+  const int pos_base = sg_xcd_position(blockIdx.x, gridDim.x);
+#endif
+  subgrid_block<T, KIND, STAGE, RANK, EARLY_PREV, WIDE, false>(P, block_begin, block_count, pos_base, threadIdx.x, prev, src, out, volumes,
+                                                               dt, pe, xb);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Family kernel (RANK 3): one workgroup of eight wavefronts = a 2x2x2 cube of consecutive same-level blocks
+// (subgrid_plan.cpp), wavefront w = block e0 + w at (w & 1, w >> 1 & 1, w >> 2) of the cube. Against eight runs of the
+// block kernel:
+//   * the 12 inner coarse faces are evaluated ONCE, by the + pass of the block on their low side, from primitives that
+//     are already in LDS (no far-cell loads, no far-cell primitives); the block on the high side picks the flux up;
+//   * the far cells of the 24 outward faces are POOLED over the wavefronts: the 192 behind the + faces fill waves 0-2,
+//     the 192 behind the - faces waves 3-5 (which also evaluate those faces), instead of two 48-lane rounds per block.
+// Per cube: 8 + 6 primitive rounds instead of 24, 24 + 3 flux rounds instead of 32, two workgroup barriers. Every flux
+// has the arguments it has in the block kernel and every cell adds its faces in the same order (+x, +y, +z passes, then
+// the -x, -y, -z faces), so the two kernels agree bit for bit (tests/test_gpu_subgrid_fused.py).
+T8_DEV int fam_compact(int w, int d) { return d == 0 ? w >> 1 : (d == 1 ? (w & 1) | ((w >> 2) << 1) : w & 3); }   // drop bit d
+T8_DEV int fam_expand(int j, int d) { return d == 0 ? j << 1 : (d == 1 ? (j & 1) | ((j >> 1) << 2) : j); }      // zero bit at d
+
+// (second launch bound = wavefronts per SIMD the register allocation must allow: 3 workgroups per CU in fp32 (80 VGPRs),
+//  2 in fp64 (128 VGPRs; its 66 KB of LDS allow no more))
+template <class T, int KIND, int STAGE, bool WIDE>
+__global__ __launch_bounds__(512, sizeof(T) == 8 ? 2 : 6) void k_subgrid_family(T8gpuSubgridPlan P, SVars<T> prev, SVars<T> src, SVars<T> out,
+                                                        const T* __restrict__ volumes, T dt) {
+  constexpr int  NW    = CellData<T, KIND>::words;
+  constexpr bool EARLY = false;   // previous-step state fetched last: requested up front it costs registers the kernel does not have
+  constexpr int FAM_WORDS = NW * 704 + 3 * 5 * 64 + 5 * 192;       // this kernel's arrays
+  constexpr int BLK_WORDS = NW * 112 + 5 * 64;                      // one wavefront of the block algorithm
+  __shared__ T lds[FAM_WORDS > 8 * BLK_WORDS ? FAM_WORDS : 8 * BLK_WORDS];
+  const int tid = threadIdx.x, c = tid & 63;
+  const int w   = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the per-block reads below stay scalar
+  // The workgroups behind the cubes take the blocks outside every cube (the coarse side of 2:1 interfaces and their
+  // siblings: 4 % of c3), eight per workgroup, each wavefront on its own with the block algorithm and its own LDS slice.
+  // (As a second launch they cost 8 % of a stage -- ramp-up and tail of a small grid; on a side stream more: the fork /
+  //  join events keep the launches from running back to back.)
+  if (static_cast<int>(blockIdx.x) >= P.n_families) {
+    const int pos = (static_cast<int>(blockIdx.x) - P.n_families) * 8 + w;
+    if (pos < P.n_rest) {
+      T8gpuSubgridPlan R = P;
+      R.block_rec        = P.rest_rec;
+      T* const mine_lds  = lds + w * BLK_WORDS;
+      subgrid_block<T, KIND, STAGE, 3, sizeof(T) == 4, WIDE, true>(R, 0, P.n_rest, pos, c, prev, src, out, volumes, dt, mine_lds,
+                                                                  mine_lds + NW * 112);
+    }
+    return;
+  }
+  // primitives of the cube's cells [block * 64 + cell], then of the far cells behind the outward + faces
+  // [512 + (d * 4 + j) * 16 + sub-face]; fluxes through the inner coarse faces [d][k][j * 16 + sub-face] for the block on
+  // their high side; fluxes through the outward - faces [k][(d * 4 + j) * 16 + sub-face]
+  T(*const pown)[704]   = reinterpret_cast<T(*)[704]>(lds);
+  T(*const sfl)[5][64]  = reinterpret_cast<T(*)[5][64]>(lds + NW * 704);
+  T(*const mfl)[192]    = reinterpret_cast<T(*)[192]>(lds + NW * 704 + 3 * 5 * 64);
+  const int4* __restrict__ frec = reinterpret_cast<const int4*>(P.fam_rec) + 40 * (size_t)sg_xcd_position(blockIdx.x, P.n_families);
+  const int    e0 = frec[0].x;
+  const int    e  = e0 + w;
+  const int    cc[3] = {c & 3, (c >> 2) & 3, c >> 4};
+  const size_t o = (size_t)e * 64 + c;
+
+  T s0[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) s0[k] = at<WIDE>(src.p[k], o);
+  const T vol     = volumes[e];
+  const T edge    = t8_cbrt(vol) / T(4);
+  const T surface = edge * edge;
+
+  // ---- pooled far cells of the outward faces: waves 0-2 the + faces, waves 3-5 the - faces ---------------------------
+  const bool xp = w < 3, xm = w >= 3 && w < 6;
+  const int  xs = (xp || xm) ? (xp ? w : w - 3) * 64 + c : 0;   // slot 0..191 = (d * 4 + j) * 16 + sub-face
+  const int  xf = xs >> 4, xsub = xs & 15, xd = xf >> 2;  // face row, sub-face, axis
+  const int  xb = fam_expand(xf & 3, xd) | (xp ? 1 << xd : 0);   // the block of the cube that owns the face
+  const int  xla = xd == 0 ? 2 : 0, xlb = xd == 2 ? 2 : 4, xti = xsub & 3, xtj = xsub >> 2;
+  // its cell behind the sub-face: coordinate 3 (+ faces) or 0 (- faces) along the axis
+  const int  xcell = (xti << xla) + (xtj << xlb) + (xp ? 3 << (2 * xd) : 0);
+  const int4 xrow  = (xp || xm) ? frec[1 + xf + (xm ? 12 : 0)] : make_int4(-2, 0, 0, 0);
+  const bool x_on = xrow.x != -2, x_wall = xrow.x == -1;
+  T          xst[5];
+  // (a wall on the - side re-reads the cell itself, as in the block kernel; a wall on the + side needs no far cell)
+  load_far<T, WIDE>(src, x_on && (xm || !x_wall), x_wall, xrow.x, (xrow.y >> 19) & 1, xla, xlb, xti, xtj,
+                    (size_t)(e0 + xb) * 64 + xcell, xst);
+  T pv[5] = {T(0), T(0), T(0), T(0), T(0)};
+  if (STAGE > 1 && EARLY) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) pv[k] = at<WIDE>(prev.p[k], o);
+  }
+
+  const CellData<T, KIND> mine = cell_from_state<T, KIND>(s0);
+#pragma unroll
+  for (int q = 0; q < NW; q++) pown[q][tid] = mine.v[q];
+  CellData<T, KIND> there;
+#pragma unroll
+  for (int q = 0; q < NW; q++) there.v[q] = T(1);
+  if (x_on && (xm || !x_wall)) {
+    there = cell_from_state<T, KIND>(xst);
+    if (xp) {
+#pragma unroll
+      for (int q = 0; q < NW; q++) pown[q][512 + xs] = there.v[q];
+    }
+  }
+  __syncthreads();
+
+  T acc[5] = {T(0), T(0), T(0), T(0), T(0)};
+  // ---- + passes: inner faces, inner coarse faces (sibling on the high side), outward + faces ------------------------
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const int  str   = d == 0 ? 1 : (d == 1 ? 4 : 16);
+    const bool inner = cc[d] < 3;
+    const bool sib   = !((w >> d) & 1);                       // the +d neighbour block is in the cube
+    const int  j     = fam_compact(w, d);
+    const int4 row   = frec[1 + (sib ? 24 : 0) + d * 4 + j];  // the block's +d coarse face (wave-uniform)
+    const bool wall  = !inner && !sib && row.x == -1;
+    const int  tsub  = d == 0 ? cc[1] + 4 * cc[2] : (d == 1 ? cc[0] + 4 * cc[2] : cc[0] + 4 * cc[1]);
+    // the other cell: next lane's; the sibling's cell with coordinate 0; the pooled far cell; a wall mirrors this cell
+    const int  oidx = inner ? tid + str : (sib ? tid + 64 * (1 << d) - 3 * str : (wall ? tid : 512 + (d * 4 + j) * 16 + tsub));
+    CellData<T, KIND> other;
+#pragma unroll
+    for (int q = 0; q < NW; q++) other.v[q] = pown[q][oidx];
+    const T ar = inner ? surface : area_of(row.z, row.w, T(0)) / T(16);
+    T g[5];
+    cell_flux<T, KIND>(mine, other, wall, d, true, ar, g);   // left = this cell, normal +e_d
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      acc[k] -= g[k];
+      const T lower = __shfl_up(g[k], str, 64);               // the same face seen from the cell on its high side
+      if (cc[d] > 0) acc[k] += lower;
+    }
+    if (!inner && sib) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) sfl[d][k][j * 16 + tsub] = g[k];
+    }
+  }
+  // ---- outward - faces, pooled: left = the far cell (low side), normal +e_d; walls: left = the cell, outward normal ----
+  if (xm && x_on) {
+    CellData<T, KIND> here;
+#pragma unroll
+    for (int q = 0; q < NW; q++) here.v[q] = pown[q][xb * 64 + xcell];
+    T g[5];
+    cell_flux<T, KIND>(there, here, x_wall, xd, !x_wall, area_of(xrow.z, xrow.w, T(0)) / T(16), g);
+    const T sgn = x_wall ? T(-1) : T(1);
+#pragma unroll
+    for (int k = 0; k < 5; k++) mfl[k][xs] = g[k] * sgn;
+  }
+  __syncthreads();
+  // ---- every cell with coordinate 0 picks up its -d face: from the sibling's + pass or from the pooled round ----------
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    if (cc[d] == 0) {
+      const int tsub = d == 0 ? cc[1] + 4 * cc[2] : (d == 1 ? cc[0] + 4 * cc[2] : cc[0] + 4 * cc[1]);
+      const int j    = fam_compact(w, d);
+      if ((w >> d) & 1) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) acc[k] += sfl[d][k][j * 16 + tsub];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 5; k++) acc[k] += mfl[k][(d * 4 + j) * 16 + tsub];
+      }
+    }
+  }
+  // ---- RK stage ---------------------------------------------------------------------------------------------------------
+  if (STAGE > 1 && !EARLY) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) pv[k] = at<WIDE>(prev.p[k], o);
+  }
+  const T scale = dt / (vol / T(64));
+#pragma unroll
+  for (int k = 0; k < 5; k++) at<WIDE>(out.p[k], o) = rk_stage_update<T, STAGE>(pv[k], s0[k], scale, acc[k]);
+}
+
 template <class T, class V>
 SVars<T> smk(const V& v) {
   SVars<T> o;
@@ -466,7 +659,6 @@ int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, int b
   if (block_begin < 0 || block_count < 0 || block_begin + block_count > plan->num_elements) return static_cast<int>(hipErrorInvalidValue);
   if (block_count == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3  grid(plan->rank == 3 ? block_count : (block_count + 3) / 4), block(64);
   // fp32 requests the previous-step state up front (one round trip less per wavefront); fp64 keeps fetching it last:
   // it is bound by DP instruction issue and the 10 extra registers would cost it a wavefront per SIMD (measured both ways).
   constexpr bool early = sizeof(T) == 4;
@@ -474,31 +666,67 @@ int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, int b
   const int64_t cells = static_cast<int64_t>(plan->n_blocks_addressed) * (plan->rank == 3 ? 64 : 16);
   static const bool force_wide = std::getenv("T8GPU_SG_WIDE") && std::getenv("T8GPU_SG_WIDE")[0] == '1';   // (tests)
   const bool    wide  = force_wide || plan->n_blocks_addressed <= 0 || cells * static_cast<int64_t>(sizeof(T)) >= (int64_t(1) << 32);
-#define T8_SG(K, S, R)                                                                                                          \
-  do {                                                                                                                          \
-    if (wide)                                                                                                                   \
-      hipLaunchKernelGGL((k_subgrid_fused<T, K, S, R, early, true>), grid, block, 0, s, *plan, block_begin, block_count,        \
-                         smk<T>(prev), smk<T>(mid), smk<T>(out), volumes, dt);                                                  \
-    else                                                                                                                        \
-      hipLaunchKernelGGL((k_subgrid_fused<T, K, S, R, early, false>), grid, block, 0, s, *plan, block_begin, block_count,       \
-                         smk<T>(prev), smk<T>(mid), smk<T>(out), volumes, dt);                                                  \
+  // one launch of the block kernel over records `pl.block_rec[begin, begin + count)`
+  auto blocks = [&](const T8gpuSubgridPlan& pl, int begin, int count) {
+    const dim3 grid(pl.rank == 3 ? count : (count + 3) / 4), block(64);
+#define T8_SG(K, S, R)                                                                                                     \
+  do {                                                                                                                     \
+    if (wide)                                                                                                              \
+      hipLaunchKernelGGL((k_subgrid_fused<T, K, S, R, early, true>), grid, block, 0, s, pl, begin, count, smk<T>(prev),   \
+                         smk<T>(mid), smk<T>(out), volumes, dt);                                                           \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((k_subgrid_fused<T, K, S, R, early, false>), grid, block, 0, s, pl, begin, count, smk<T>(prev),  \
+                         smk<T>(mid), smk<T>(out), volumes, dt);                                                           \
   } while (0)
-#define T8_SGR(K, S)     \
-  do {                   \
-    if (plan->rank == 3) \
-      T8_SG(K, S, 3);    \
-    else                 \
-      T8_SG(K, S, 2);    \
+#define T8_SGR(K, S)  \
+  do {                \
+    if (pl.rank == 3) \
+      T8_SG(K, S, 3); \
+    else              \
+      T8_SG(K, S, 2); \
   } while (0)
-  if (kind == 0) {
-    if (stage == 1) T8_SGR(0, 1); else if (stage == 2) T8_SGR(0, 2); else T8_SGR(0, 3);
-  } else if (kind == 1) {
-    if (stage == 1) T8_SGR(1, 1); else if (stage == 2) T8_SGR(1, 2); else T8_SGR(1, 3);
-  } else {
-    if (stage == 1) T8_SGR(2, 1); else if (stage == 2) T8_SGR(2, 2); else T8_SGR(2, 3);
-  }
+    if (kind == 0) {
+      if (stage == 1) T8_SGR(0, 1); else if (stage == 2) T8_SGR(0, 2); else T8_SGR(0, 3);
+    } else if (kind == 1) {
+      if (stage == 1) T8_SGR(1, 1); else if (stage == 2) T8_SGR(1, 2); else T8_SGR(1, 3);
+    } else {
+      if (stage == 1) T8_SGR(2, 1); else if (stage == 2) T8_SGR(2, 2); else T8_SGR(2, 3);
+    }
 #undef T8_SGR
 #undef T8_SG
+  };
+  // A launch that covers the whole plan of a 3D mesh: 2x2x2 cubes of same-level blocks through the family kernel, the
+  // other blocks through the block kernel (T8GPU_SG_FAMILY=0: every block through the block kernel -- same bits).
+  // (measured where it pays: KEPES in fp32. fp64 and the HLL fluxes need more registers than three / two workgroups of
+  //  eight wavefronts per CU leave them and spill: T8GPU_SG_FAMILY=2 takes the family kernel for those too.)
+  static const int fam_env = std::getenv("T8GPU_SG_FAMILY") ? std::atoi(std::getenv("T8GPU_SG_FAMILY")) : 1;
+  const bool fam_off = fam_env == 0 || (fam_env == 1 && !(kind == 0 && sizeof(T) == 4));
+  const bool families = !fam_off && plan->rank == 3 && block_begin == 0 && block_count == plan->num_elements && plan->n_families > 0 &&
+                        plan->fam_rec && plan->rest_rec && plan->n_rest == plan->num_elements - 8 * plan->n_families;
+  if (!families) {
+    blocks(*plan, block_begin, block_count);
+    return static_cast<int>(hipGetLastError());
+  }
+  {
+    const dim3 grid(plan->n_families + (plan->n_rest + 7) / 8), block(512);
+#define T8_FM(K, S)                                                                                                          \
+  do {                                                                                                                       \
+    if (wide)                                                                                                                \
+      hipLaunchKernelGGL((k_subgrid_family<T, K, S, true>), grid, block, 0, s, *plan, smk<T>(prev), smk<T>(mid), smk<T>(out), \
+                         volumes, dt);                                                                                       \
+    else                                                                                                                     \
+      hipLaunchKernelGGL((k_subgrid_family<T, K, S, false>), grid, block, 0, s, *plan, smk<T>(prev), smk<T>(mid), smk<T>(out), \
+                         volumes, dt);                                                                                       \
+  } while (0)
+    if (kind == 0) {
+      if (stage == 1) T8_FM(0, 1); else if (stage == 2) T8_FM(0, 2); else T8_FM(0, 3);
+    } else if (kind == 1) {
+      if (stage == 1) T8_FM(1, 1); else if (stage == 2) T8_FM(1, 2); else T8_FM(1, 3);
+    } else {
+      if (stage == 1) T8_FM(2, 1); else if (stage == 2) T8_FM(2, 2); else T8_FM(2, 3);
+    }
+#undef T8_FM
+  }
   return static_cast<int>(hipGetLastError());
 }
 

@@ -26,6 +26,8 @@ namespace {
 struct SubgridPlan {
   int32_t N = 0, F = 0, B = 0, rank = 3, max_bf = 0, n_addressed = 0;
   std::vector<int32_t> bf_off, bf_ent, face_rec, plus, minus, block_order;  // block_order: interior blocks first
+  std::vector<int32_t> fam_first;   // first block of every 2x2x2 family (below)
+  std::vector<uint8_t> in_family;
   int32_t n_interior = 0, n_deep = 0;
 };
 }  // namespace
@@ -114,6 +116,45 @@ void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, c
     if (l < N && !folded_l[f]) P->bf_ent[cur[l]++] = f;
     if (r < N && r != l && !folded_r[f]) P->bf_ent[cur[r]++] = f | static_cast<int32_t>(0x80000000u);
   }
+  // 2x2x2 families (RANK 3): eight CONSECUTIVE owned blocks e .. e + 7 that form a cube in Morton order -- the +x / +y /
+  // +z neighbour of block e + w is block e + w + 1 / 2 / 4 at the same level wherever that bit of w is clear --, each of
+  // whose 24 outward sides is one foldable coarse face (same level, coarser neighbour or wall) and none of which has a
+  // generic face. One workgroup of the family kernel takes such a cube: the 12 inner coarse faces are evaluated once,
+  // from primitives that are already in LDS, and the far cells of the outward faces are pooled over the eight wavefronts.
+  P->in_family.assign(static_cast<size_t>(N), 0);
+  if (rank == 3) {
+    auto other_of = [&](int32_t ent, int32_t* hanging) {
+      const int32_t* rec = &P->face_rec[4 * static_cast<size_t>(ent & 0x7FFFFFFF)];
+      *hanging = (rec[2] >> 3) & 1;
+      return ent < 0 ? rec[0] : rec[1];
+    };
+    auto is_family = [&](int32_t e) {
+      for (int w = 0; w < 8; w++) {
+        const int32_t b = e + w;
+        if (P->bf_off[b + 1] != P->bf_off[b]) return false;
+        for (int d = 0; d < 3; d++) {
+          const int32_t pe = P->plus[static_cast<size_t>(b) * 3 + d], me = P->minus[static_cast<size_t>(b) * 3 + d];
+          if (pe == -1 || me == -1) return false;
+          int32_t hang = 0;
+          if (!((w >> d) & 1)) {
+            if (other_of(pe, &hang) != b + (1 << d) || hang) return false;
+          } else {
+            if (other_of(me, &hang) != b - (1 << d) || hang) return false;
+          }
+        }
+      }
+      return true;
+    };
+    for (int32_t e = 0; e + 8 <= N;) {
+      if (is_family(e)) {
+        P->fam_first.push_back(e);
+        for (int w = 0; w < 8; w++) P->in_family[e + w] = 1;
+        e += 8;
+      } else {
+        e++;
+      }
+    }
+  }
   // blocks whose faces all stay among owned blocks can run while the halo exchange is in flight
   std::vector<uint8_t> ghosty(static_cast<size_t>(N), 0);
   for (int32_t f = 0; f < F; f++) {
@@ -144,7 +185,8 @@ void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, c
 
 void t8gpu_plan_subgrid_destroy(void* h) { delete static_cast<SubgridPlan*>(h); }
 
-/* sizes[6] = {n_entries, max faces per block, F + B, n_interior_blocks, n_deep_blocks, 1 + largest block index referred to} */
+/* sizes[8] = {n_entries, max faces per block, F + B, n_interior_blocks, n_deep_blocks, 1 + largest block index referred to,
+ *             n_families, n_rest = blocks outside every family} */
 void t8gpu_plan_subgrid_sizes(const void* h, int64_t* sizes) {
   const SubgridPlan* P = static_cast<const SubgridPlan*>(h);
   sizes[0] = static_cast<int64_t>(P->bf_ent.size());
@@ -153,6 +195,8 @@ void t8gpu_plan_subgrid_sizes(const void* h, int64_t* sizes) {
   sizes[3] = P->n_interior;
   sizes[4] = P->n_deep;
   sizes[5] = P->n_addressed > P->N ? P->n_addressed : P->N;
+  sizes[6] = static_cast<int64_t>(P->fam_first.size());
+  sizes[7] = static_cast<int64_t>(P->N) - 8 * static_cast<int64_t>(P->fam_first.size());
 }
 
 void t8gpu_plan_subgrid_order(const void* h, int32_t* block_order) {
@@ -185,10 +229,9 @@ void t8gpu_plan_subgrid_arrays(const void* h, int32_t* bf_off, int32_t* bf_ent, 
 //   cell(i, j) = c0 + ((i >> h) << la) + ((j >> h) << lb)
 // on either side needs no decoding of the anchor; area = face_surfaces[f] as float (word 0) or double.
 // (32-bit cell indices: a rank holds fewer than 2^31 subcells including its ghost blocks.)
-void t8gpu_plan_subgrid_records(const void* h, const double* areas, int float_size, int32_t* block_rec, int32_t* bf_rec) {
-  const SubgridPlan* P = static_cast<const SubgridPlan*>(h);
+static void put_row(const SubgridPlan* P, const double* areas, int float_size, int32_t* dst, int32_t ent) {
   const int32_t S = P->rank == 3 ? 64 : 16;
-  auto put = [&](int32_t* dst, int32_t ent) {
+  {
     const int32_t  f     = ent & 0x7FFFFFFF;
     const bool     right = ent < 0;
     const int32_t* rec   = &P->face_rec[4 * static_cast<size_t>(f)];
@@ -212,7 +255,12 @@ void t8gpu_plan_subgrid_records(const void* h, const double* areas, int float_si
     } else {
       std::memcpy(&dst[2], &areas[f], 8);
     }
-  };
+  }
+}
+
+void t8gpu_plan_subgrid_records(const void* h, const double* areas, int float_size, int32_t* block_rec, int32_t* bf_rec) {
+  const SubgridPlan* P = static_cast<const SubgridPlan*>(h);
+  auto put = [&](int32_t* dst, int32_t ent) { put_row(P, areas, float_size, dst, ent); };
   int32_t first = 0;
   for (int32_t pos = 0; pos < P->N; pos++) {
     const int32_t e   = P->block_order[pos];
@@ -238,6 +286,56 @@ void t8gpu_plan_subgrid_records(const void* h, const double* areas, int float_si
       }
     }
     for (int32_t j = P->bf_off[e]; j < P->bf_off[e + 1]; j++) put(bf_rec + 4 * static_cast<size_t>(first++), P->bf_ent[j]);
+  }
+}
+
+
+// Family records (RANK 3; see t8gpu_plan_subgrid_create): fam_rec[n_families][160] =
+//   {first block, 0, 0, 0,
+//    12 rows for the outward + faces: row d * 4 + j = the +d face of the j-th block (ascending) that has bit d SET,
+//    12 rows for the outward - faces: row 12 + d * 4 + j = the -d face of the j-th block that has bit d CLEAR,
+//    12 rows for the inner coarse faces: row 24 + d * 4 + j = the +d face of the j-th block that has bit d CLEAR (only
+//    its area is read: the far cell is the sibling's, in LDS)}, rows as in block_rec: {far, code, area (2 words)};
+// rest_rec[n_rest][32] = the block_rec rows of the blocks outside every family, in block_order order (same bf_rec).
+void t8gpu_plan_subgrid_family_records(const void* h, const double* areas, int float_size, int32_t* fam_rec, int32_t* rest_rec) {
+  const SubgridPlan* P = static_cast<const SubgridPlan*>(h);
+  auto expand = [](int j, int d) { return d == 0 ? j << 1 : (d == 1 ? (j & 1) | ((j >> 1) << 2) : j); };   // a zero bit at d
+  for (size_t q = 0; q < P->fam_first.size(); q++) {
+    int32_t*      rec = fam_rec + 160 * q;
+    const int32_t e0  = P->fam_first[q];
+    std::memset(rec, 0, 160 * sizeof(int32_t));
+    rec[0] = e0;
+    for (int d = 0; d < 3; d++)
+      for (int j = 0; j < 4; j++) {
+        const int lo = expand(j, d), hi = lo | (1 << d);
+        put_row(P, areas, float_size, rec + 4 + 4 * (d * 4 + j), P->plus[static_cast<size_t>(e0 + hi) * 3 + d]);
+        put_row(P, areas, float_size, rec + 4 + 4 * (12 + d * 4 + j), P->minus[static_cast<size_t>(e0 + lo) * 3 + d]);
+        put_row(P, areas, float_size, rec + 4 + 4 * (24 + d * 4 + j), P->plus[static_cast<size_t>(e0 + lo) * 3 + d]);
+      }
+  }
+  // the remaining blocks keep their block records (and their rows of bf_rec: `first` counts every block's entries)
+  int32_t first = 0;
+  size_t  r     = 0;
+  for (int32_t pos = 0; pos < P->N; pos++) {
+    const int32_t e = P->block_order[pos];
+    const int32_t n = P->bf_off[e + 1] - P->bf_off[e];
+    if (!P->in_family[e]) {
+      int32_t* rec = rest_rec + 32 * r++;
+      std::memset(rec, 0, 128);
+      rec[0] = e;
+      rec[1] = n;
+      rec[2] = first;
+      for (int d = 0; d < 3; d++) {
+        int32_t *pd = rec + 4 + 4 * d, *md = rec + 16 + 4 * d;
+        pd[0] = md[0] = -2;
+        if (d < P->rank) {
+          const int32_t pe = P->plus[static_cast<size_t>(e) * P->rank + d], me = P->minus[static_cast<size_t>(e) * P->rank + d];
+          if (pe != -1) put_row(P, areas, float_size, pd, pe);
+          if (me != -1) put_row(P, areas, float_size, md, me);
+        }
+      }
+    }
+    first += n;
   }
 }
 

@@ -88,7 +88,8 @@ class PlainPlan:
 class T8gpuSubgridPlan(C.Structure):
     _fields_ = [("block_rec", C.c_void_p), ("bf_rec", C.c_void_p),
                 ("num_elements", C.c_int32), ("rank", C.c_int32), ("max_faces_per_block", C.c_int32),
-                ("n_interior_blocks", C.c_int32), ("n_deep_blocks", C.c_int32), ("n_blocks_addressed", C.c_int32)]
+                ("n_interior_blocks", C.c_int32), ("n_deep_blocks", C.c_int32), ("n_blocks_addressed", C.c_int32),
+                ("fam_rec", C.c_void_p), ("rest_rec", C.c_void_p), ("n_families", C.c_int32), ("n_rest", C.c_int32)]
 
 
 class SubgridPlan:
@@ -101,6 +102,10 @@ class SubgridPlan:
         block_rec, bf_rec = self.host.records(part.areas, 4 if dtype == torch.float32 else 8)
         self._keep = {"block_rec": torch.from_numpy(block_rec).cuda(), "bf_rec": torch.from_numpy(bf_rec).cuda()}
         c = T8gpuSubgridPlan()
+        if self.host.n_families > 0:
+            fam_rec, rest_rec = self.host.family_records(part.areas, 4 if dtype == torch.float32 else 8)
+            self._keep["fam_rec"], self._keep["rest_rec"] = torch.from_numpy(fam_rec).cuda(), torch.from_numpy(rest_rec).cuda()
+            c.n_families, c.n_rest = self.host.n_families, self.host.n_rest
         for k, t in self._keep.items():
             setattr(c, k, t.data_ptr())
         c.num_elements, c.rank, c.max_faces_per_block = part.N, part.mesh.dim, self.host.max_bf

@@ -100,6 +100,7 @@ class HostSubgridPlan:
         self.N, self.rank, self.max_bf, self.n_interior, self.n_deep = part.N, rank, int(sz[1]), int(sz[3]), int(sz[4])
         self.n_entries = int(sz[0])
         self.n_addressed = int(sz[5])     # 1 + largest block index any face refers to (owned and ghost blocks)
+        self.n_families, self.n_rest = int(sz[6]), int(sz[7])
         lib.t8gpu_plan_subgrid_order.argtypes = [C.c_void_p, C.c_void_p]
         self.block_order = np.zeros(part.N, np.int32)
         lib.t8gpu_plan_subgrid_order(h, p(self.block_order))
@@ -118,6 +119,16 @@ class HostSubgridPlan:
         bf_rec = np.zeros((max(1, self.n_entries), 4), np.int32)
         lib.t8gpu_plan_subgrid_records(self._h, _synth._p(ar), int(float_size), _synth._p(block_rec), _synth._p(bf_rec))
         return block_rec, bf_rec
+
+    def family_records(self, areas, float_size):
+        """fam_rec [n_families, 160], rest_rec [n_rest, 32] (RANK 3; see T8gpuSubgridPlan)."""
+        lib = _synth.lib()
+        lib.t8gpu_plan_subgrid_family_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        ar = np.ascontiguousarray(areas, np.float64)
+        fam_rec = np.zeros((max(1, self.n_families), 160), np.int32)
+        rest_rec = np.zeros((max(1, self.n_rest), 32), np.int32)
+        lib.t8gpu_plan_subgrid_family_records(self._h, _synth._p(ar), int(float_size), _synth._p(fam_rec), _synth._p(rest_rec))
+        return fam_rec, rest_rec
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -125,3 +125,44 @@ def test_32_bit_and_64_bit_plane_addressing_agree_bitwise(tmp_path):
         res.append(np.load(out))
     assert np.isfinite(res[0]).all()
     assert np.array_equal(res[0], res[1])
+
+
+_FAMILY_CHILD = """
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from _gpu import perturbed_state
+from t8gpu_amd import hip
+from t8gpu_amd.solver import SubgridSolver
+from t8gpu_amd.synth import SynthMesh
+out = []
+for args in (dict(base_level=2, max_level=2), dict(base_level=3, max_level=4, band=0.03), dict(base_level=2, max_level=4, band=0.05, periodic=False)):
+    mesh = SynthMesh(3, **args)
+    part = mesh.partition(subgrid=True)
+    for dtype in (torch.float32, torch.float64):
+        for kind in (hip.KEPES, hip.HLL, hip.HLLC):
+            g = SubgridSolver(part, dtype, flux_kind=kind, mode="fused", state=perturbed_state(part, 11))
+            assert g.plan.host.n_families > 0
+            for _ in range(3):
+                g.iterate(0.1 * 2.0 ** -(mesh.finest_level + 2))
+            out.append(g.state().double().cpu().numpy().ravel())
+np.save(sys.argv[1], np.concatenate(out))
+"""
+
+
+def test_family_kernel_and_block_kernel_agree_bitwise(tmp_path):
+    """2x2x2 cubes of same-level blocks run through the family kernel (one workgroup per cube, inner coarse faces
+    evaluated once, outward far cells pooled); T8GPU_SG_FAMILY=0 sends every block through the block kernel. Same
+    fluxes, same summation order: the states must agree bit for bit (periodic, walled, 2:1 meshes; three fluxes)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    script = tmp_path / "child.py"
+    script.write_text(_FAMILY_CHILD.format(root=os.path.dirname(here), tests=here))
+    res = []
+    for fam in ("2", "0"):      # 2: the family kernel for every flux and precision (1 = where it is the faster one)
+        out = tmp_path / f"state_{fam}.npy"
+        subprocess.run([sys.executable, str(script), str(out)], env=dict(os.environ, T8GPU_SG_FAMILY=fam), check=True, timeout=600)
+        res.append(np.load(out))
+    assert np.isfinite(res[0]).all()
+    assert np.array_equal(res[0], res[1]), int((res[0] != res[1]).sum())

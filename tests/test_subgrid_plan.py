@@ -98,3 +98,46 @@ def test_every_face_reaches_each_of_its_blocks_once(dim, args, parts):
         assert set(got) == set(want)
         for key in want:
             assert sorted(got[key]) == sorted(want[key]), key
+
+
+@pytest.mark.parametrize("args,parts", [(dict(base_level=2, max_level=2), 1), (dict(base_level=3, max_level=4, band=0.03), 1),
+                                        (dict(base_level=2, max_level=4, band=0.05, periodic=False), 1),
+                                        (dict(base_level=3, max_level=4, band=0.03), 2)])
+def test_families_are_cubes_of_same_level_blocks_and_cover_the_plan_with_the_rest(args, parts):
+    """2x2x2 families (subgrid_plan.cpp): eight consecutive owned blocks whose mutual faces follow the Morton pattern at
+    equal level; every block is in exactly one family or in the rest list; the family record's 36 rows are the faces the
+    block records hold for the same (block, side)."""
+    mesh = SynthMesh(3, **args)
+    for rank in range(parts):
+        part = mesh.partition(rank, parts, subgrid=True) if parts > 1 else mesh.partition(subgrid=True)
+        plan = HostSubgridPlan(part)
+        block_rec, _ = plan.records(part.areas, 8)
+        fam_rec, rest_rec = plan.family_records(part.areas, 8)
+        N = part.N
+        assert 8 * plan.n_families + plan.n_rest == N
+        by_block = {int(r[0]): r for r in block_rec[:N]}
+        seen = np.zeros(N, int)
+        expand = lambda j, d: (j << 1) if d == 0 else ((j & 1) | ((j >> 1) << 2) if d == 1 else j)
+        for q in range(plan.n_families):
+            rec = fam_rec[q]
+            e0 = int(rec[0])
+            seen[e0:e0 + 8] += 1
+            levels = {int(part.levels[e0 + w]) for w in range(8)}
+            assert len(levels) == 1
+            for w in range(8):
+                assert by_block[e0 + w][1] == 0                      # no generic faces inside a family
+            for d in range(3):
+                for j in range(4):
+                    lo, hi = expand(j, d), expand(j, d) | (1 << d)
+                    assert (rec[4 + 4 * (d * 4 + j):][:4] == by_block[e0 + hi][4 + 4 * d:][:4]).all()           # outward +
+                    assert (rec[4 + 4 * (12 + d * 4 + j):][:4] == by_block[e0 + lo][16 + 4 * d:][:4]).all()    # outward -
+                    inner = rec[4 + 4 * (24 + d * 4 + j):][:4]
+                    assert (inner == by_block[e0 + lo][4 + 4 * d:][:4]).all()                                  # inner
+                    assert int(inner[0]) // 64 == e0 + hi and not (int(inner[1]) >> 3) & 1                     # the sibling, same level
+        for r in range(plan.n_rest):
+            e = int(rest_rec[r][0])
+            seen[e] += 1
+            assert (rest_rec[r] == by_block[e]).all()
+        assert (seen == 1).all()
+        if parts == 1 and "band" not in args:
+            assert plan.n_rest == 0                                   # a uniform mesh is all families
