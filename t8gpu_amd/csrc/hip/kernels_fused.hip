@@ -186,8 +186,12 @@ T8_DEV void load_prim(const T* pe, int LE, int i, Prim<T>& q) {
 // accumulators in LDS with ds_add_f32 / ds_add_f64 (no ELL rows, no gather, one barrier after the last pass).
 // Kept as a measured alternative (T8GPU_LDS_SCATTER=1): the order of the additions is not fixed, so the
 // result is no longer bitwise reproducible, and the default gather is faster.
-template <class T, int KIND, int STAGE, bool DICT, int MAXP, bool SCATTER = false>
-__global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int tile_begin, FVars<T> prev, FVars<T> src,
+// DENSE: register budget for 4 (fp64) / 5 (fp32) workgroups per CU. The fp64 KEPES kernel then spills ~20 registers and
+// still gains 7 % where the tiles leave the LDS room for the fourth workgroup (2D meshes: c2 7 640 -> 8 150 M/s, the
+// one-tile kernel on c4 7 520 -> 8 090); where they do not (3D tiles: ~39 KB) the spills cost 9 % (c5, c5u); HLL / HLLC
+// spill more and lose 24 %, fp32 neither gains nor loses. The launcher takes it for fp64 KEPES with <= 38 KB of LDS.
+template <class T, int KIND, int STAGE, bool DICT, int MAXP, bool SCATTER = false, bool DENSE = false>
+__global__ __launch_bounds__(256, DENSE ? (sizeof(T) == 8 ? 4 : 5) : 1) void k_plain_fused_p(T8gpuPlainPlan P, int tile_begin, FVars<T> prev, FVars<T> src,
                                                        FVars<T> out, const T* __restrict__ vol, T dt,
                                                        T* __restrict__ speed) {
   extern __shared__ double lds_raw[];
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
     bool     valid;
     uint32_t lr;
     V4       gm;
-    int      gi, orig;
+    int      gi, orig, code;   // code: direction code of the normal (tile_plan.cpp: 0..5 = -x +x -y +y -z +z, 7 = oblique)
   };
   auto load_face = [&](int pass) {
     FaceIn f;
@@ -236,9 +240,12 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
     f.lr = P.face_lr[j];
     f.gm = V4{};
     f.gi = 0;
-    if (DICT)  // only the 2-byte row index travels with the face; the (cache-resident) row is read in phase 2
-      f.gi = 3 * (P.geo_idx[j] & 0x1FFF);   // (upper 3 bits: direction code, used by the persistent kernel)
-    else
+    f.code = 7;
+    if (DICT) {  // only the 2-byte row index travels with the face; the (cache-resident) row is read in phase 2
+      const unsigned graw = P.geo_idx[j];   // dictionary row | direction code << 13
+      f.gi   = 3 * static_cast<int>(graw & 0x1FFFu);
+      f.code = static_cast<int>(graw >> 13);
+    } else
       f.gm = reinterpret_cast<const V4*>(P.face_geo)[j];
     f.orig = speed ? P.face_orig[j] : -1;
     return f;
@@ -287,12 +294,58 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
     const FaceIn& fi   = fin[it];
     const bool    last = it == MAXP - 1 || nf <= 256 * (it + 1);
     if (fi.valid) {
-      const V4 gm = DICT ? reinterpret_cast<const V4*>(P.geo_table)[fi.gi] : fi.gm;
       const int  l = fi.lr & 0xFFFFu, r16 = fi.lr >> 16;
       const bool wall = r16 == 0xFFFFu;
       const int  r = wall ? l : r16;
+      T          g[5], spd = T(0);
+      // The tile's faces are ordered by direction inside each block of 256 (tile_plan.cpp), so a wavefront's active lanes
+      // usually share one axis-aligned normal s * e_axis: selecting components then gives the same values as the general
+      // rotation (flux_math.hpp: kepes_axis_fixed) without its 27 multiply-adds -- the persistent kernel's arrangement.
+      const int  wcode  = __builtin_amdgcn_readfirstlane(fi.code);
+      const bool shared = DICT && KIND == 0 && wcode < 6 && __all(fi.code == wcode);
+      if (KIND == 0 && shared) {
+        const T sg   = (wcode & 1) ? T(1) : T(-1);
+        const T area = reinterpret_cast<const T*>(reinterpret_cast<const V4*>(P.geo_table) + fi.gi)[3];
+        Prim<T> L, R;
+        load_prim<T>(pe, LE, l, L);
+        load_prim<T>(pe, LE, r, R);
+        T uL, vL, wL, uR, vR, wR;
+        if ((wcode >> 1) == 0) {
+          asm volatile("");
+          uL = sg * L.vx; vL = -(sg * L.vz); wL = L.vy;
+          uR = sg * R.vx; vR = -(sg * R.vz); wR = R.vy;
+        } else if ((wcode >> 1) == 1) {
+          asm volatile("");
+          uL = sg * L.vy; vL = sg * L.vx; wL = -L.vz;
+          uR = sg * R.vy; vR = sg * R.vx; wR = -R.vz;
+        } else {
+          asm volatile("");
+          uL = sg * L.vz; vL = sg * L.vy; wL = -L.vx;
+          uR = sg * R.vz; vR = sg * R.vy; wR = -R.vx;
+        }
+        if (wall) {   // reflective wall: the right state is the mirror image of the left one (kernels.cu:371-375)
+          uR = -uL;
+          vR = vL;
+          wR = wL;
+        }
+        T f[5];
+        kepes_core<T>(L, R, uL, vL, wL, uR, vR, wR, area, f, spd);
+        g[0] = f[0];
+        g[4] = f[4];
+        if ((wcode >> 1) == 0) {
+          asm volatile("");
+          g[1] = sg * f[1]; g[2] = f[3]; g[3] = -(sg * f[2]);
+        } else if ((wcode >> 1) == 1) {
+          asm volatile("");
+          g[1] = sg * f[2]; g[2] = sg * f[1]; g[3] = -f[3];
+        } else {
+          asm volatile("");
+          g[1] = -f[3]; g[2] = sg * f[2]; g[3] = sg * f[1];
+        }
+      } else {
+      const V4 gm = DICT ? reinterpret_cast<const V4*>(P.geo_table)[fi.gi] : fi.gm;
       const T    n[3] = {gm.x, gm.y, gm.z};
-      T          t1[3], t2[3], g[5], spd = T(0);
+      T          t1[3], t2[3];
       if (DICT) {  // frame precomputed per distinct normal (table rows are L1/L2 resident)
         const V4* __restrict__ tab = reinterpret_cast<const V4*>(P.geo_table);
         const V4 b1 = tab[fi.gi + 1], b2 = tab[fi.gi + 2];
@@ -320,6 +373,7 @@ __global__ __launch_bounds__(256) void k_plain_fused_p(T8gpuPlainPlan P, int til
           sr[k] = pe[k * LE + r];
         }
         hll_face<T>(sl, sr, wall, n, t1, t2, gm.w, g, spd, KIND == 2);
+      }
       }
       if (fi.orig >= 0) speed[fi.orig] = spd;
       if (SCATTER) {
@@ -415,6 +469,8 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
 #endif
   if (lds > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
   const bool  dict = pipelined && plan->geo_idx && plan->geo_table && plan->n_geo > 0;
+  static const int dense_env = std::getenv("T8GPU_DENSE") ? std::atoi(std::getenv("T8GPU_DENSE")) : -1;   // (measurements)
+  const bool  dense = dense_env >= 0 ? dense_env != 0 : kind == 0 && sizeof(T) == 8 && lds <= static_cast<size_t>(38) * 1024;
 #define T8_LAUNCH(KERNEL)                                                                                    \
   do {                                                                                                       \
     if (lds > 64 * 1024) {                                                                                   \
@@ -431,6 +487,8 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
       T8_LAUNCH((k_plain_fused_p<T, K, S, true, 2, true>));         \
     else if (scatter && pipelined && !four)                         \
       T8_LAUNCH((k_plain_fused_p<T, K, S, false, 2, true>));        \
+    else if (dict && !four && dense)                                \
+      T8_LAUNCH((k_plain_fused_p<T, K, S, true, 2, false, true>));  \
     else if (dict && !four)                                         \
       T8_LAUNCH((k_plain_fused_p<T, K, S, true, 2>));               \
     else if (dict)                                                  \
