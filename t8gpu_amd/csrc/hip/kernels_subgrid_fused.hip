@@ -503,7 +503,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 2 : 6) void k_subgrid_family(
                                                         const T* __restrict__ volumes, T dt) {
   constexpr int  NW    = CellData<T, KIND>::words;
   constexpr bool EARLY = false;   // previous-step state fetched last: requested up front it costs registers the kernel does not have
-  constexpr int FAM_WORDS = NW * 704 + 3 * 5 * 64 + 5 * 192;       // this kernel's arrays
+  constexpr int FAM_WORDS = NW * 704 + 3 * 5 * 64 + 5 * 192 + 5 * 512;   // this kernel's arrays
   constexpr int BLK_WORDS = NW * 112 + 5 * 64;                      // one wavefront of the block algorithm
   __shared__ T lds[FAM_WORDS > 8 * BLK_WORDS ? FAM_WORDS : 8 * BLK_WORDS];
   const int tid = threadIdx.x, c = tid & 63;
@@ -529,6 +529,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 2 : 6) void k_subgrid_family(
   T(*const pown)[704]   = reinterpret_cast<T(*)[704]>(lds);
   T(*const sfl)[5][64]  = reinterpret_cast<T(*)[5][64]>(lds + NW * 704);
   T(*const mfl)[192]    = reinterpret_cast<T(*)[192]>(lds + NW * 704 + 3 * 5 * 64);
+  T* const xw           = lds + NW * 704 + 3 * 5 * 64 + 5 * 192 + w * 320;   // this wavefront's flux exchange slice [5][64]
   const int4* __restrict__ frec = reinterpret_cast<const int4*>(P.fam_rec) + 40 * (size_t)sg_xcd_position(blockIdx.x, P.n_families);
   const int    e0 = frec[0].x;
   const int    e  = e0 + w;
@@ -596,11 +597,17 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 2 : 6) void k_subgrid_family(
     const T ar = inner ? surface : area_of(row.z, row.w, T(0)) / T(16);
     T g[5];
     cell_flux<T, KIND>(mine, other, wall, d, true, ar, g);   // left = this cell, normal +e_d
+    // the same face seen from the cell on its high side: through the wavefront's own LDS slice (wavefront-scope fences:
+    // measured faster than cross-lane reads, which cost two ds_bpermute per double and their index arithmetic)
+    block_sync<true>();
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-      acc[k] -= g[k];
-      const T lower = __shfl_up(g[k], str, 64);               // the same face seen from the cell on its high side
-      if (cc[d] > 0) acc[k] += lower;
+    for (int k = 0; k < 5; k++) xw[k * 64 + c] = g[k];
+    block_sync<true>();
+#pragma unroll
+    for (int k = 0; k < 5; k++) acc[k] -= g[k];
+    if (cc[d] > 0) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) acc[k] += xw[k * 64 + c - str];
     }
     if (!inner && sib) {
 #pragma unroll
