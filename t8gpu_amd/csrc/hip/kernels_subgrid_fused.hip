@@ -499,13 +499,14 @@ T8_DEV int fam_expand(int j, int d) { return d == 0 ? j << 1 : (d == 1 ? (j & 1)
 // (second launch bound = wavefronts per SIMD the register allocation must allow: 3 workgroups per CU in fp32 (80 VGPRs),
 //  2 in fp64 (128 VGPRs; its 66 KB of LDS allow no more))
 template <class T, int KIND, int STAGE, bool WIDE>
-__global__ __launch_bounds__(512, sizeof(T) == 8 ? 2 : 6) void k_subgrid_family(T8gpuSubgridPlan P, SVars<T> prev, SVars<T> src, SVars<T> out,
+__global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_subgrid_family(T8gpuSubgridPlan P, SVars<T> prev, SVars<T> src, SVars<T> out,
                                                         const T* __restrict__ volumes, T dt) {
   constexpr int  NW    = CellData<T, KIND>::words;
   constexpr bool EARLY = false;   // previous-step state fetched last: requested up front it costs registers the kernel does not have
-  constexpr int FAM_WORDS = NW * 704 + 3 * 5 * 64 + 5 * 192 + 5 * 512;   // this kernel's arrays
+  constexpr int FAM_WORDS = NW * 704 + 3 * 5 * 64 + 5 * 512;       // this kernel's arrays
   constexpr int BLK_WORDS = NW * 112 + 5 * 64;                      // one wavefront of the block algorithm
-  __shared__ T lds[FAM_WORDS > 8 * BLK_WORDS ? FAM_WORDS : 8 * BLK_WORDS];
+  constexpr int RESTB     = sizeof(T) == 8 ? 4 : 8;                 // leftover blocks per workgroup (fp64: LDS for 4 only)
+  __shared__ T lds[FAM_WORDS > RESTB * BLK_WORDS ? FAM_WORDS : RESTB * BLK_WORDS];
   const int tid = threadIdx.x, c = tid & 63;
   const int w   = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the per-block reads below stay scalar
   // The workgroups behind the cubes take the blocks outside every cube (the coarse side of 2:1 interfaces and their
@@ -513,8 +514,8 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 2 : 6) void k_subgrid_family(
   // (As a second launch they cost 8 % of a stage -- ramp-up and tail of a small grid; on a side stream more: the fork /
   //  join events keep the launches from running back to back.)
   if (static_cast<int>(blockIdx.x) >= P.n_families) {
-    const int pos = (static_cast<int>(blockIdx.x) - P.n_families) * 8 + w;
-    if (pos < P.n_rest) {
+    const int pos = (static_cast<int>(blockIdx.x) - P.n_families) * RESTB + w;
+    if (w < RESTB && pos < P.n_rest) {
       T8gpuSubgridPlan R = P;
       R.block_rec        = P.rest_rec;
       T* const mine_lds  = lds + w * BLK_WORDS;
@@ -528,8 +529,10 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 2 : 6) void k_subgrid_family(
   // their high side; fluxes through the outward - faces [k][(d * 4 + j) * 16 + sub-face]
   T(*const pown)[704]   = reinterpret_cast<T(*)[704]>(lds);
   T(*const sfl)[5][64]  = reinterpret_cast<T(*)[5][64]>(lds + NW * 704);
-  T(*const mfl)[192]    = reinterpret_cast<T(*)[192]>(lds + NW * 704 + 3 * 5 * 64);
-  T* const xw           = lds + NW * 704 + 3 * 5 * 64 + 5 * 192 + w * 320;   // this wavefront's flux exchange slice [5][64]
+  // per-wavefront flux exchange slices [8][5][64]; after its + passes a wavefront's slice is free, and waves 3-5 leave the
+  // fluxes through the outward - faces in theirs ([k][lane]: slot s of the pooled round = slice 3 + s / 64, lane s % 64)
+  T* const xall         = lds + NW * 704 + 3 * 5 * 64;
+  T* const xw           = xall + w * 320;
   const int4* __restrict__ frec = reinterpret_cast<const int4*>(P.fam_rec) + 40 * (size_t)sg_xcd_position(blockIdx.x, P.n_families);
   const int    e0 = frec[0].x;
   const int    e  = e0 + w;
@@ -566,15 +569,10 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 2 : 6) void k_subgrid_family(
   const CellData<T, KIND> mine = cell_from_state<T, KIND>(s0);
 #pragma unroll
   for (int q = 0; q < NW; q++) pown[q][tid] = mine.v[q];
-  CellData<T, KIND> there;
+  if (xp && x_on && !x_wall) {
+    const CellData<T, KIND> far = cell_from_state<T, KIND>(xst);
 #pragma unroll
-  for (int q = 0; q < NW; q++) there.v[q] = T(1);
-  if (x_on && (xm || !x_wall)) {
-    there = cell_from_state<T, KIND>(xst);
-    if (xp) {
-#pragma unroll
-      for (int q = 0; q < NW; q++) pown[q][512 + xs] = there.v[q];
-    }
+    for (int q = 0; q < NW; q++) pown[q][512 + xs] = far.v[q];
   }
   __syncthreads();
 
@@ -619,11 +617,14 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 2 : 6) void k_subgrid_family(
     CellData<T, KIND> here;
 #pragma unroll
     for (int q = 0; q < NW; q++) here.v[q] = pown[q][xb * 64 + xcell];
+    // (the far cell's primitives only now: five state words instead of nine primitives live during the + passes)
+    const CellData<T, KIND> there = cell_from_state<T, KIND>(xst);
     T g[5];
     cell_flux<T, KIND>(there, here, x_wall, xd, !x_wall, area_of(xrow.z, xrow.w, T(0)) / T(16), g);
     const T sgn = x_wall ? T(-1) : T(1);
+    block_sync<true>();   // (this wavefront's last reads of its exchange slice are behind it)
 #pragma unroll
-    for (int k = 0; k < 5; k++) mfl[k][xs] = g[k] * sgn;
+    for (int k = 0; k < 5; k++) xw[k * 64 + c] = g[k] * sgn;
   }
   __syncthreads();
   // ---- every cell with coordinate 0 picks up its -d face: from the sibling's + pass or from the pooled round ----------
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 2 : 6) void k_subgrid_family(
         for (int k = 0; k < 5; k++) acc[k] += sfl[d][k][j * 16 + tsub];
       } else {
 #pragma unroll
-        for (int k = 0; k < 5; k++) acc[k] += mfl[k][(d * 4 + j) * 16 + tsub];
+        for (int k = 0; k < 5; k++) acc[k] += xall[(3 + d) * 320 + k * 64 + j * 16 + tsub];   // slot (d * 4 + j) * 16 + tsub
       }
     }
   }
@@ -646,9 +647,12 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 2 : 6) void k_subgrid_family(
 #pragma unroll
     for (int k = 0; k < 5; k++) pv[k] = at<WIDE>(prev.p[k], o);
   }
+  T s1[5];   // fp64: the own state is fetched again here instead of occupying ten registers through the flux passes
+#pragma unroll
+  for (int k = 0; k < 5; k++) s1[k] = sizeof(T) == 8 ? at<WIDE>(src.p[k], o) : s0[k];
   const T scale = dt / (vol / T(64));
 #pragma unroll
-  for (int k = 0; k < 5; k++) at<WIDE>(out.p[k], o) = rk_stage_update<T, STAGE>(pv[k], s0[k], scale, acc[k]);
+  for (int k = 0; k < 5; k++) at<WIDE>(out.p[k], o) = rk_stage_update<T, STAGE>(pv[k], s1[k], scale, acc[k]);
 }
 
 template <class T, class V>
@@ -704,10 +708,9 @@ int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, int b
   };
   // A launch that covers the whole plan of a 3D mesh: 2x2x2 cubes of same-level blocks through the family kernel, the
   // other blocks through the block kernel (T8GPU_SG_FAMILY=0: every block through the block kernel -- same bits).
-  // (measured where it pays: KEPES in fp32. fp64 and the HLL fluxes need more registers than three / two workgroups of
-  //  eight wavefronts per CU leave them and spill: T8GPU_SG_FAMILY=2 takes the family kernel for those too.)
-  static const int fam_env = std::getenv("T8GPU_SG_FAMILY") ? std::atoi(std::getenv("T8GPU_SG_FAMILY")) : 1;
-  const bool fam_off = fam_env == 0 || (fam_env == 1 && !(kind == 0 && sizeof(T) == 4));
+  // (T8GPU_SG_FAMILY=0: every block through the block kernel -- same bits. Measured on c3: KEPES fp32 +6 %, fp64 +8 %,
+  //  HLL fp32 +9 %, fp64 +3 %, HLLC fp32 +5 %.)
+  static const bool fam_off = std::getenv("T8GPU_SG_FAMILY") && std::getenv("T8GPU_SG_FAMILY")[0] == '0';
   const bool families = !fam_off && plan->rank == 3 && block_begin == 0 && block_count == plan->num_elements && plan->n_families > 0 &&
                         plan->fam_rec && plan->rest_rec && plan->n_rest == plan->num_elements - 8 * plan->n_families;
   if (!families) {
@@ -715,7 +718,8 @@ int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, int b
     return static_cast<int>(hipGetLastError());
   }
   {
-    const dim3 grid(plan->n_families + (plan->n_rest + 7) / 8), block(512);
+    const int  restb = sizeof(T) == 8 ? 4 : 8;   // leftover blocks per workgroup (k_subgrid_family: RESTB)
+    const dim3 grid(plan->n_families + (plan->n_rest + restb - 1) / restb), block(512);
 #define T8_FM(K, S)                                                                                                          \
   do {                                                                                                                       \
     if (wide)                                                                                                                \

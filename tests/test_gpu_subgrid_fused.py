@@ -160,7 +160,7 @@ def test_family_kernel_and_block_kernel_agree_bitwise(tmp_path):
     script = tmp_path / "child.py"
     script.write_text(_FAMILY_CHILD.format(root=os.path.dirname(here), tests=here))
     res = []
-    for fam in ("2", "0"):      # 2: the family kernel for every flux and precision (1 = where it is the faster one)
+    for fam in ("1", "0"):
         out = tmp_path / f"state_{fam}.npy"
         subprocess.run([sys.executable, str(script), str(out)], env=dict(os.environ, T8GPU_SG_FAMILY=fam), check=True, timeout=600)
         res.append(np.load(out))
