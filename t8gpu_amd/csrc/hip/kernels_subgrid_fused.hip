@@ -711,22 +711,37 @@ int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, int b
   // (T8GPU_SG_FAMILY=0: every block through the block kernel -- same bits. Measured on c3: KEPES fp32 +6 %, fp64 +8 %,
   //  HLL fp32 +9 %, fp64 +3 %, HLLC fp32 +5 %.)
   static const bool fam_off = std::getenv("T8GPU_SG_FAMILY") && std::getenv("T8GPU_SG_FAMILY")[0] == '0';
-  const bool families = !fam_off && plan->rank == 3 && block_begin == 0 && block_count == plan->num_elements && plan->n_families > 0 &&
-                        plan->fam_rec && plan->rest_rec && plan->n_rest == plan->num_elements - 8 * plan->n_families;
+  // The cubes consist of deep interior blocks only, and rest_rec lists the other blocks in block_order order, so with
+  // nf = 8 * n_families: positions [0, n_deep) = the cubes + rest_rec[0, n_deep - nf), and position p >= n_deep = rest_rec[p - nf].
+  // Launches that are the whole plan or exactly its first class take the family kernel; launches inside the later
+  // classes read their block records from rest_rec; anything else goes through block_rec.
+  const int  nf       = 8 * plan->n_families;
+  const bool have_fam = !fam_off && plan->rank == 3 && plan->n_families > 0 && plan->fam_rec && plan->rest_rec &&
+                        plan->n_rest == plan->num_elements - nf && plan->n_deep_blocks >= nf;
+  const bool families = have_fam && block_begin == 0 && (block_count == plan->num_elements || block_count == plan->n_deep_blocks);
   if (!families) {
-    blocks(*plan, block_begin, block_count);
+    if (have_fam && block_begin >= plan->n_deep_blocks) {
+      T8gpuSubgridPlan rest = *plan;
+      rest.block_rec        = plan->rest_rec;
+      blocks(rest, block_begin - nf, block_count);
+    } else {
+      blocks(*plan, block_begin, block_count);
+    }
     return static_cast<int>(hipGetLastError());
   }
+  const int n_rest_here = block_count - nf;   // the leading rows of rest_rec that belong to this launch
   {
     const int  restb = sizeof(T) == 8 ? 4 : 8;   // leftover blocks per workgroup (k_subgrid_family: RESTB)
-    const dim3 grid(plan->n_families + (plan->n_rest + restb - 1) / restb), block(512);
+    const dim3 grid(plan->n_families + (n_rest_here + restb - 1) / restb), block(512);
+    T8gpuSubgridPlan fam = *plan;
+    fam.n_rest           = n_rest_here;
 #define T8_FM(K, S)                                                                                                          \
   do {                                                                                                                       \
     if (wide)                                                                                                                \
-      hipLaunchKernelGGL((k_subgrid_family<T, K, S, true>), grid, block, 0, s, *plan, smk<T>(prev), smk<T>(mid), smk<T>(out), \
+      hipLaunchKernelGGL((k_subgrid_family<T, K, S, true>), grid, block, 0, s, fam, smk<T>(prev), smk<T>(mid), smk<T>(out),   \
                          volumes, dt);                                                                                       \
     else                                                                                                                     \
-      hipLaunchKernelGGL((k_subgrid_family<T, K, S, false>), grid, block, 0, s, *plan, smk<T>(prev), smk<T>(mid), smk<T>(out), \
+      hipLaunchKernelGGL((k_subgrid_family<T, K, S, false>), grid, block, 0, s, fam, smk<T>(prev), smk<T>(mid), smk<T>(out),  \
                          volumes, dt);                                                                                       \
   } while (0)
     if (kind == 0) {

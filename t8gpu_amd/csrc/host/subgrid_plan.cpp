@@ -116,10 +116,28 @@ void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, c
     if (l < N && !folded_l[f]) P->bf_ent[cur[l]++] = f;
     if (r < N && r != l && !folded_r[f]) P->bf_ent[cur[r]++] = f | static_cast<int32_t>(0x80000000u);
   }
+  // blocks whose faces all stay among owned blocks can run while the halo exchange is in flight
+  std::vector<uint8_t> ghosty(static_cast<size_t>(N), 0);
+  for (int32_t f = 0; f < F; f++) {
+    const int32_t l = fn[2 * static_cast<size_t>(f)], r = fn[2 * static_cast<size_t>(f) + 1];
+    if (l >= N && r < N) ghosty[r] = 1;
+    if (r >= N && l < N) ghosty[l] = 1;
+  }
+  // three classes for the multi-rank step driver (as for plain tiles, tile_plan.cpp): deep interior blocks (no
+  // neighbour that touches a ghost block), near-boundary interior blocks, ghost-touching blocks
+  std::vector<uint8_t> near(static_cast<size_t>(N), 0);
+  for (int32_t f = 0; f < F; f++) {
+    const int32_t l = fn[2 * static_cast<size_t>(f)], r = fn[2 * static_cast<size_t>(f) + 1];
+    if (l < N && r < N) {
+      if (ghosty[l] && !ghosty[r]) near[r] = 1;
+      if (ghosty[r] && !ghosty[l]) near[l] = 1;
+    }
+  }
   // 2x2x2 families (RANK 3): eight CONSECUTIVE owned blocks e .. e + 7 that form a cube in Morton order -- the +x / +y /
   // +z neighbour of block e + w is block e + w + 1 / 2 / 4 at the same level wherever that bit of w is clear --, each of
   // whose 24 outward sides is one foldable coarse face (same level, coarser neighbour or wall) and none of which has a
-  // generic face. One workgroup of the family kernel takes such a cube: the 12 inner coarse faces are evaluated once,
+  // generic face, and all of which are deep interior blocks (so that a multi-rank stage's first class = the cubes + the
+// leading part of the rest list). One workgroup of the family kernel takes such a cube: the 12 inner coarse faces are evaluated once,
   // from primitives that are already in LDS, and the far cells of the outward faces are pooled over the eight wavefronts.
   P->in_family.assign(static_cast<size_t>(N), 0);
   if (rank == 3) {
@@ -131,6 +149,7 @@ void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, c
     auto is_family = [&](int32_t e) {
       for (int w = 0; w < 8; w++) {
         const int32_t b = e + w;
+        if (ghosty[b] || near[b]) return false;   // cubes of DEEP blocks only: they then lie inside the first class below
         if (P->bf_off[b + 1] != P->bf_off[b]) return false;
         for (int d = 0; d < 3; d++) {
           const int32_t pe = P->plus[static_cast<size_t>(b) * 3 + d], me = P->minus[static_cast<size_t>(b) * 3 + d];
@@ -153,23 +172,6 @@ void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, c
       } else {
         e++;
       }
-    }
-  }
-  // blocks whose faces all stay among owned blocks can run while the halo exchange is in flight
-  std::vector<uint8_t> ghosty(static_cast<size_t>(N), 0);
-  for (int32_t f = 0; f < F; f++) {
-    const int32_t l = fn[2 * static_cast<size_t>(f)], r = fn[2 * static_cast<size_t>(f) + 1];
-    if (l >= N && r < N) ghosty[r] = 1;
-    if (r >= N && l < N) ghosty[l] = 1;
-  }
-  // three classes for the multi-rank step driver (as for plain tiles, tile_plan.cpp): deep interior blocks (no
-  // neighbour that touches a ghost block), near-boundary interior blocks, ghost-touching blocks
-  std::vector<uint8_t> near(static_cast<size_t>(N), 0);
-  for (int32_t f = 0; f < F; f++) {
-    const int32_t l = fn[2 * static_cast<size_t>(f)], r = fn[2 * static_cast<size_t>(f) + 1];
-    if (l < N && r < N) {
-      if (ghosty[l] && !ghosty[r]) near[r] = 1;
-      if (ghosty[r] && !ghosty[l]) near[l] = 1;
     }
   }
   for (int32_t e = 0; e < N; e++)
