@@ -189,7 +189,10 @@ T8_DEV void load_prim(const T* pe, int LE, int i, Prim<T>& q) {
 // DENSE: register budget for 4 (fp64) / 5 (fp32) workgroups per CU. The fp64 KEPES kernel then spills ~20 registers and
 // still gains 7 % where the tiles leave the LDS room for the fourth workgroup (2D meshes: c2 7 640 -> 8 150 M/s, the
 // one-tile kernel on c4 7 520 -> 8 090); where they do not (3D tiles: ~39 KB) the spills cost 9 % (c5, c5u); HLL / HLLC
-// spill more and lose 24 %, fp32 neither gains nor loses. The launcher takes it for fp64 KEPES with <= 38 KB of LDS.
+// spill more and lose 24 %, fp32 neither gains nor loses. The launcher takes it for fp64 KEPES tiles of <= 36 KB (2D
+// meshes: 35 KB; 3D tiles are 37 KB and lose 7 % with it even though the fourth workgroup then fits -- their wavefronts mix
+// face directions and run both arms of the axis path under the tighter budget). The DENSE kernel reads the logarithm
+// table from global memory instead of an LDS copy (c2: +1 %).
 template <class T, int KIND, int STAGE, bool DICT, int MAXP, bool SCATTER = false, bool DENSE = false>
 __global__ __launch_bounds__(256, DENSE ? (sizeof(T) == 8 ? 4 : 5) : 1) void k_plain_fused_p(T8gpuPlainPlan P, int tile_begin, FVars<T> prev, FVars<T> src,
                                                        FVars<T> out, const T* __restrict__ vol, T dt,
@@ -202,7 +205,9 @@ __global__ __launch_bounds__(256, DENSE ? (sizeof(T) == 8 ? 4 : 5) : 1) void k_p
   T* const      pe  = lds;
   T* const      ff  = lds + (size_t)NW * LE;  // [5][256]: one pass of 256 faces at a time
   constexpr bool kTab = sizeof(T) == 8 && KIND == 0;   // fp64 KEPES: table-driven logarithms, table behind the flux buffer
-  double* const lt  = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(ff + 5 * 256) + 15) & ~uintptr_t(15));   // 16-byte rows
+  // (DENSE: the table is read from global memory -- 2 KB of LDS less is what lets a 3D tile's fourth workgroup fit)
+  double* const lt_lds = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(ff + 5 * 256) + 15) & ~uintptr_t(15));   // 16-byte rows
+  const double* const lt = DENSE ? kLogTab : lt_lds;
 
 #ifdef T8GPU_EXP_TILEMOD   // experiment builds only (build.py variants): every workgroup works on one of the first few tiles,
                            // so all traffic stays in the caches -- what remains is the kernel's instruction time
@@ -259,8 +264,8 @@ __global__ __launch_bounds__(256, DENSE ? (sizeof(T) == 8 ? 4 : 5) : 1) void k_p
   const uint4 ell0 = ellrow[0];
 
   // ---- phase 1 -----------------------------------------------------------------------------------
-  if (kTab) {   // (requested with the loads above; the barrier costs one per tile -- the persistent kernel pays it once)
-    lt[tid] = kLogTab[tid];
+  if (kTab && !DENSE) {   // (requested with the loads above; the barrier costs one per tile -- the persistent kernel pays it once)
+    lt_lds[tid] = kLogTab[tid];
     __syncthreads();
   }
   if (SCATTER) {
@@ -462,15 +467,17 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
                                              dt, speed, s);
     if (rc >= 0) return rc;
   }
-  size_t lds = sizeof(T) * ((size_t)nw * slots + (size_t)5 * (pipelined ? 256 : plan->max_faces)) +
-               ((sizeof(T) == 8 && kind == 0) ? 2 * kLogTabEntries * sizeof(double) + 16 : 0);
+  const size_t lds_table = (sizeof(T) == 8 && kind == 0) ? 2 * kLogTabEntries * sizeof(double) + 16 : 0;
+  size_t       lds       = sizeof(T) * ((size_t)nw * slots + (size_t)5 * (pipelined ? 256 : plan->max_faces)) + lds_table;
 #ifdef T8GPU_EXP_LDS_PAD   // experiment builds only: fewer workgroups per CU, to measure how much the kernel leans on occupancy
   if (const char* pad = std::getenv("T8GPU_EXP_LDS_PAD")) lds += static_cast<size_t>(std::atoi(pad));
 #endif
   if (lds > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
   const bool  dict = pipelined && plan->geo_idx && plan->geo_table && plan->n_geo > 0;
   static const int dense_env = std::getenv("T8GPU_DENSE") ? std::atoi(std::getenv("T8GPU_DENSE")) : -1;   // (measurements)
-  const bool  dense = dense_env >= 0 ? dense_env != 0 : kind == 0 && sizeof(T) == 8 && lds <= static_cast<size_t>(38) * 1024;
+  const bool  dense = pipelined && !scatter && kind == 0 && sizeof(T) == 8 && plan->geo_idx && plan->geo_table && plan->n_geo > 0 &&
+                     plan->max_faces <= 512 && (dense_env >= 0 ? dense_env != 0 : lds - lds_table <= static_cast<size_t>(36) * 1024);
+  if (dense) lds -= lds_table;   // (the DENSE kernel reads the logarithm table from global memory)
 #define T8_LAUNCH(KERNEL)                                                                                    \
   do {                                                                                                       \
     if (lds > 64 * 1024) {                                                                                   \
