@@ -299,7 +299,7 @@ namespace t8gpu::hip {
       std::vector<int32_t> block_rec(32 * static_cast<size_t>(std::max<int32_t>(1, m.num_local_elements))),
           bf_rec(4 * static_cast<size_t>(std::max<int64_t>(1, sz[0])));
       t8gpu_plan_subgrid_records(h, m.face_surfaces.data(), static_cast<int>(sizeof(ft)), block_rec.data(), bf_rec.data());
-      std::vector<int32_t> fam_rec(160 * static_cast<size_t>(std::max<int64_t>(1, sz[6]))), rest_rec(32 * static_cast<size_t>(std::max<int64_t>(1, sz[7])));
+      std::vector<int32_t> fam_rec((m.rank == 3 ? 160 : 64) * static_cast<size_t>(std::max<int64_t>(1, sz[6]))), rest_rec(32 * static_cast<size_t>(std::max<int64_t>(1, sz[7])));
       if (sz[6] > 0) t8gpu_plan_subgrid_family_records(h, m.face_surfaces.data(), static_cast<int>(sizeof(ft)), fam_rec.data(), rest_rec.data());
       t8gpu_plan_subgrid_destroy(h);
       T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_block_rec, sizeof(int32_t) * block_rec.size()));

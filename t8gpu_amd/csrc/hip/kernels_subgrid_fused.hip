@@ -655,6 +655,149 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_subgrid_family(
   for (int k = 0; k < 5; k++) at<WIDE>(out.p[k], o) = rk_stage_update<T, STAGE>(pv[k], s1[k], scale, acc[k]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Family kernel, RANK 2: one wavefront = a 2x2 square of consecutive same-level Subgrid<4,4> blocks (lanes 16 w .. 16 w + 15
+// = block e0 + w at (w & 1, w >> 1)). The same idea as above within one wavefront, so without workgroup barriers: the 4
+// inner coarse faces are evaluated once from primitives in LDS, the far cells of the 8 outward faces are pooled (16 behind
+// the + faces in lanes 0-15, 16 behind the - faces in lanes 16-31: one half-filled primitive round instead of the block
+// kernel's two). Same fluxes, same summation order: bitwise equal to the block kernel. The blocks outside every square run
+// behind the squares in the same launch (four per wavefront, the block algorithm).
+template <class T, int KIND, int STAGE, bool WIDE>
+__global__ __launch_bounds__(64) void k_subgrid_family2(T8gpuSubgridPlan P, SVars<T> prev, SVars<T> src, SVars<T> out,
+                                                        const T* __restrict__ volumes, T dt) {
+  constexpr int  NW        = CellData<T, KIND>::words;
+  constexpr bool EARLY     = sizeof(T) == 4;
+  constexpr int  FAM_WORDS = NW * 80 + 5 * 64 + 2 * 5 * 8 + 5 * 16;
+  constexpr int  BLK_WORDS = NW * 96 + 5 * 64;
+  __shared__ T lds[FAM_WORDS > BLK_WORDS ? FAM_WORDS : BLK_WORDS];
+  const int c = threadIdx.x;
+  if (static_cast<int>(blockIdx.x) >= P.n_families) {   // the blocks outside every square: four per wavefront
+    T8gpuSubgridPlan R = P;
+    R.block_rec        = P.rest_rec;
+    subgrid_block<T, KIND, STAGE, 2, EARLY, WIDE, false>(R, 0, P.n_rest, static_cast<int>(blockIdx.x) - P.n_families, c, prev, src, out,
+                                                         volumes, dt, lds, lds + NW * 96);
+    return;
+  }
+  // primitives [64 cells of the square, then 16 far cells behind the outward + faces ((d * 2 + j) * 4 + sub-face)];
+  // the wavefront's flux exchange buffer [5][64]; fluxes through the inner coarse faces [d][k][j * 4 + sub-face]; fluxes
+  // through the outward - faces [k][(d * 2 + j) * 4 + sub-face]
+  T(*const pown)[80] = reinterpret_cast<T(*)[80]>(lds);
+  T* const xw        = lds + NW * 80;
+  T(*const sfl)[5][8] = reinterpret_cast<T(*)[5][8]>(lds + NW * 80 + 320);
+  T(*const mfl)[16]  = reinterpret_cast<T(*)[16]>(lds + NW * 80 + 320 + 80);
+  const int4* __restrict__ frec = reinterpret_cast<const int4*>(P.fam_rec) + 16 * (size_t)sg_xcd_position(blockIdx.x, P.n_families);
+  const int    e0 = frec[0].x;
+  const int    w = c >> 4, cl = c & 15;
+  const int    e  = e0 + w;
+  const int    cc[2] = {cl & 3, cl >> 2};
+  const size_t o = (size_t)e * 16 + cl;
+
+  T s0[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) s0[k] = at<WIDE>(src.p[k], o);
+  const T vol     = volumes[e];
+  const T surface = t8_sqrt(vol) / T(4);   // edge of a subcell = length of an inner face
+  // the block's two + faces (area, wall flag): outward rows 0-3 or inner rows 8-11
+  const int  jx = w >> 1, jy = w & 1;      // the block's index among those with / without bit d (fam_compact for RANK 2)
+  const int4 rowx = frec[1 + ((w & 1) ? 0 : 8) + jx], rowy = frec[1 + ((w & 2) ? 0 : 8) + 2 + jy];
+
+  // ---- pooled far cells of the outward faces: lanes 0-15 the + faces, lanes 16-31 the - faces -------------------------
+  const bool xp = c < 16, xm = c >= 16 && c < 32;
+  const int  xs = c & 15, xf = xs >> 2, xsub = xs & 3, xd = xf >> 1;   // slot = (d * 2 + j) * 4 + sub-face
+  const int  xbk = (xd == 0 ? (xf & 1) << 1 : (xf & 1)) | (xp ? 1 << xd : 0);   // the block of the square that owns the face
+  const int  xla = xd == 0 ? 2 : 0;
+  const int  xcell = (xsub << xla) + (xp ? 3 << (2 * xd) : 0);   // its cell behind the sub-face
+  const int4 xrow  = (xp || xm) ? frec[1 + xf + (xm ? 4 : 0)] : make_int4(-2, 0, 0, 0);
+  const bool x_on = xrow.x != -2, x_wall = xrow.x == -1;
+  T          xst[5];
+  load_far<T, WIDE>(src, x_on && (xm || !x_wall), x_wall, xrow.x, (xrow.y >> 19) & 1, xla, 0, xsub, 0, (size_t)(e0 + xbk) * 16 + xcell,
+                    xst);
+  T pv[5] = {T(0), T(0), T(0), T(0), T(0)};
+  if (STAGE > 1 && EARLY) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) pv[k] = at<WIDE>(prev.p[k], o);
+  }
+
+  const CellData<T, KIND> mine = cell_from_state<T, KIND>(s0);
+#pragma unroll
+  for (int q = 0; q < NW; q++) pown[q][c] = mine.v[q];
+  CellData<T, KIND> there;
+#pragma unroll
+  for (int q = 0; q < NW; q++) there.v[q] = T(1);
+  if (x_on && (xm || !x_wall)) {
+    there = cell_from_state<T, KIND>(xst);
+    if (xp) {
+#pragma unroll
+      for (int q = 0; q < NW; q++) pown[q][64 + xs] = there.v[q];
+    }
+  }
+  __syncthreads();
+
+  T acc[5] = {T(0), T(0), T(0), T(0), T(0)};
+#pragma unroll
+  for (int d = 0; d < 2; d++) {
+    const int  str   = d == 0 ? 1 : 4;
+    const bool inner = cc[d] < 3;
+    const bool sib   = !((w >> d) & 1);
+    const int  j     = d == 0 ? jx : jy;
+    const int4 row   = d == 0 ? rowx : rowy;
+    const bool wall  = !inner && !sib && row.x == -1;
+    const int  tsub  = cc[1 - d];
+    const int  oidx  = inner ? c + str : (sib ? c + 16 * (1 << d) - 3 * str : (wall ? c : 64 + (d * 2 + j) * 4 + tsub));
+    CellData<T, KIND> other;
+#pragma unroll
+    for (int q = 0; q < NW; q++) other.v[q] = pown[q][oidx];
+    const T ar = inner ? surface : area_of(row.z, row.w, T(0)) / T(4);
+    T g[5];
+    cell_flux<T, KIND>(mine, other, wall, d, true, ar, g);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; k++) xw[k * 64 + c] = g[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; k++) acc[k] -= g[k];
+    if (cc[d] > 0) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) acc[k] += xw[k * 64 + c - str];
+    }
+    if (!inner && sib) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) sfl[d][k][j * 4 + tsub] = g[k];
+    }
+  }
+  if (xm && x_on) {   // outward - faces: left = the far cell (low side), normal +e_d; walls: left = the cell, outward normal
+    CellData<T, KIND> here;
+#pragma unroll
+    for (int q = 0; q < NW; q++) here.v[q] = pown[q][xbk * 16 + xcell];
+    T g[5];
+    cell_flux<T, KIND>(there, here, x_wall, xd, !x_wall, area_of(xrow.z, xrow.w, T(0)) / T(4), g);
+    const T sgn = x_wall ? T(-1) : T(1);
+#pragma unroll
+    for (int k = 0; k < 5; k++) mfl[k][xs] = g[k] * sgn;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 2; d++) {
+    if (cc[d] == 0) {
+      const int tsub = cc[1 - d], j = d == 0 ? jx : jy;
+      if ((w >> d) & 1) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) acc[k] += sfl[d][k][j * 4 + tsub];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 5; k++) acc[k] += mfl[k][(d * 2 + j) * 4 + tsub];
+      }
+    }
+  }
+  if (STAGE > 1 && !EARLY) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) pv[k] = at<WIDE>(prev.p[k], o);
+  }
+  const T scale = dt / (vol / T(16));
+#pragma unroll
+  for (int k = 0; k < 5; k++) at<WIDE>(out.p[k], o) = rk_stage_update<T, STAGE>(pv[k], s0[k], scale, acc[k]);
+}
+
 template <class T, class V>
 SVars<T> smk(const V& v) {
   SVars<T> o;
@@ -715,8 +858,8 @@ int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, int b
   // nf = 8 * n_families: positions [0, n_deep) = the cubes + rest_rec[0, n_deep - nf), and position p >= n_deep = rest_rec[p - nf].
   // Launches that are the whole plan or exactly its first class take the family kernel; launches inside the later
   // classes read their block records from rest_rec; anything else goes through block_rec.
-  const int  nf       = 8 * plan->n_families;
-  const bool have_fam = !fam_off && plan->rank == 3 && plan->n_families > 0 && plan->fam_rec && plan->rest_rec &&
+  const int  nf       = (plan->rank == 3 ? 8 : 4) * plan->n_families;
+  const bool have_fam = !fam_off && plan->n_families > 0 && plan->fam_rec && plan->rest_rec &&
                         plan->n_rest == plan->num_elements - nf && plan->n_deep_blocks >= nf;
   const bool families = have_fam && block_begin == 0 && (block_count == plan->num_elements || block_count == plan->n_deep_blocks);
   if (!families) {
@@ -730,29 +873,35 @@ int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, int b
     return static_cast<int>(hipGetLastError());
   }
   const int n_rest_here = block_count - nf;   // the leading rows of rest_rec that belong to this launch
-  {
-    const int  restb = sizeof(T) == 8 ? 4 : 8;   // leftover blocks per workgroup (k_subgrid_family: RESTB)
-    const dim3 grid(plan->n_families + (n_rest_here + restb - 1) / restb), block(512);
-    T8gpuSubgridPlan fam = *plan;
-    fam.n_rest           = n_rest_here;
+  T8gpuSubgridPlan fam = *plan;
+  fam.n_rest           = n_rest_here;
+  // RANK 3: workgroups of eight wavefronts, `restb` leftover blocks per workgroup behind the cubes; RANK 2: one wavefront
+  // per square, four leftover blocks per wavefront
+  const int  restb = plan->rank == 3 ? (sizeof(T) == 8 ? 4 : 8) : 4;   // (k_subgrid_family: RESTB)
+  const dim3 grid(plan->n_families + (n_rest_here + restb - 1) / restb), block(plan->rank == 3 ? 512 : 64);
 #define T8_FM(K, S)                                                                                                          \
   do {                                                                                                                       \
-    if (wide)                                                                                                                \
+    if (plan->rank == 3 && wide)                                                                                             \
       hipLaunchKernelGGL((k_subgrid_family<T, K, S, true>), grid, block, 0, s, fam, smk<T>(prev), smk<T>(mid), smk<T>(out),   \
                          volumes, dt);                                                                                       \
-    else                                                                                                                     \
+    else if (plan->rank == 3)                                                                                                \
       hipLaunchKernelGGL((k_subgrid_family<T, K, S, false>), grid, block, 0, s, fam, smk<T>(prev), smk<T>(mid), smk<T>(out),  \
                          volumes, dt);                                                                                       \
+    else if (wide)                                                                                                           \
+      hipLaunchKernelGGL((k_subgrid_family2<T, K, S, true>), grid, block, 0, s, fam, smk<T>(prev), smk<T>(mid), smk<T>(out),  \
+                         volumes, dt);                                                                                       \
+    else                                                                                                                     \
+      hipLaunchKernelGGL((k_subgrid_family2<T, K, S, false>), grid, block, 0, s, fam, smk<T>(prev), smk<T>(mid), smk<T>(out), \
+                         volumes, dt);                                                                                       \
   } while (0)
-    if (kind == 0) {
-      if (stage == 1) T8_FM(0, 1); else if (stage == 2) T8_FM(0, 2); else T8_FM(0, 3);
-    } else if (kind == 1) {
-      if (stage == 1) T8_FM(1, 1); else if (stage == 2) T8_FM(1, 2); else T8_FM(1, 3);
-    } else {
-      if (stage == 1) T8_FM(2, 1); else if (stage == 2) T8_FM(2, 2); else T8_FM(2, 3);
-    }
-#undef T8_FM
+  if (kind == 0) {
+    if (stage == 1) T8_FM(0, 1); else if (stage == 2) T8_FM(0, 2); else T8_FM(0, 3);
+  } else if (kind == 1) {
+    if (stage == 1) T8_FM(1, 1); else if (stage == 2) T8_FM(1, 2); else T8_FM(1, 3);
+  } else {
+    if (stage == 1) T8_FM(2, 1); else if (stage == 2) T8_FM(2, 2); else T8_FM(2, 3);
   }
+#undef T8_FM
   return static_cast<int>(hipGetLastError());
 }
 

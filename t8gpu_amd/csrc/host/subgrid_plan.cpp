@@ -139,20 +139,22 @@ void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, c
   // generic face, and all of which are deep interior blocks (so that a multi-rank stage's first class = the cubes + the
 // leading part of the rest list). One workgroup of the family kernel takes such a cube: the 12 inner coarse faces are evaluated once,
   // from primitives that are already in LDS, and the far cells of the outward faces are pooled over the eight wavefronts.
+  // (RANK 2: the same with four blocks -- a 2x2 square, one wavefront of the 2D family kernel.)
   P->in_family.assign(static_cast<size_t>(N), 0);
-  if (rank == 3) {
+  {
+    const int NB = 1 << rank;
     auto other_of = [&](int32_t ent, int32_t* hanging) {
       const int32_t* rec = &P->face_rec[4 * static_cast<size_t>(ent & 0x7FFFFFFF)];
       *hanging = (rec[2] >> 3) & 1;
       return ent < 0 ? rec[0] : rec[1];
     };
     auto is_family = [&](int32_t e) {
-      for (int w = 0; w < 8; w++) {
+      for (int w = 0; w < NB; w++) {
         const int32_t b = e + w;
         if (ghosty[b] || near[b]) return false;   // cubes of DEEP blocks only: they then lie inside the first class below
         if (P->bf_off[b + 1] != P->bf_off[b]) return false;
-        for (int d = 0; d < 3; d++) {
-          const int32_t pe = P->plus[static_cast<size_t>(b) * 3 + d], me = P->minus[static_cast<size_t>(b) * 3 + d];
+        for (int d = 0; d < rank; d++) {
+          const int32_t pe = P->plus[static_cast<size_t>(b) * rank + d], me = P->minus[static_cast<size_t>(b) * rank + d];
           if (pe == -1 || me == -1) return false;
           int32_t hang = 0;
           if (!((w >> d) & 1)) {
@@ -164,11 +166,11 @@ void* t8gpu_plan_subgrid_create(int32_t N, int32_t F, int32_t B, int32_t rank, c
       }
       return true;
     };
-    for (int32_t e = 0; e + 8 <= N;) {
+    for (int32_t e = 0; e + NB <= N;) {
       if (is_family(e)) {
         P->fam_first.push_back(e);
-        for (int w = 0; w < 8; w++) P->in_family[e + w] = 1;
-        e += 8;
+        for (int w = 0; w < NB; w++) P->in_family[e + w] = 1;
+        e += NB;
       } else {
         e++;
       }
@@ -198,7 +200,7 @@ void t8gpu_plan_subgrid_sizes(const void* h, int64_t* sizes) {
   sizes[4] = P->n_deep;
   sizes[5] = P->n_addressed > P->N ? P->n_addressed : P->N;
   sizes[6] = static_cast<int64_t>(P->fam_first.size());
-  sizes[7] = static_cast<int64_t>(P->N) - 8 * static_cast<int64_t>(P->fam_first.size());
+  sizes[7] = static_cast<int64_t>(P->N) - (static_cast<int64_t>(1) << P->rank) * static_cast<int64_t>(P->fam_first.size());
 }
 
 void t8gpu_plan_subgrid_order(const void* h, int32_t* block_order) {
@@ -292,27 +294,32 @@ void t8gpu_plan_subgrid_records(const void* h, const double* areas, int float_si
 }
 
 
-// Family records (RANK 3; see t8gpu_plan_subgrid_create): fam_rec[n_families][160] =
+// Family records (see t8gpu_plan_subgrid_create). RANK 3: fam_rec[n_families][160] =
 //   {first block, 0, 0, 0,
 //    12 rows for the outward + faces: row d * 4 + j = the +d face of the j-th block (ascending) that has bit d SET,
 //    12 rows for the outward - faces: row 12 + d * 4 + j = the -d face of the j-th block that has bit d CLEAR,
 //    12 rows for the inner coarse faces: row 24 + d * 4 + j = the +d face of the j-th block that has bit d CLEAR (only
 //    its area is read: the far cell is the sibling's, in LDS)}, rows as in block_rec: {far, code, area (2 words)};
+// RANK 2: fam_rec[n_families][64] = {first block, 0, 0, 0, 4 + 4 + 4 rows likewise: row d * 2 + j, 4 + d * 2 + j, 8 + d * 2 + j};
 // rest_rec[n_rest][32] = the block_rec rows of the blocks outside every family, in block_order order (same bf_rec).
 void t8gpu_plan_subgrid_family_records(const void* h, const double* areas, int float_size, int32_t* fam_rec, int32_t* rest_rec) {
   const SubgridPlan* P = static_cast<const SubgridPlan*>(h);
-  auto expand = [](int j, int d) { return d == 0 ? j << 1 : (d == 1 ? (j & 1) | ((j >> 1) << 2) : j); };   // a zero bit at d
+  const int rank = P->rank, per = 1 << (rank - 1), rows = rank * per, words = rank == 3 ? 160 : 64;   // per: blocks per (axis, side)
+  auto expand = [&](int j, int d) {   // a zero bit at position d
+    if (rank == 2) return d == 0 ? j << 1 : j;
+    return d == 0 ? j << 1 : (d == 1 ? (j & 1) | ((j >> 1) << 2) : j);
+  };
   for (size_t q = 0; q < P->fam_first.size(); q++) {
-    int32_t*      rec = fam_rec + 160 * q;
+    int32_t*      rec = fam_rec + static_cast<size_t>(words) * q;
     const int32_t e0  = P->fam_first[q];
-    std::memset(rec, 0, 160 * sizeof(int32_t));
+    std::memset(rec, 0, words * sizeof(int32_t));
     rec[0] = e0;
-    for (int d = 0; d < 3; d++)
-      for (int j = 0; j < 4; j++) {
+    for (int d = 0; d < rank; d++)
+      for (int j = 0; j < per; j++) {
         const int lo = expand(j, d), hi = lo | (1 << d);
-        put_row(P, areas, float_size, rec + 4 + 4 * (d * 4 + j), P->plus[static_cast<size_t>(e0 + hi) * 3 + d]);
-        put_row(P, areas, float_size, rec + 4 + 4 * (12 + d * 4 + j), P->minus[static_cast<size_t>(e0 + lo) * 3 + d]);
-        put_row(P, areas, float_size, rec + 4 + 4 * (24 + d * 4 + j), P->plus[static_cast<size_t>(e0 + lo) * 3 + d]);
+        put_row(P, areas, float_size, rec + 4 + 4 * (d * per + j), P->plus[static_cast<size_t>(e0 + hi) * rank + d]);
+        put_row(P, areas, float_size, rec + 4 + 4 * (rows + d * per + j), P->minus[static_cast<size_t>(e0 + lo) * rank + d]);
+        put_row(P, areas, float_size, rec + 4 + 4 * (2 * rows + d * per + j), P->plus[static_cast<size_t>(e0 + lo) * rank + d]);
       }
   }
   // the remaining blocks keep their block records (and their rows of bf_rec: `first` counts every block's entries)

@@ -121,11 +121,11 @@ class HostSubgridPlan:
         return block_rec, bf_rec
 
     def family_records(self, areas, float_size):
-        """fam_rec [n_families, 160], rest_rec [n_rest, 32] (RANK 3; see T8gpuSubgridPlan)."""
+        """fam_rec [n_families, 160 (RANK 3) / 64 (RANK 2)], rest_rec [n_rest, 32] (see T8gpuSubgridPlan)."""
         lib = _synth.lib()
         lib.t8gpu_plan_subgrid_family_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         ar = np.ascontiguousarray(areas, np.float64)
-        fam_rec = np.zeros((max(1, self.n_families), 160), np.int32)
+        fam_rec = np.zeros((max(1, self.n_families), 160 if self.rank == 3 else 64), np.int32)
         rest_rec = np.zeros((max(1, self.n_rest), 32), np.int32)
         lib.t8gpu_plan_subgrid_family_records(self._h, _synth._p(ar), int(float_size), _synth._p(fam_rec), _synth._p(rest_rec))
         return fam_rec, rest_rec

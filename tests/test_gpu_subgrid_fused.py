@@ -135,8 +135,10 @@ from t8gpu_amd import hip
 from t8gpu_amd.solver import SubgridSolver
 from t8gpu_amd.synth import SynthMesh
 out = []
-for args in (dict(base_level=2, max_level=2), dict(base_level=3, max_level=4, band=0.03), dict(base_level=2, max_level=4, band=0.05, periodic=False)):
-    mesh = SynthMesh(3, **args)
+for dim, args in ((3, dict(base_level=2, max_level=2)), (3, dict(base_level=3, max_level=4, band=0.03)),
+                  (3, dict(base_level=2, max_level=4, band=0.05, periodic=False)), (2, dict(base_level=3, max_level=3)),
+                  (2, dict(base_level=3, max_level=6, band=0.03)), (2, dict(base_level=3, max_level=5, band=0.03, periodic=False))):
+    mesh = SynthMesh(dim, **args)
     part = mesh.partition(subgrid=True)
     for dtype in (torch.float32, torch.float64):
         for kind in (hip.KEPES, hip.HLL, hip.HLLC):
@@ -150,7 +152,7 @@ np.save(sys.argv[1], np.concatenate(out))
 
 
 def test_family_kernel_and_block_kernel_agree_bitwise(tmp_path):
-    """2x2x2 cubes of same-level blocks run through the family kernel (one workgroup per cube, inner coarse faces
+    """2x2x2 cubes (3D) / 2x2 squares (2D) of same-level blocks run through the family kernels (inner coarse faces
     evaluated once, outward far cells pooled); T8GPU_SG_FAMILY=0 sends every block through the block kernel. Same
     fluxes, same summation order: the states must agree bit for bit (periodic, walled, 2:1 meshes; three fluxes)."""
     import os
