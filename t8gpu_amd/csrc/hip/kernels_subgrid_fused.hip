@@ -1,5 +1,10 @@
-// kernels_subgrid_fused.hip -- Subgrid<4,4,4> (one 64-lane wavefront = one block) and Subgrid<4,4> (four
-// blocks per wavefront): one launch per RK stage.
+// kernels_subgrid_fused.hip -- Subgrid<4,4,4> and Subgrid<4,4>: one launch per RK stage. Three kernels:
+//   k_subgrid_fused    the BLOCK kernel: one 64-lane wavefront = one 4x4x4 block (or four 4x4 blocks), described below;
+//   k_subgrid_family   3D: one workgroup of eight wavefronts = a 2x2x2 cube of same-level blocks -- inner coarse faces
+//                      evaluated once from LDS, the far cells of the outward faces pooled over the wavefronts;
+//   k_subgrid_family2  2D: one wavefront = a 2x2 square of blocks, the same within a wavefront.
+// The launcher (subgrid_fused_stage) takes the family kernels wherever the host plan found cubes / squares and runs the
+// remaining blocks with the block algorithm in the same launch; all three give the same bits.
 //
 // Replaces, per stage, compute_inner_fluxes + compute_boundary_fluxes + compute_outer_fluxes +
 // subgrid::SSP_3RK_stepK (examples/subgrid/solver.inl:166-195) and their flux-plane round trips
