@@ -507,7 +507,7 @@ template <class T, int KIND, int STAGE, bool WIDE>
 __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_subgrid_family(T8gpuSubgridPlan P, SVars<T> prev, SVars<T> src, SVars<T> out,
                                                         const T* __restrict__ volumes, T dt) {
   constexpr int  NW    = CellData<T, KIND>::words;
-  constexpr bool EARLY = false;   // previous-step state fetched last: requested up front it costs registers the kernel does not have
+  constexpr bool EARLY = sizeof(T) == 4;   // fp32: previous-step state requested up front; fp64: fetched last (registers)
   constexpr int FAM_WORDS = NW * 704 + 3 * 5 * 64 + 5 * 512;       // this kernel's arrays
   constexpr int BLK_WORDS = NW * 112 + 5 * 64;                      // one wavefront of the block algorithm
   constexpr int RESTB     = sizeof(T) == 8 ? 4 : 8;                 // leftover blocks per workgroup (fp64: LDS for 4 only)
