@@ -58,6 +58,29 @@ def test_fused_block_kernel_properties_at_c3_size():
     assert np.abs(av - cv).max() / np.abs(cv).max() < 2e-5       # rho_v2 is ~0 in this case: normalise globally
 
 
+def test_fused_kernels_properties_at_c3q_size():
+    """The reference's 2D example at its own size (examples/subgrid/main_2d.cu: levels 9-10, 581 632 blocks = 9.3 M subcells,
+    fp64): the 2D family kernel + leftover blocks -- conservation, reproducibility, fused == compat."""
+    mesh = SynthMesh(2, 9, 10, band=0.1)
+    part = mesh.partition(subgrid=True)
+    a = SubgridSolver(part, torch.float64, mode="fused")
+    b = SubgridSolver(part, torch.float64, mode="fused")
+    c = SubgridSolver(part, torch.float64, mode="compat")
+    assert a.plan.host.n_families > 0.9 * part.N / 4
+    dt = 0.1 * 2.0 ** -(mesh.finest_level + 2)
+    cellvol = torch.from_numpy(np.repeat(part.volumes / 16, 16)).cuda()
+    m0 = (a.state() * cellvol).sum(1)
+    for _ in range(2):
+        a.iterate(dt)
+        b.iterate(dt)
+        c.iterate(dt)
+    assert torch.equal(a.state(), b.state())
+    m1 = (a.state() * cellvol).sum(1)
+    assert float((m1 - m0).abs().max()) < 1e-12 * float(m0.abs().max())
+    av, cv = a.state().cpu().numpy(), c.state().cpu().numpy()
+    assert np.abs(av - cv).max() / np.abs(cv).max() < 1e-11
+
+
 @pytest.mark.parametrize("kind", [hip.KEPES, hip.HLLC])
 def test_long_run_stays_physical_and_conservative(kind):
     """Subgrid<4,4> Kelvin-Helmholtz with hanging block faces to t ~ 1.5 (fp64): positive density and pressure,
