@@ -265,12 +265,14 @@ typedef struct T8gpuSubgridPlan {
   int32_t n_blocks_addressed;   /* 1 + the largest block index any record refers to (owned and ghost blocks; sizes[5] of
                                    t8gpu_plan_subgrid_sizes): lets the kernel use 32-bit byte offsets into the state planes
                                    when a plane is shorter than 4 GiB. 0 = unknown (64-bit addressing) */
-  /* optional (RANK 3, t8gpu_plan_subgrid_family_records()): 2x2x2 cubes of consecutive same-level blocks take the family
-   * kernel (one workgroup of 8 wavefronts per cube) when a launch covers the whole plan; the blocks outside every family
-   * then run through rest_rec. n_families = 0: every block through block_rec. */
-  const int32_t* fam_rec;       /* [n_families][160]: {first block, 0, 0, 0, 36 rows {far, code, area (2 words)}}: the 12
-                                   outward + faces, the 12 outward - faces, the 12 inner faces (layout: subgrid_plan.cpp) */
-  const int32_t* rest_rec;      /* [n_rest][32]: block_rec rows of the blocks outside every family */
+  /* optional (t8gpu_plan_subgrid_family_records()): 2x2x2 cubes (RANK 3) / 2x2 squares (RANK 2) of consecutive same-level
+   * deep interior blocks take the family kernels (one workgroup of 8 wavefronts per cube / one wavefront per square) when a
+   * launch covers the whole plan or exactly its first class [0, n_deep_blocks); the blocks outside every family then run
+   * through rest_rec (launches inside the later classes read rest_rec too). n_families = 0: every block through block_rec. */
+  const int32_t* fam_rec;       /* RANK 3: [n_families][160] = {first block, 0, 0, 0, 36 rows {far, code, area (2 words)}}: the 12
+                                   outward + faces, the 12 outward - faces, the 12 inner faces; RANK 2: [n_families][64] with
+                                   4 + 4 + 4 rows (layout: subgrid_plan.cpp) */
+  const int32_t* rest_rec;      /* [n_rest][32]: block_rec rows of the blocks outside every family, in block_order order */
   int32_t n_families, n_rest;
 } T8gpuSubgridPlan;
 

@@ -84,8 +84,9 @@ void t8gpu_plan_subgrid_arrays(const void* plan, int32_t* bf_off, int32_t* bf_en
  * block_rec[N][32] in block_order position order (128-byte rows, see T8gpuSubgridPlan), bf_rec[n_entries][4]; areas = face_surfaces[F + B] (doubles),
  * float_size = 4 or 8 selects how the areas are stored in the records. */
 void t8gpu_plan_subgrid_records(const void* plan, const double* areas, int float_size, int32_t* block_rec, int32_t* bf_rec);
-/* RANK 3: the 2x2x2 families of consecutive same-level blocks (sizes[6] of them) and the remaining blocks (sizes[7]):
- * fam_rec[n_families][160], rest_rec[n_rest][32] (layout: csrc/host/subgrid_plan.cpp; T8gpuSubgridPlan::fam_rec / rest_rec) */
+/* The 2x2x2 (RANK 3) / 2x2 (RANK 2) families of consecutive same-level deep interior blocks (sizes[6] of them) and the
+ * remaining blocks (sizes[7]): fam_rec[n_families][160 or 64], rest_rec[n_rest][32] (layout: csrc/host/subgrid_plan.cpp;
+ * T8gpuSubgridPlan::fam_rec / rest_rec) */
 void t8gpu_plan_subgrid_family_records(const void* plan, const double* areas, int float_size, int32_t* fam_rec, int32_t* rest_rec);
 
 /* ---- connectivity from forest queries (the t8code-independent part) -------------------------
