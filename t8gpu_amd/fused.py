@@ -27,11 +27,16 @@ class PlainPlan:
         tmax = int(os.environ.get("T8GPU_TMAX", 128 if small else 256)) if tmax is None else tmax
         if small:
             fcap = int(os.environ.get("T8GPU_FCAP", 256))
-        # 512 faces = two passes of 256. Larger tiles (the kernel takes up to 1024 faces in four passes) were
-        # measured on 3D meshes, where 512 cuts tiles at ~130-150 elements: 768 / 1024 are 1-8 % SLOWER (LDS per
-        # workgroup grows, 3 instead of 4 workgroups per CU), and so is a 512-lane workgroup with one lane per
-        # own + halo element and two passes of 512 faces (-5 ... -7 %: fewer instructions, but 8 waves per barrier
-        # and 2 workgroups per CU), so 512 stays the default for every mesh.
+        # 512 faces = two passes of 256: what the persistent kernel takes, and the default. (Round 1 measured larger tiles
+        # 1-8 % slower on 3D meshes because the one-tile kernel then lost its fourth workgroup per CU; since round 2 that
+        # kernel holds three either way, and 3D AMR meshes get 768 -- below.) A 512-lane workgroup with one lane per own +
+        # halo element and two passes of 512 faces was 5-7 % slower (8 waves per barrier, 2 workgroups per CU).
+        if fcap is None and "T8GPU_FCAP" not in os.environ and not small and self._wide_rows(part):
+            # elements with more than 8 faces (3D AMR, tetrahedron / hexahedron meshes): their 16-entry ELL rows rule the
+            # persistent kernel out anyway, and the one-tile kernel -- 146 VGPRs, three workgroups per CU whatever the LDS
+            # -- does better on tiles of up to 768 faces in three passes (c5: 134 -> ~200 elements per tile, 4 110 ->
+            # 4 450 M cell-updates/s; c5t +3 %). Meshes the persistent kernel can take keep its 512-face tiles.
+            fcap = 768
         fcap = int(os.environ.get("T8GPU_FCAP", 512)) if fcap is None else fcap
         # the per-face geometry rows are only read by the kernels without a dictionary (generic kernel, dictionary=False)
         self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary))
@@ -73,6 +78,18 @@ class PlainPlan:
         c.max_elems, c.max_halo, c.max_faces = self.host.max_elems, self.host.max_halo, self.host.max_faces
         c.max_slots, c.n_deep_tiles = self.host.max_slots, self.host.n_deep
         self.c = c
+
+    @staticmethod
+    def _wide_rows(part):
+        """True if some owned element has more than 8 faces (ELL rows of 16 or 24 entries: tile_plan.cpp)."""
+        fn = np.asarray(part.face_neighbors).reshape(-1)
+        F, N = part.F, part.N
+        l, r = fn[0:2 * F:2], fn[1:2 * F:2]
+        deg = np.bincount(l[l < N], minlength=N) + np.bincount(r[(r < N) & (r != l)], minlength=N)
+        if part.B:
+            lb = fn[2 * F:2 * F + part.B]
+            deg = deg + np.bincount(lb[lb < N], minlength=N)
+        return bool(deg.size) and int(deg.max()) > 8
 
     def stage(self, solver, stage, src, dst, dt, stream, tile_begin=0, tile_count=None):
         from .solver import _timer_begin, _timer_end
