@@ -31,11 +31,14 @@ class PlainPlan:
         # 1-8 % slower on 3D meshes because the one-tile kernel then lost its fourth workgroup per CU; since round 2 that
         # kernel holds three either way, and 3D AMR meshes get 768 -- below.) A 512-lane workgroup with one lane per own +
         # halo element and two passes of 512 faces was 5-7 % slower (8 waves per barrier, 2 workgroups per CU).
-        if fcap is None and "T8GPU_FCAP" not in os.environ and not small and self._wide_rows(part):
-            # elements with more than 8 faces (3D AMR, tetrahedron / hexahedron meshes): their 16-entry ELL rows rule the
-            # persistent kernel out anyway, and the one-tile kernel -- 146 VGPRs, three workgroups per CU whatever the LDS
-            # -- does better on tiles of up to 768 faces in three passes (c5: 134 -> ~200 elements per tile, 4 110 ->
-            # 4 450 M cell-updates/s; c5t +3 %). Meshes the persistent kernel can take keep its 512-face tiles.
+        if (fcap is None and "T8GPU_FCAP" not in os.environ and not small and getattr(part.mesh, "dim", 2) == 3 and
+                (self._wide_rows(part) or self._many_geometries(part))):
+            # 3D meshes the persistent kernel cannot take -- elements with more than 8 faces (3D AMR, tetrahedron /
+            # hexahedron meshes: 16-entry ELL rows) or no small geometry dictionary (curved meshes) -- run the one-tile
+            # kernel, which holds three workgroups per CU whatever the LDS (146 VGPRs) and does better on tiles of up to 768
+            # faces in three passes: ~200 instead of 134 elements per 256-lane workgroup. c5 4 110 -> 4 450, c5p 4 230 ->
+            # 4 545, c5t 4 380 -> 4 540 M cell-updates/s. Meshes the persistent kernel takes keep its 512-face tiles, 2D
+            # meshes too (their 35 KB tiles are what the DENSE budget needs).
             fcap = 768
         fcap = int(os.environ.get("T8GPU_FCAP", 512)) if fcap is None else fcap
         # the per-face geometry rows are only read by the kernels without a dictionary (generic kernel, dictionary=False)
@@ -90,6 +93,15 @@ class PlainPlan:
             lb = fn[2 * F:2 * F + part.B]
             deg = deg + np.bincount(lb[lb < N], minlength=N)
         return bool(deg.size) and int(deg.max()) > 8
+
+    @staticmethod
+    def _many_geometries(part, sample=20000, limit=128):
+        """True if already a sample of the faces shows more distinct {normal, area} rows than the persistent kernel's
+        LDS dictionary holds (curved meshes: every face its own)."""
+        nd = part.normal_dim
+        nrm = np.asarray(part.normals, np.float64).reshape(-1, nd)[:sample]
+        rows = np.concatenate([nrm, np.asarray(part.areas, np.float64).reshape(-1, 1)[:sample]], axis=1)
+        return np.unique(rows, axis=0).shape[0] > limit
 
     def stage(self, solver, stage, src, dst, dt, stream, tile_begin=0, tile_count=None):
         from .solver import _timer_begin, _timer_end
