@@ -652,12 +652,9 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_subgrid_family(
 #pragma unroll
     for (int k = 0; k < 5; k++) pv[k] = at<WIDE>(prev.p[k], o);
   }
-  T s1[5];   // fp64: the own state is fetched again here instead of occupying ten registers through the flux passes
-#pragma unroll
-  for (int k = 0; k < 5; k++) s1[k] = sizeof(T) == 8 ? at<WIDE>(src.p[k], o) : s0[k];
   const T scale = dt / (vol / T(64));
 #pragma unroll
-  for (int k = 0; k < 5; k++) at<WIDE>(out.p[k], o) = rk_stage_update<T, STAGE>(pv[k], s1[k], scale, acc[k]);
+  for (int k = 0; k < 5; k++) at<WIDE>(out.p[k], o) = rk_stage_update<T, STAGE>(pv[k], s0[k], scale, acc[k]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
