@@ -31,14 +31,15 @@ class PlainPlan:
         # 1-8 % slower on 3D meshes because the one-tile kernel then lost its fourth workgroup per CU; since round 2 that
         # kernel holds three either way, and 3D AMR meshes get 768 -- below.) A 512-lane workgroup with one lane per own +
         # halo element and two passes of 512 faces was 5-7 % slower (8 waves per barrier, 2 workgroups per CU).
-        if (fcap is None and "T8GPU_FCAP" not in os.environ and not small and getattr(part.mesh, "dim", 2) == 3 and
-                (self._wide_rows(part) or self._many_geometries(part))):
+        if (fcap is None and "T8GPU_FCAP" not in os.environ and not small and dtype == torch.float64 and
+                getattr(part.mesh, "dim", 2) == 3 and (self._wide_rows(part) or self._many_geometries(part))):
             # 3D meshes the persistent kernel cannot take -- elements with more than 8 faces (3D AMR, tetrahedron /
             # hexahedron meshes: 16-entry ELL rows) or no small geometry dictionary (curved meshes) -- run the one-tile
             # kernel, which holds three workgroups per CU whatever the LDS (146 VGPRs) and does better on tiles of up to 768
             # faces in three passes: ~200 instead of 134 elements per 256-lane workgroup. c5 4 110 -> 4 450, c5p 4 230 ->
-            # 4 545, c5t 4 380 -> 4 540 M cell-updates/s. Meshes the persistent kernel takes keep its 512-face tiles, 2D
-            # meshes too (their 35 KB tiles are what the DENSE budget needs).
+            # 4 545, c5t 4 380 -> 4 540 M cell-updates/s (fp64 KEPES; HLL +3 %). Meshes the persistent kernel takes keep its
+            # 512-face tiles, 2D meshes too (their 35 KB tiles are what the DENSE budget needs; 768: -13 %), and so does
+            # fp32, whose kernels fit four to five workgroups per CU on 512-face tiles (c5 fp32 with 768: -9 %).
             fcap = 768
         fcap = int(os.environ.get("T8GPU_FCAP", 512)) if fcap is None else fcap
         # the per-face geometry rows are only read by the kernels without a dictionary (generic kernel, dictionary=False)
