@@ -75,3 +75,19 @@ def test_plan_rejects_oversized_tiles():
     part = SynthMesh(2, 4, 4).partition()
     with pytest.raises(ValueError):
         HostPlainPlan.from_partition(part, tmax=2000, fcap=10 ** 6)
+
+
+def test_tile_cap_heuristics_of_the_device_plan():
+    """t8gpu_amd/fused.py picks 768-face tiles for fp64 on 3D meshes the persistent kernel cannot take: elements with more
+    than 8 faces (16-entry ELL rows) or more distinct {normal, area} rows than its LDS dictionary holds."""
+    from t8gpu_amd.fused import PlainPlan
+    from t8gpu_amd.synth import SynthMesh
+    from t8gpu_amd.unstructured import PrismHexMesh
+    amr2 = SynthMesh(2, base_level=4, max_level=7, band=0.05).partition()
+    amr3 = SynthMesh(3, base_level=3, max_level=5, band=0.05).partition()
+    uni3 = SynthMesh(3, base_level=3, max_level=3).partition()
+    curved = PrismHexMesh((8, 8, 10)).partition()
+    assert not PlainPlan._wide_rows(amr2) and not PlainPlan._many_geometries(amr2)
+    assert PlainPlan._wide_rows(amr3) and not PlainPlan._many_geometries(amr3)
+    assert not PlainPlan._wide_rows(uni3) and not PlainPlan._many_geometries(uni3)
+    assert not PlainPlan._wide_rows(curved) and PlainPlan._many_geometries(curved)
