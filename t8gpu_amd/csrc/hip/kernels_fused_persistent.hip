@@ -423,8 +423,9 @@ int plain_persistent_stage(int kind, int stage, const T8gpuPlainPlan* plan, int 
   // (then this kernel is simply the cheaper one-tile kernel). In between (c2: 4.4 k tiles, < 6 per workgroup) the
   // exposed first tile of every workgroup and the ragged last round cost more than the pipelining saves: measured
   // 0.047 vs 0.044 ms per stage, so those launches go back to the one-tile kernel.
+  // (fp64 KEPES: small launches too -- there the one-tile kernel has its denser register budget: c1 2 270 -> 2 400 M/s)
   const int resident = cus * per_cu;
-  if (per_cu_env == 0 && tile_count > resident && tile_count < 8 * resident) return -1;
+  if (per_cu_env == 0 && tile_count < 8 * resident && (tile_count > resident || (kind == 0 && sizeof(T) == 8))) return -1;
   const int  grid_size = tile_count < resident ? tile_count : resident;
   const dim3 grid(grid_size), block(256);
 #define T8_P(K, S) hipLaunchKernelGGL((k_plain_persistent<T, K, S>), grid, block, lds, stream, *plan, tile_begin, tile_count, prev, mid, out, volume, dt, speed)
