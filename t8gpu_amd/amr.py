@@ -14,6 +14,15 @@ from . import hip
 from .solver import FLUXES, PlainSolver
 
 
+def _inherited_plan_options(solver):
+    """Tile caps of the adapted mesh's plan: those the previous plan settled on (fused.PlainPlan may build a plan twice to
+    find out which kernel a mesh class gets; an adaptive run should pay for that once, not at every adapt)."""
+    plan = getattr(solver, "plan", None)
+    if plan is None or getattr(plan, "auto_fcap", None) is None:
+        return None
+    return {"fcap": plan.auto_fcap}
+
+
 def refinement_criteria(solver):
     """estimate_gradient + compute_refinement_criteria (solver.cu:245-263); returns a device tensor [N]."""
     s = hip.stream_ptr()
@@ -38,7 +47,7 @@ def adapt(solver, threshold=10.0, min_level=1, max_level=4, family_members_avera
     new_part = new_mesh.partition(0, 1, subgrid=False, normal_dim=part.normal_dim)
     dim = mesh.dim if volume_dim is None else volume_dim
     new = PlainSolver(new_part, solver.dtype, flux_kind=solver.kind, mode=solver.mode,
-                      state=np.zeros((5, new_part.N + new_part.G)))
+                      state=np.zeros((5, new_part.N + new_part.G)), plan_options=_inherited_plan_options(solver))
     new.next, new.prev = solver.next, solver.prev
     ad = torch.from_numpy(adapt_data).cuda()
     hip.call("t8gpu_hip_adapt_variables_and_volume", solver.dtype, new_part.N, dim, hip.ptr(ad),
@@ -93,7 +102,8 @@ class PartitionedAdapt:
         # 2. the new partition and an empty solver for it
         self.new_part = self.new_mesh.partition(self.rank, self.world, subgrid=False, normal_dim=part.normal_dim)
         self.new_solver = PlainSolver(self.new_part, dtype, flux_kind=solver.kind, mode=solver.mode,
-                                      state=np.zeros((5, self.new_part.N + self.new_part.G)))
+                                      state=np.zeros((5, self.new_part.N + self.new_part.G)),
+                                      plan_options=_inherited_plan_options(solver))
         self.new_solver.next, self.new_solver.prev = solver.next, solver.prev
         # 3. message plan: intersections of what I have with what every rank will own (and vice versa)
         self.sends, self.recvs = [], []

@@ -119,7 +119,8 @@ struct TileDesc {
 };
 
 // (second launch bound = waves per SIMD the register allocation must allow: 3 workgroups per CU in fp64, 5 in fp32)
-template <class T, int KIND, int STAGE>
+// ELLC = 8-entry chunks per ELL row: 1 (2D meshes, uniform 3D meshes) or up to 3 (3D AMR: up to 24 faces per element)
+template <class T, int KIND, int STAGE, int ELLC>
 __global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_persistent(T8gpuPlainPlan P, int tile_begin, int tile_count, FVars<T> prev,
                                                           FVars<T> src, FVars<T> out, const T* __restrict__ vol, T dt,
                                                           T* __restrict__ speed) {
@@ -234,6 +235,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_persisten
       for (int k = 0; k < 5; k++) pv[k] = prev.p[k][e];
     }
     const T volume = vol[e];
+    // second chunk of this tile's face lists (3D AMR): requested with the previous state, needed just before it
+    uint4 ell1 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (ELLC > 1) ell1 = *reinterpret_cast<const uint4*>(P.ell + static_cast<size_t>(e) * P.ell_width + 8);
     // ---- phase 1: the tile's own + halo elements -> LDS records ---------------------------------------------
     if (a0) {
       T w[NW];
@@ -368,7 +372,15 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_persisten
     __syncthreads();
     // ---- phase 3: each owned element sums its faces in list order -------------------------------------------------
     T acc[5] = {T(0), T(0), T(0), T(0), T(0)};
-    if (own) ell_gather<T>(cur.ell, ff, acc);
+    if (own) {
+      ell_gather<T>(cur.ell, ff, acc);
+      if (ELLC > 1) {
+        ell_gather<T>(ell1, ff, acc);
+        // a third chunk only where an element has more than 15 faces (rare: fetched here, other waves cover it)
+        if (ELLC > 2 && P.ell_width > 16 && (ell1.w >> 16) != 0xFFFFu)
+          ell_gather<T>(*reinterpret_cast<const uint4*>(P.ell + static_cast<size_t>(e) * P.ell_width + 16), ff, acc);
+      }
+    }
 
     // ---- RK stage (ssp_runge_kutta.inl:30-99); stored at the top of the next iteration --------------------------
     const T scale = dt / volume;
@@ -395,9 +407,10 @@ int plain_persistent_stage(int kind, int stage, const T8gpuPlainPlan* plan, int 
                            FVars<T> mid, FVars<T> out, const T* volume, T dt, T* speed, hipStream_t stream) {
   static const bool off = std::getenv("T8GPU_PERSISTENT") && std::getenv("T8GPU_PERSISTENT")[0] == '0';
   const int slots = plan->max_slots;
-  // what this kernel takes: the compressed plan with a geometry dictionary small enough for LDS, 8-entry ELL rows,
-  // tiles of <= 256 elements, <= 512 own + halo slots and <= 512 faces
-  if (off || !plan->tile_desc || !plan->ell || plan->ell_width != 8 || !plan->geo_idx || !plan->geo_table || plan->n_geo <= 0 || plan->n_geo > 128 ||
+  // what this kernel takes: the compressed plan with a geometry dictionary small enough for LDS, ELL rows of 8, 16 or 24
+  // entries (the second chunk travels with the previous state, a third is fetched where an element has more than 15
+  // faces), tiles of <= 256 elements, <= 512 own + halo slots and <= 512 faces
+  if (off || !plan->tile_desc || !plan->ell || (plan->ell_width != 8 && plan->ell_width != 16 && plan->ell_width != 24) || !plan->geo_idx || !plan->geo_table || plan->n_geo <= 0 || plan->n_geo > 128 ||
       plan->max_elems > 256 || slots <= 0 || slots > 512 || plan->max_faces > 512)
     return -1;
   const int    nw  = kind == 0 ? kPrimWords : 5;
@@ -405,6 +418,10 @@ int plain_persistent_stage(int kind, int stage, const T8gpuPlainPlan* plan, int 
   const size_t lds = sizeof(T) * (static_cast<size_t>(5) * 512 + static_cast<size_t>(12) * plan->n_geo + static_cast<size_t>(rec) * slots) +
                      ((sizeof(T) == 8 && kind == 0) ? 2 * kLogTabEntries * sizeof(double) : 0);
   if (lds > 64 * 1024) return -1;
+  // fp64: the kernel lives on three workgroups per CU. 3 x 53.1 KB (a 3D tile of 376 slots) is nominally inside the 160 KB
+  // and yet only two become resident (c5 on 512-face tiles: 3 950 against 4 110 M/s for the one-tile kernel); with a margin
+  // the third fits (480-face tiles, 51.7 KB: 4 770). Plans above the margin go to the one-tile kernel.
+  if (sizeof(T) == 8 && 3 * lds > static_cast<size_t>(156) * 1024) return -1;
   // persistent grid: enough workgroups to fill the chip at the occupancy the kernel reaches, never more than there are
   // tiles. T8GPU_PERSISTENT_WGS overrides the per-CU count (tuning).
   static int per_cu_env = 0, cus = 0;
@@ -428,7 +445,14 @@ int plain_persistent_stage(int kind, int stage, const T8gpuPlainPlan* plan, int 
   if (per_cu_env == 0 && tile_count < 8 * resident && (tile_count > resident || (kind == 0 && sizeof(T) == 8))) return -1;
   const int  grid_size = tile_count < resident ? tile_count : resident;
   const dim3 grid(grid_size), block(256);
-#define T8_P(K, S) hipLaunchKernelGGL((k_plain_persistent<T, K, S>), grid, block, lds, stream, *plan, tile_begin, tile_count, prev, mid, out, volume, dt, speed)
+#define T8_PE(K, S, C) hipLaunchKernelGGL((k_plain_persistent<T, K, S, C>), grid, block, lds, stream, *plan, tile_begin, tile_count, prev, mid, out, volume, dt, speed)
+#define T8_P(K, S)          \
+  do {                      \
+    if (plan->ell_width == 8) \
+      T8_PE(K, S, 1);       \
+    else                    \
+      T8_PE(K, S, 3);       \
+  } while (0)
 #define T8_PS(K)             \
   do {                       \
     if (stage == 1)          \
@@ -446,6 +470,7 @@ int plain_persistent_stage(int kind, int stage, const T8gpuPlainPlan* plan, int 
     T8_PS(2);
 #undef T8_PS
 #undef T8_P
+#undef T8_PE
   return static_cast<int>(hipGetLastError());
 }
 

@@ -23,6 +23,7 @@ class PlainPlan:
         import os
         # tuning knobs of the tiling. A mesh that would give fewer than 512 tiles (two per CU) gets half-size tiles:
         # c1 (65 536 elements) runs 16 % faster on 512 tiles of 128 than on 256 tiles of 256.
+        given_fcap = fcap
         small = part.N < 512 * 256 and tmax is None and fcap is None and "T8GPU_TMAX" not in os.environ
         tmax = int(os.environ.get("T8GPU_TMAX", 128 if small else 256)) if tmax is None else tmax
         if small:
@@ -31,19 +32,33 @@ class PlainPlan:
         # 1-8 % slower on 3D meshes because the one-tile kernel then lost its fourth workgroup per CU; since round 2 that
         # kernel holds three either way, and 3D AMR meshes get 768 -- below.) A 512-lane workgroup with one lane per own +
         # halo element and two passes of 512 faces was 5-7 % slower (8 waves per barrier, 2 workgroups per CU).
+        # the face cap chosen by the heuristics below, or handed down from the plan of the mesh this one was adapted from
+        # (amr._inherited_plan_options); None: the default
+        self.auto_fcap = given_fcap
+        retry_768 = given_fcap == 480 and dtype == torch.float64      # an inherited 480 still has to fit the persistent kernel
         if (fcap is None and "T8GPU_FCAP" not in os.environ and not small and dtype == torch.float64 and
-                getattr(part.mesh, "dim", 2) == 3 and (self._wide_rows(part) or self._many_geometries(part))):
-            # 3D meshes the persistent kernel cannot take -- elements with more than 8 faces (3D AMR, tetrahedron /
-            # hexahedron meshes: 16-entry ELL rows) or no small geometry dictionary (curved meshes) -- run the one-tile
-            # kernel, which holds three workgroups per CU whatever the LDS (146 VGPRs) and does better on tiles of up to 768
-            # faces in three passes: ~200 instead of 134 elements per 256-lane workgroup. c5 4 110 -> 4 450, c5p 4 230 ->
-            # 4 545, c5t 4 380 -> 4 540 M cell-updates/s (fp64 KEPES; HLL +3 %). Meshes the persistent kernel takes keep its
-            # 512-face tiles, 2D meshes too (their 35 KB tiles are what the DENSE budget needs; 768: -13 %), and so does
-            # fp32, whose kernels fit four to five workgroups per CU on 512-face tiles (c5 fp32 with 768: -9 %).
-            fcap = 768
+                getattr(part.mesh, "dim", 2) == 3):
+            # fp64 on 3D meshes. Curved meshes (no small geometry dictionary) run the one-tile kernel, which holds three
+            # workgroups per CU whatever the LDS (146 VGPRs) and does better on tiles of up to 768 faces in three passes
+            # (~200 instead of 134 elements per 256-lane workgroup): c5p 4 230 -> 4 545, c5t 4 380 -> 4 540 M cell-updates/s.
+            # Cartesian 3D AMR (elements with more than 8 faces) runs the persistent kernel IF its third workgroup per CU
+            # fits: 480-face tiles (51.7 KB of LDS) do, 512-face tiles (53.1 KB) do not -- c5 4 110 (one-tile, 512) ->
+            # 4 450 (one-tile, 768) -> 4 770 (persistent, 480). 2D meshes keep 512 (their 35 KB tiles are what the DENSE
+            # budget needs; 768: -13 %), and so does fp32 (four to five workgroups per CU on 512-face tiles either way).
+            if self._many_geometries(part):
+                fcap = self.auto_fcap = 768
+            elif self._wide_rows(part):
+                fcap, retry_768 = 480, True
+                self.auto_fcap = 480
         fcap = int(os.environ.get("T8GPU_FCAP", 512)) if fcap is None else fcap
         # the per-face geometry rows are only read by the kernels without a dictionary (generic kernel, dictionary=False)
         self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary))
+        if retry_768:
+            h = self.host   # does the persistent kernel take this plan (kernels_fused_persistent.hip: its launcher's test)?
+            lds = 8 * (5 * 512 + 12 * h.geo_table.shape[0] + 10 * h.max_slots) + 2048
+            if not (compressed and dictionary and 0 < h.geo_table.shape[0] <= 128 and h.ell_width <= 24 and 3 * lds <= 156 * 1024):
+                fcap = self.auto_fcap = 768
+                self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary))
         self.dtype = dtype
         self._keep = {}
         c = T8gpuPlainPlan()

@@ -260,3 +260,48 @@ def test_stage_one_requires_prev_and_mid_to_be_the_same_planes():
     assert lib.t8gpu_hip_plain_fused_stage_f64(*args(0, 0)) == 0
     assert lib.t8gpu_hip_plain_fused_stage_f64(*args(3, 0)) == 1
     torch.cuda.synchronize()
+
+
+_PERSISTENT_CHILD = """
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from _gpu import perturbed_state
+from t8gpu_amd import hip
+from t8gpu_amd.solver import PlainSolver
+from t8gpu_amd.synth import SynthMesh
+out = []
+for dim, args in ((2, dict(base_level=4, max_level=7, band=0.05)), (2, dict(base_level=4, max_level=6, band=0.05, periodic=False)),
+                  (3, dict(base_level=3, max_level=5, band=0.05)), (3, dict(base_level=3, max_level=3)),
+                  (3, dict(base_level=2, max_level=4, band=0.08, periodic=False))):
+    mesh = SynthMesh(dim, **args)
+    part = mesh.partition()
+    for dtype in (torch.float32, torch.float64):
+        for kind in (hip.KEPES, hip.HLL):
+            g = PlainSolver(part, dtype, flux_kind=kind, mode="fused", state=perturbed_state(part, 5))
+            for _ in range(3):
+                g.iterate(0.1 * 2.0 ** -(mesh.finest_level + 2))
+            out.append(g.state().double().cpu().numpy().ravel())
+            out.append(g.speed.double().cpu().numpy().ravel())
+np.save(sys.argv[1], np.concatenate(out))
+"""
+
+
+def test_persistent_and_one_tile_kernels_agree_bitwise(tmp_path):
+    """T8GPU_PERSISTENT=2 sends every whole-plan launch through the persistent, software-pipelined kernel (2D meshes:
+    8-entry face lists; 3D AMR: 16- / 24-entry lists, second chunk prefetched, third on demand), =0 through the one-tile
+    kernels. Same arithmetic, same summation order: states and speed estimates must agree bit for bit."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    script = tmp_path / "child.py"
+    script.write_text(_PERSISTENT_CHILD.format(root=os.path.dirname(here), tests=here))
+    res = []
+    for mode in ("2", "0"):
+        out = tmp_path / f"state_{mode}.npy"
+        # (T8GPU_PERSISTENT_WGS also switches the launcher's size heuristic off: these meshes are small)
+        subprocess.run([sys.executable, str(script), str(out)], env=dict(os.environ, T8GPU_PERSISTENT=mode, T8GPU_PERSISTENT_WGS="3"),
+                       check=True, timeout=600)
+        res.append(np.load(out))
+    assert np.isfinite(res[0]).all()
+    assert np.array_equal(res[0], res[1]), int((res[0] != res[1]).sum())
