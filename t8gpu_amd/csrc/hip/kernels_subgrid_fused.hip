@@ -511,7 +511,11 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_subgrid_family(
   constexpr int FAM_WORDS = NW * 704 + 3 * 5 * 64 + 5 * 512;       // this kernel's arrays
   constexpr int BLK_WORDS = NW * 112 + 5 * 64;                      // one wavefront of the block algorithm
   constexpr int RESTB     = sizeof(T) == 8 ? 4 : 8;                 // leftover blocks per workgroup (fp64: LDS for 4 only)
+#ifdef T8GPU_EXP_FAM_PAD   // experiment builds: extra LDS words, to see how many workgroups per CU the kernel really gets
+  __shared__ T lds[(FAM_WORDS > RESTB * BLK_WORDS ? FAM_WORDS : RESTB * BLK_WORDS) + T8GPU_EXP_FAM_PAD];
+#else
   __shared__ T lds[FAM_WORDS > RESTB * BLK_WORDS ? FAM_WORDS : RESTB * BLK_WORDS];
+#endif
   const int tid = threadIdx.x, c = tid & 63;
   const int w   = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the per-block reads below stay scalar
   // The workgroups behind the cubes take the blocks outside every cube (the coarse side of 2:1 interfaces and their
