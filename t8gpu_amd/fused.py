@@ -45,11 +45,15 @@ class PlainPlan:
             # fits: 480-face tiles (51.7 KB of LDS) do, 512-face tiles (53.1 KB) do not -- c5 4 110 (one-tile, 512) ->
             # 4 450 (one-tile, 768) -> 4 770 (persistent, 480). 2D meshes keep 512 (their 35 KB tiles are what the DENSE
             # budget needs; 768: -13 %), and so does fp32 (four to five workgroups per CU on 512-face tiles either way).
+            # (A partitioned run launches tile classes, i.e. the one-tile kernel: 768 there too.)
             if self._many_geometries(part):
                 fcap = self.auto_fcap = 768
             elif self._wide_rows(part):
-                fcap, retry_768 = 480, True
-                self.auto_fcap = 480
+                if getattr(part, "nranks", 1) > 1:
+                    fcap = self.auto_fcap = 768
+                else:
+                    fcap, retry_768 = 480, True
+                    self.auto_fcap = 480
         fcap = int(os.environ.get("T8GPU_FCAP", 512)) if fcap is None else fcap
         # the per-face geometry rows are only read by the kernels without a dictionary (generic kernel, dictionary=False)
         self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary))
