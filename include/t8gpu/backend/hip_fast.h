@@ -140,10 +140,11 @@ namespace t8gpu::hip {
     /// them) and the communicator; iterate_fused then exchanges the ghost layer per stage (csrc/hip/stepper.hip).
     explicit PlainFusedPlan(HostMeshArrays const& m, int ndim = 3, int tmax = 256, int fcap = 512, HostHaloArrays const* halo = nullptr,
                             Communicator const* comm = nullptr) {
-      void* h = t8gpu_plan_plain_create(m.num_local_elements, m.num_ghost_elements, m.num_local_faces,
-                                        m.num_local_boundary_faces, ndim, m.face_neighbors.data(), m.face_normals.data(),
-                                        m.face_surfaces.data(), tmax, fcap);
-      if (!h) T8GPU_ABORT("t8gpu_plan_plain_create failed");
+      // (flag 1: structured 16 x 16 patches are cut out of the tiling and run through the patch kernel)
+      void* h = t8gpu_plan_plain_create_ex(m.num_local_elements, m.num_ghost_elements, m.num_local_faces,
+                                           m.num_local_boundary_faces, ndim, m.face_neighbors.data(), m.face_normals.data(),
+                                           m.face_surfaces.data(), tmax, fcap, 1);
+      if (!h) T8GPU_ABORT("t8gpu_plan_plain_create_ex failed");
       int64_t sz[16];
       t8gpu_plan_plain_sizes(h, sz);
       const size_t nt = sz[0], nhalo = sz[1], nfaces = sz[2], ncsr = sz[3], N = sz[8], w = sz[10], ngeo = sz[11];
@@ -157,6 +158,8 @@ namespace t8gpu::hip {
       t8gpu_plan_plain_compressed(h, ell.data(), ngeo ? geo_idx.data() : nullptr, ngeo ? table.data() : nullptr);
       std::vector<int32_t> tile_desc(8 * std::max<size_t>(nt, 1));
       t8gpu_plan_plain_tile_desc(h, tile_desc.data());
+      int32_t patch_counts[4];
+      t8gpu_plan_plain_patch_counts(h, patch_counts);
       t8gpu_plan_plain_destroy(h);
       m_plan.elem_off   = up(elem_off);
       m_plan.halo_off   = up(halo_off);
@@ -177,6 +180,8 @@ namespace t8gpu::hip {
       m_plan.max_faces = static_cast<int32_t>(sz[6]); m_plan.ell_width = static_cast<int32_t>(w);
       m_plan.n_geo = static_cast<int32_t>(ngeo); m_plan.max_slots = static_cast<int32_t>(sz[12]);
       m_plan.n_deep_tiles = static_cast<int32_t>(sz[13]); m_plan.reserved = 0;
+      for (int c = 0; c < 3; c++) m_plan.n_patch_tiles[c] = patch_counts[c];
+      m_plan.reserved2 = 0;
       T8gpuHalo  hl{};
       const bool multi = halo && comm && !halo->peers.empty();
       if (multi) {

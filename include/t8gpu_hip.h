@@ -154,6 +154,14 @@ typedef struct T8gpuPlainPlan {
   const int32_t* tile_desc;   /* [ntiles][8], in tile_order order: {first element, elements, first halo entry, halo entries,
                                * first face, faces, 0, 0} of tile_order[k] -- one 32-byte record per tile for the persistent
                                * kernel, which reads it several tiles ahead (NULL: that kernel is not used) */
+  /* STRUCTURED PATCHES (ABI 4; t8gpu_plan_plain_create_ex flag 1, csrc/host/tile_plan.cpp: find_patches): tiles of 256
+   * consecutive elements that form an aligned 16 x 16 block of same-size quadrilaterals with the canonical face listing.
+   * They have no face records; their tile_desc is {first element, 256, first halo entry, 64, id of the first own face,
+   * 0x100 | flags, area as a double}, their 64 halo entries the elements across the -x | +x | -y | +y sides. The first
+   * n_patch_tiles[c] tiles of class c of tile_order (c = 0: [0, n_deep_tiles), 1: [n_deep_tiles, n_interior_tiles),
+   * 2: the rest) are patch tiles; they run through kernels_fused_patch.hip. All zero: no patches. */
+  int32_t n_patch_tiles[3];
+  int32_t reserved2;
 } T8gpuPlainPlan;
 
 /* tile_begin/tile_count select a range of tile_order (0, ntiles = everything; [0, n_interior) can run

@@ -55,8 +55,17 @@ int   t8gpu_synth_mesh_adapt_data(const void* old_mesh, const void* new_mesh, in
 /* ---- tile plan of the fused plain-element kernels --------------------------------------------- */
 void* t8gpu_plan_plain_create(int32_t N, int32_t G, int32_t F, int32_t B, int32_t ndim, const int32_t* face_neighbors,
                               const double* normals, const double* areas, int32_t tmax, int32_t fcap);
+/* flags bit 0: cut STRUCTURED PATCHES out of the tiling -- 16 x 16 same-size quadrilaterals that are 256 consecutive
+ * elements in Morton order with the canonical face listing (csrc/host/tile_plan.cpp: find_patches). A patch is a tile
+ * without face records: tile_desc holds {first element, 256, first halo entry, 64, id of its first own face,
+ * 0x100 | flags, area (double)}, halo_ids the 64 elements across its sides ([-x | +x | -y | +y] x 16). Inside every
+ * class of tile_order the patch tiles come first (t8gpu_plan_plain_patch_counts). */
+void* t8gpu_plan_plain_create_ex(int32_t N, int32_t G, int32_t F, int32_t B, int32_t ndim, const int32_t* face_neighbors,
+                                 const double* normals, const double* areas, int32_t tmax, int32_t fcap, int32_t flags);
 void  t8gpu_plan_plain_destroy(void* plan);
-/* sizes[16] (12 = max over tiles of own + halo elements, 13 = number of deep-interior tiles, 14-15 reserved = 0) = {ntiles, n_halo, n_faces, n_csr, max_elems, max_halo, max_faces, n_interior_tiles, N, F,
+/* counts[4] = leading patch tiles of the deep / near-boundary / ghost-reading class of tile_order, total */
+void  t8gpu_plan_plain_patch_counts(const void* plan, int32_t* counts);
+/* sizes[16] (12 = max over the generic tiles of own + halo elements, 13 = number of deep-interior tiles, 14 = number of patch tiles, 15 reserved = 0; the maxima 4-6 are over the generic tiles) = {ntiles, n_halo, n_faces, n_csr, max_elems, max_halo, max_faces, n_interior_tiles, N, F,
  *              ell_width, n_geo} */
 void t8gpu_plan_plain_sizes(const void* plan, int64_t* sizes);
 void t8gpu_plan_plain_arrays(const void* plan, int32_t* elem_off, int32_t* halo_off, int32_t* face_off,

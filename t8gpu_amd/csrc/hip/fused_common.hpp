@@ -38,11 +38,83 @@ FVars<T> fmk(const V& v) {
   return o;
 }
 
+// ---- LDS records of the persistent kernels (kernels_fused_persistent.hip, kernels_fused_patch.hip) ---------------
+template <class T>
+struct vec16;
+template <>
+struct vec16<double> {
+  using type = double2;
+  static constexpr int lanes = 2;
+};
+template <>
+struct vec16<float> {
+  using type = float4;
+  static constexpr int lanes = 4;
+};
+
+// words per LDS record: NW payload words padded so that (a) 16-byte pieces stay aligned and (b) consecutive slots
+// start in different bank groups (record size / 16 B is odd: 5 or 3)
+template <class T, int NW>
+constexpr int rec_words() {
+  return sizeof(T) == 8 ? (NW > 5 ? 10 : 6) : 12;
+}
+
+template <class T, int NW>
+T8_DEV void rec_store(T* rec, const T* w) {
+  using V         = typename vec16<T>::type;
+  constexpr int L = vec16<T>::lanes;
+#pragma unroll
+  for (int c = 0; c + L <= NW; c += L) {
+    V v;
+    T* vv = reinterpret_cast<T*>(&v);
+#pragma unroll
+    for (int j = 0; j < L; j++) vv[j] = w[c + j];
+    *reinterpret_cast<V*>(rec + c) = v;
+  }
+#pragma unroll
+  for (int c = NW / L * L; c < NW; c++) rec[c] = w[c];
+}
+
+template <class T, int NW>
+T8_DEV void rec_load(const T* rec, T* w) {
+  using V         = typename vec16<T>::type;
+  constexpr int L = vec16<T>::lanes;
+#pragma unroll
+  for (int c = 0; c + L <= NW; c += L) {
+    const V  v  = *reinterpret_cast<const V*>(rec + c);
+    const T* vv = reinterpret_cast<const T*>(&v);
+#pragma unroll
+    for (int j = 0; j < L; j++) w[c + j] = vv[j];
+  }
+#pragma unroll
+  for (int c = NW / L * L; c < NW; c++) w[c] = rec[c];
+}
+
+template <class T>
+T8_DEV void prim_words(const T s[5], T w[kPrimWords], const double* logtab) {
+#ifdef T8GPU_EXP_NOMATH    // experiment builds only: same loads, LDS traffic, barriers and stores, (almost) no arithmetic
+  Prim<T> q;
+  q.rho = s[0]; q.vx = s[1]; q.vy = s[2]; q.vz = s[3]; q.p = s[4]; q.beta = s[0]; q.lrho = s[1]; q.lbeta = s[2]; q.v0 = s[3];
+#else
+  const Prim<T> q = prim_from_state<T, sizeof(T) == 8>(s, logtab);   // fp64: table-driven logarithms (flux_math.hpp)
+#endif
+  w[0] = q.rho; w[1] = q.vx; w[2] = q.vy; w[3] = q.vz; w[4] = q.p; w[5] = q.beta; w[6] = q.lrho; w[7] = q.lbeta; w[8] = q.v0;
+}
+template <class T>
+T8_DEV void words_prim(const T w[kPrimWords], Prim<T>& q) {
+  q.rho = w[0]; q.vx = w[1]; q.vy = w[2]; q.vz = w[3]; q.p = w[4]; q.beta = w[5]; q.lrho = w[6]; q.lbeta = w[7]; q.v0 = w[8];
+}
+
 // persistent, software-pipelined tile kernel (kernels_fused_persistent.hip). Returns -1 when the plan is outside what
 // that kernel takes (the caller then uses the one-tile-per-workgroup kernels), otherwise 0 or a hipError_t.
 template <class T>
 int plain_persistent_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count, FVars<T> prev,
                            FVars<T> mid, FVars<T> out, const T* volume, T dt, T* speed, hipStream_t stream);
+
+// structured-patch kernel (kernels_fused_patch.hip): [tile_begin, tile_begin + tile_count) of tile_order are patch tiles
+template <class T>
+int plain_patch_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count, FVars<T> prev, FVars<T> mid,
+                      FVars<T> out, const T* volume, T dt, T* speed, bool persistent, hipStream_t stream);
 
 }  // namespace t8gpu_hip
 

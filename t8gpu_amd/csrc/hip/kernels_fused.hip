@@ -435,18 +435,11 @@ __global__ __launch_bounds__(256, DENSE ? (sizeof(T) == 8 ? 4 : 5) : 1) void k_p
   }
 }
 
+// tiles [tile_begin, tile_begin + tile_count) of tile_order, none of them a patch tile. whole_plan: the caller's launch
+// covers the whole plan (what the persistent kernel is for).
 template <class T, class V>
-int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count, V prev, V mid,
-                      V out, const T* volume, T dt, T* speed, void* stream) {
-  if (!plan || kind < 0 || kind > 2 || stage < 1 || stage > 3) return static_cast<int>(hipErrorInvalidValue);
-  if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > plan->ntiles) return static_cast<int>(hipErrorInvalidValue);
-  if (plan->max_elems > 256 * 4) return static_cast<int>(hipErrorInvalidValue);
-  // stage 1 is u1 = u0 + dt/vol f(u0) (ssp_runge_kutta.inl:30-50: `prev` is both the flux source and the summand):
-  // the pipelined kernel keeps the source state in registers and never reads `prev` at stage 1, the generic kernel
-  // does -- so a caller passing prev != mid at stage 1 would get variant-dependent results. Refused instead.
-  if (stage == 1)
-    for (int k = 0; k < 5; k++)
-      if (prev.p[k] != mid.p[k]) return static_cast<int>(hipErrorInvalidValue);
+int plain_generic_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count, V prev, V mid,
+                        V out, const T* volume, T dt, T* speed, bool whole_plan, void* stream) {
   if (tile_count == 0) return 0;
   const int   nw = kind == 0 ? kPrimWords : 5;
   hipStream_t s  = static_cast<hipStream_t>(stream);
@@ -462,7 +455,7 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
   // done and keep those small kernels -- the exchange the split exists to overlap -- from starting, so partial
   // ranges use the one-tile-per-workgroup kernels, whose slots free up continuously. Both give the same bits.
   static const bool persistent_always = std::getenv("T8GPU_PERSISTENT") && std::getenv("T8GPU_PERSISTENT")[0] == '2';
-  if (!scatter && (persistent_always || (tile_begin == 0 && tile_count == plan->ntiles))) {
+  if (!scatter && (persistent_always || whole_plan)) {
     const int rc = plain_persistent_stage<T>(kind, stage, plan, tile_begin, tile_count, fmk<T>(prev), fmk<T>(mid), fmk<T>(out), volume,
                                              dt, speed, s);
     if (rc >= 0) return rc;
@@ -517,6 +510,63 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
 #undef T8_FUSED
 #undef T8_LAUNCH
   return static_cast<int>(hipGetLastError());
+}
+
+// The C-ABI entry: splits the range of tile_order into its patch tiles (kernels_fused_patch.hip) and its generic tiles
+// (the kernels above / the persistent kernel). Inside every class the patch tiles come first (T8gpuPlainPlan).
+template <class T, class V>
+int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count, V prev, V mid,
+                      V out, const T* volume, T dt, T* speed, void* stream) {
+  if (!plan || kind < 0 || kind > 2 || stage < 1 || stage > 3) return static_cast<int>(hipErrorInvalidValue);
+  if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > plan->ntiles) return static_cast<int>(hipErrorInvalidValue);
+  if (plan->max_elems > 256 * 4) return static_cast<int>(hipErrorInvalidValue);
+  // stage 1 is u1 = u0 + dt/vol f(u0) (ssp_runge_kutta.inl:30-50: `prev` is both the flux source and the summand):
+  // the pipelined kernel keeps the source state in registers and never reads `prev` at stage 1, the generic kernel
+  // does -- so a caller passing prev != mid at stage 1 would get variant-dependent results. Refused instead.
+  if (stage == 1)
+    for (int k = 0; k < 5; k++)
+      if (prev.p[k] != mid.p[k]) return static_cast<int>(hipErrorInvalidValue);
+  if (tile_count == 0) return 0;
+  const bool whole = tile_begin == 0 && tile_count == plan->ntiles;
+  const int  np_total = plan->n_patch_tiles[0] + plan->n_patch_tiles[1] + plan->n_patch_tiles[2];
+  if (np_total == 0) return plain_generic_stage<T, V>(kind, stage, plan, tile_begin, tile_count, prev, mid, out, volume, dt, speed, whole, stream);
+  if (!plan->tile_desc) return static_cast<int>(hipErrorInvalidValue);
+  const int nd = plan->n_deep_tiles > 0 && plan->n_deep_tiles <= plan->n_interior_tiles ? plan->n_deep_tiles : 0;
+  // class segments of tile_order: [0, nd) deep, [nd, n_interior) near the boundary, [n_interior, ntiles) ghost-reading.
+  // (a plan whose n_deep_tiles is 0 = "unknown" has classes 0 and 1 merged: the planner then reports no class-1 patches)
+  const int seg[4] = {0, nd, plan->n_interior_tiles, plan->ntiles};
+  const int b = tile_begin, e = tile_begin + tile_count;
+  static const bool persistent_always = std::getenv("T8GPU_PERSISTENT") && std::getenv("T8GPU_PERSISTENT")[0] == '2';
+  // generic sub-ranges that touch are launched together (single rank: one patch launch + one generic launch)
+  int gb = -1, ge = -1;
+  auto flush = [&]() -> int {
+    if (gb < 0 || ge <= gb) return 0;
+    const int rc = plain_generic_stage<T, V>(kind, stage, plan, gb, ge - gb, prev, mid, out, volume, dt, speed, whole, stream);
+    gb = ge = -1;
+    return rc;
+  };
+  for (int c = 0; c < 3; c++) {
+    const int s0 = seg[c], s1 = seg[c + 1], p1 = s0 + plan->n_patch_tiles[c];
+    if (p1 > s1) return static_cast<int>(hipErrorInvalidValue);
+    const int pb = b > s0 ? b : s0, pe = e < p1 ? e : p1;   // patch tiles of this class inside the range
+    if (pe > pb) {
+      if (int rc = flush()) return rc;
+      const int rc = plain_patch_stage<T>(kind, stage, plan, pb, pe - pb, fmk<T>(prev), fmk<T>(mid), fmk<T>(out), volume, dt, speed,
+                                          whole || persistent_always, static_cast<hipStream_t>(stream));
+      if (rc != 0) return rc;
+    }
+    const int qb = b > p1 ? b : p1, qe = e < s1 ? e : s1;   // its generic tiles
+    if (qe > qb) {
+      if (gb >= 0 && ge == qb) {
+        ge = qe;
+      } else {
+        if (int rc = flush()) return rc;
+        gb = qb;
+        ge = qe;
+      }
+    }
+  }
+  return flush();
 }
 
 }  // namespace t8gpu_hip

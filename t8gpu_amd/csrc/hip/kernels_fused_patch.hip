@@ -1,0 +1,327 @@
+// kernels_fused_patch.hip -- fused RK stage over STRUCTURED PATCHES of a plain-element mesh (round 3).
+//
+// Reference: examples/compressible_euler/kernels.cu:135-309 (kepes_compute_fluxes) + ssp_runge_kutta.inl:30-99, the same
+// stage the tile kernels fuse (kernels_fused.hip, kernels_fused_persistent.hip).
+//
+// Adaptive quadrilateral meshes are locally structured: on the benchmark mesh (c4) 97 % of the elements lie in aligned
+// 16 x 16 blocks of same-size squares, which are 256 CONSECUTIVE elements in Morton order. The host plan finds such
+// patches from the reference-format arrays alone (csrc/host/tile_plan.cpp: find_patches) and hands them over as tiles
+// WITHOUT face records. For those tiles everything the generic tile kernels fetch per face -- packed (l, r) indices,
+// geometry index, original face id, the per-element face list -- follows from the lane index:
+//
+//   lane t = element e0 + t = cell (i, j) of the patch (t = Morton interleave of i and j, x in bit 0)
+//   phase 1   primitives of the own cell -> registers and an LDS record; wave 3 also takes the 64 cells across the
+//             patch's four sides (the plan lists them per patch: [-x | +x | -y | +y] x 16)
+//   phase 2   the lane's OWN faces: +x against cell (i + 1, j), +y against (i, j + 1) (normals exactly +e_x, +e_y: no
+//             rotation, no dictionary; left operand in registers); lanes 0-31 of wave 0 evaluate the 32 faces of the
+//             -x / -y sides, which belong to the cells across (same orientation, same values as in their own tile)
+//   phase 3   a cell adds its four fluxes in ascending original face id, which for a patch is: the -x and -y faces in
+//             the order of the owning neighbours' indices (a function of (i, j), checked by the planner), then +x, +y;
+//             RK stage
+//
+// Per 256 elements that is 5 + 9 wave-rounds of primitives / fluxes (the tile kernels: 8 + 8 for 234) and a quarter of
+// the index traffic; speed estimates go to fbase + 2 t (+1) without an id list. Same flux functions, same operand order,
+// same summation order as the tile kernels: results are bitwise theirs (tests/test_gpu_patch.py), and a face that a patch
+// and a generic tile both evaluate gets the same value in both.
+//
+// Persistent and software-pipelined like k_plain_persistent: a workgroup walks patches j, j + n, ... of its XCD's
+// contiguous share with the next patch's loads in flight; two barriers per patch.
+#include <cstdlib>
+
+#include "fused_common.hpp"
+
+namespace t8gpu_hip {
+
+constexpr int kPatchFF = 544;   // flux slots per variable: 256 +x faces, 256 +y faces, 16 -x side, 16 -y side
+
+T8_DEV int patch_morton(int i, int j) {
+  int t = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) t |= (((i >> b) & 1) << (2 * b)) | (((j >> b) & 1) << (2 * b + 1));
+  return t;
+}
+T8_DEV int patch_ctz4(int v) { return v == 0 ? 4 : __builtin_ctz(static_cast<unsigned>(v)); }
+
+// velocity components in the frame of a face with normal +e_AXIS (the frame face_basis() gives that normal, see
+// kepes_axis_fixed in flux_math.hpp), and a frame flux back to xyz. YSEL: per lane (mixed wavefront of the - sides).
+template <class T>
+T8_DEV void frame_in(bool y, T vx, T vy, T vz, T& u, T& v, T& w) {
+  u = y ? vy : vx;
+  v = y ? vx : -vz;
+  w = y ? -vz : vy;
+}
+template <class T>
+T8_DEV void frame_out(bool y, const T f[5], T g[5]) {
+  g[0] = f[0];
+  g[1] = y ? f[2] : f[1];
+  g[2] = y ? f[1] : f[3];
+  g[3] = y ? -f[3] : -f[2];
+  g[4] = f[4];
+}
+
+// one face with normal +e_x (AXIS 0) or +e_y (AXIS 1); KEPES from primitives, HLL / HLLC from the conserved states
+template <class T, int KIND, int NW>
+T8_DEV void patch_face(bool y, const T* wl, const T* wr, T area, T g[5], T& spd) {
+  T f[5];
+  if (KIND == 0) {
+    Prim<T> L, R;
+    words_prim<T>(wl, L);
+    words_prim<T>(wr, R);
+    T uL, vL, wL, uR, vR, wR;
+    frame_in<T>(y, L.vx, L.vy, L.vz, uL, vL, wL);
+    frame_in<T>(y, R.vx, R.vy, R.vz, uR, vR, wR);
+#ifdef T8GPU_EXP_NOMATH
+    f[0] = L.rho + R.rho + uL; f[1] = vL + wL + uR; f[2] = vR + wR + L.beta + R.beta; f[3] = L.lrho + R.lrho;
+    f[4] = L.p + R.p + L.lbeta + R.lbeta + L.v0 + R.v0 + area;
+    spd = f[0];
+#else
+    kepes_core<T>(L, R, uL, vL, wL, uR, vR, wR, area, f, spd);
+#endif
+  } else {
+    T a[5], b[5];
+    a[0] = wl[0]; a[4] = wl[4];
+    b[0] = wr[0]; b[4] = wr[4];
+    frame_in<T>(y, wl[1], wl[2], wl[3], a[1], a[2], a[3]);
+    frame_in<T>(y, wr[1], wr[2], wr[3], b[1], b[2], b[3]);
+    if (KIND == 2)
+      hllc_fast<T>(a, b, f, spd);
+    else
+      hll_fast<T>(a, b, f, spd);
+#pragma unroll
+    for (int k = 0; k < 5; k++) f[k] = area * f[k];
+  }
+  frame_out<T>(y, f, g);
+}
+
+// (second launch bound = waves per SIMD the register allocation must allow: 3 workgroups per CU in fp64, 5 in fp32)
+template <class T, int KIND, int STAGE>
+__global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_patch(T8gpuPlainPlan P, int tile_begin, int tile_count, FVars<T> prev,
+                                                                                FVars<T> src, FVars<T> out, const T* __restrict__ vol, T dt,
+                                                                                T* __restrict__ speed) {
+  constexpr int NW  = KIND == 0 ? kPrimWords : 5;
+  constexpr int REC = rec_words<T, NW>();
+  extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+  T* const  ff = reinterpret_cast<T*>(lds_raw);               // [5][kPatchFF] the patch's face fluxes
+  T* const  pe = ff + 5 * kPatchFF;                           // [320][REC] primitives (or states): 256 own, 64 across the sides
+  constexpr bool kTab = sizeof(T) == 8 && KIND == 0;          // fp64 KEPES: the logarithm table, behind the records
+  double* const lt = reinterpret_cast<double*>(pe + REC * 320);
+  const int tid = threadIdx.x;
+
+  // this workgroup's patches (same walk as k_plain_persistent: XCD x takes one contiguous eighth of the range, its
+  // workgroups walk it together)
+  const int G = gridDim.x, xcd = blockIdx.x & 7, jw = blockIdx.x >> 3;
+  const int nxcd = G < 8 ? G : 8, nx = (G - xcd + 7) >> 3;
+  const int per = tile_count / nxcd, rem = tile_count % nxcd;
+  const int x0   = tile_begin + xcd * per + (xcd < rem ? xcd : rem);
+  const int tend = x0 + per + (xcd < rem ? 1 : 0);
+  int       t    = x0 + jw;
+  if (xcd >= nxcd || t >= tend) return;
+  if (kTab) {
+    lt[tid] = kLogTab[tid];
+    __syncthreads();
+  }
+
+  // ---- lane constants -------------------------------------------------------------------------------------------------
+  int ci = 0, cj = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    ci |= ((tid >> (2 * b)) & 1) << b;
+    cj |= ((tid >> (2 * b + 1)) & 1) << b;
+  }
+  // records of the right operands of the lane's faces; flux slots of its - faces (the + faces of the cells across)
+  const int  rx   = ci < 15 ? patch_morton(ci + 1, cj) : 272 + cj;
+  const int  ry   = cj < 15 ? patch_morton(ci, cj + 1) : 304 + ci;
+  const int  a_mx = ci > 0 ? patch_morton(ci - 1, cj) : 512 + cj;
+  const int  a_my = cj > 0 ? 256 + patch_morton(ci, cj - 1) : 528 + ci;
+  const bool yfirst_lane = patch_ctz4(cj) >= patch_ctz4(ci);   // (cell (0, 0): per patch, from the descriptor)
+  const bool halo_wave = tid >= 192;                           // wave 3: the 64 cells across the sides
+  const int  hl        = tid - 192;
+  const bool minus_lane = tid < 32;                            // wave 0, lanes 0-31: the faces of the -x / -y sides
+  const bool minus_y    = tid >= 16;
+  const int  m_l = 256 + (minus_y ? 32 : 0) + (tid & 15);      // left operand: the cell across; right: the patch's cell
+  const int  m_r = minus_y ? patch_morton(tid & 15, 0) : patch_morton(0, tid & 15);
+
+  typedef int int8v __attribute__((ext_vector_type(8)));
+  struct Desc {
+    int    e0, h0, fbase, flags;
+    double area;
+  };
+  auto load_desc = [&](int tt) {   // scalar load through the constant address space (see k_plain_persistent)
+    const size_t k = static_cast<size_t>(tt < tend ? tt : tend - 1);
+    const int8v  r = *reinterpret_cast<const __attribute__((address_space(4))) int8v*>(
+        reinterpret_cast<const __attribute__((address_space(4))) char*>(reinterpret_cast<uintptr_t>(P.tile_desc)) + 32 * k);
+    Desc d;
+    d.e0 = r[0]; d.h0 = r[2]; d.fbase = r[4]; d.flags = r[5];
+    d.area = __hiloint2double(r[7], r[6]);
+    return d;
+  };
+  struct Pre {
+    T s0[5], sh[5];
+  };
+  auto prefetch = [&](const Desc& d, int hslot) {
+    Pre p;
+#pragma unroll
+    for (int k = 0; k < 5; k++) p.s0[k] = src.p[k][d.e0 + tid];
+    if (halo_wave) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) p.sh[k] = src.p[k][hslot];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 5; k++) p.sh[k] = T(0);
+    }
+    return p;
+  };
+
+  const int stride = nx;
+  Desc      d0 = load_desc(t), d1 = load_desc(t + stride);
+  int       hs_a = halo_wave ? P.halo_ids[d0.h0 + hl] : 0, hs_b = halo_wave ? P.halo_ids[d1.h0 + hl] : 0;
+  Pre       cur = prefetch(d0, hs_a);
+  T         res[5] = {T(0), T(0), T(0), T(0), T(0)};
+  int       res_e  = -1;
+  __builtin_amdgcn_s_waitcnt(0);   // (see k_plain_persistent: the prologue's loads must not become a wait inside the loop)
+
+  for (; t < tend; t += stride) {
+    const Desc d2   = load_desc(t + 2 * stride);
+    const int  hs_c = halo_wave ? P.halo_ids[d2.h0 + hl] : 0;
+    Pre        nxt;
+    if (t + stride < tend) nxt = prefetch(d1, hs_b);
+    const int e = d0.e0 + tid;
+    T         pv[5] = {T(0), T(0), T(0), T(0), T(0)};
+    if (STAGE > 1) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) pv[k] = prev.p[k][e];
+    }
+    const T volume = vol[e];
+    const T area   = static_cast<T>(d0.area);
+
+    // ---- phase 1: records of the own cell and (wave 3) of the cells across the sides ----------------------------------
+    T mine[NW];
+    if (KIND == 0) {
+      prim_words<T>(cur.s0, mine, lt);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 5; k++) mine[k] = cur.s0[k];
+    }
+    rec_store<T, NW>(pe + tid * REC, mine);
+    if (halo_wave) {
+      T w[NW];
+      if (KIND == 0) {
+        prim_words<T>(cur.sh, w, lt);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 5; k++) w[k] = cur.sh[k];
+      }
+      rec_store<T, NW>(pe + (256 + hl) * REC, w);
+    }
+    if (res_e >= 0) {   // results of the previous patch: behind this iteration's first wait (vmcnt retires in order)
+#pragma unroll
+      for (int k = 0; k < 5; k++) out.p[k][res_e] = res[k];
+    }
+    __syncthreads();
+
+    // ---- phase 2: the lane's +x and +y faces; the - sides ------------------------------------------------------------
+    T gy[5];
+    {
+      T wr[NW], g[5], sx, sy;
+      rec_load<T, NW>(pe + rx * REC, wr);
+      patch_face<T, KIND, NW>(false, mine, wr, area, g, sx);
+#pragma unroll
+      for (int k = 0; k < 5; k++) ff[k * kPatchFF + tid] = g[k];
+      rec_load<T, NW>(pe + ry * REC, wr);
+      patch_face<T, KIND, NW>(true, mine, wr, area, gy, sy);
+#pragma unroll
+      for (int k = 0; k < 5; k++) ff[k * kPatchFF + 256 + tid] = gy[k];
+      if (speed) {   // the patch's own faces: ids fbase + 2 t (+x) and fbase + 2 t + 1 (+y)
+        speed[d0.fbase + 2 * tid]     = sx;
+        speed[d0.fbase + 2 * tid + 1] = sy;
+      }
+    }
+    if (minus_lane) {
+      T wl[NW], wr[NW], g[5], sm;
+      rec_load<T, NW>(pe + m_l * REC, wl);
+      rec_load<T, NW>(pe + m_r * REC, wr);
+      patch_face<T, KIND, NW>(minus_y, wl, wr, area, g, sm);
+#pragma unroll
+      for (int k = 0; k < 5; k++) ff[k * kPatchFF + 512 + tid] = g[k];
+    }
+    __syncthreads();
+
+    // ---- phase 3: the four fluxes in ascending face id, RK stage -------------------------------------------------------
+    const bool yfirst = tid == 0 ? (d0.flags & 1) != 0 : yfirst_lane;
+    const int  a1 = yfirst ? a_my : a_mx, a2 = yfirst ? a_mx : a_my;
+    T          acc[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      acc[k] = __builtin_fma(T(1), ff[k * kPatchFF + a1], T(0));
+      acc[k] = __builtin_fma(T(1), ff[k * kPatchFF + a2], acc[k]);
+      acc[k] = __builtin_fma(T(-1), ff[k * kPatchFF + tid], acc[k]);
+      acc[k] = __builtin_fma(T(-1), gy[k], acc[k]);
+    }
+    const T scale = dt / volume;
+#pragma unroll
+    for (int k = 0; k < 5; k++) res[k] = rk_stage_update<T, STAGE>(pv[k], cur.s0[k], scale, acc[k]);
+    res_e = e;
+
+    cur  = nxt;
+    d0   = d1;
+    d1   = d2;
+    hs_b = hs_c;
+  }
+  if (res_e >= 0) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) out.p[k][res_e] = res[k];
+  }
+}
+
+// tiles [tile_begin, tile_begin + tile_count) of tile_order must all be patch tiles. persistent = false: one patch per
+// workgroup (class-split multi-rank launches: slots free up continuously, see plain_fused_stage).
+template <class T>
+int plain_patch_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count, FVars<T> prev, FVars<T> mid,
+                      FVars<T> out, const T* volume, T dt, T* speed, bool persistent, hipStream_t stream) {
+  if (tile_count <= 0) return 0;
+  if (!plan->tile_desc) return static_cast<int>(hipErrorInvalidValue);
+  const int    nw  = kind == 0 ? kPrimWords : 5;
+  const int    rec = sizeof(T) == 8 ? (nw > 5 ? 10 : 6) : 12;
+  const size_t lds = sizeof(T) * (static_cast<size_t>(5) * kPatchFF + static_cast<size_t>(rec) * 320) +
+                     ((sizeof(T) == 8 && kind == 0) ? 2 * kLogTabEntries * sizeof(double) : 0);
+  static int per_cu_env = -1, cus = 0;
+  if (cus == 0) {
+    int             dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return static_cast<int>(hipErrorInvalidDevice);
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const char* env = std::getenv("T8GPU_PATCH_WGS");
+    per_cu_env      = env ? std::atoi(env) : 0;
+    if (per_cu_env < 0 || per_cu_env > 8) per_cu_env = 0;
+  }
+  const int  per_cu   = per_cu_env > 0 ? per_cu_env : (sizeof(T) == 8 ? 3 : 5);
+  const int  resident = cus * per_cu;
+  const int  grid_size = (!persistent || tile_count < resident) ? tile_count : resident;
+  const dim3 grid(grid_size), block(256);
+#define T8_PA(K, S) hipLaunchKernelGGL((k_plain_patch<T, K, S>), grid, block, lds, stream, *plan, tile_begin, tile_count, prev, mid, out, volume, dt, speed)
+#define T8_PAS(K)          \
+  do {                     \
+    if (stage == 1)        \
+      T8_PA(K, 1);         \
+    else if (stage == 2)   \
+      T8_PA(K, 2);         \
+    else                   \
+      T8_PA(K, 3);         \
+  } while (0)
+  if (kind == 0)
+    T8_PAS(0);
+  else if (kind == 1)
+    T8_PAS(1);
+  else
+    T8_PAS(2);
+#undef T8_PAS
+#undef T8_PA
+  return static_cast<int>(hipGetLastError());
+}
+
+template int plain_patch_stage<float>(int, int, const T8gpuPlainPlan*, int, int, FVars<float>, FVars<float>, FVars<float>, const float*,
+                                      float, float*, bool, hipStream_t);
+template int plain_patch_stage<double>(int, int, const T8gpuPlainPlan*, int, int, FVars<double>, FVars<double>, FVars<double>,
+                                       const double*, double, double*, bool, hipStream_t);
+
+}  // namespace t8gpu_hip

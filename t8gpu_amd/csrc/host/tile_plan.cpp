@@ -24,6 +24,31 @@
 
 namespace {
 
+// A structured patch: kPatchSide x kPatchSide same-size quadrilaterals that are kPatchElems CONSECUTIVE elements in
+// Morton order (x = bit 0 of the local index), every one with exactly four interior faces in the canonical listing:
+// its +x and +y faces are its own (left = the element, normal exactly +e_x / +e_y, ids fbase + 2 t and fbase + 2 t + 1
+// for local index t), its -x and -y faces are the +x / +y faces of the elements across (right = the element), all with
+// one area. The kernel needs no face records for such a tile: neighbours inside the patch follow from the lane index,
+// the 64 elements across its four sides are listed in `halo` ([-x side by j | +x side by j | -y side by i | +y side by
+// i]), and an element adds its four fluxes in ascending face id: (-x, -y in the order of the owning neighbours' indices,
+// which inside the patch is a function of (i, j) alone -- patch_y_first), then +x, +y.
+constexpr int kPatchSide = 16, kPatchElems = 256, kPatchHalo = 64;
+struct Patch {
+  int32_t e0 = 0, fbase = 0, flags = 0;   // flags bit 0: element 0 adds its -y face before its -x face
+  double  area = 0;
+  int32_t halo[kPatchHalo];
+};
+
+inline int morton2(int i, int j) {
+  int t = 0;
+  for (int b = 0; b < 4; b++) t |= ((i >> b) & 1) << (2 * b) | ((j >> b) & 1) << (2 * b + 1);
+  return t;
+}
+inline int ctz4(int v) { return v == 0 ? 4 : __builtin_ctz(static_cast<unsigned>(v)); }
+// does element (i, j) of a patch add its -y face before its -x face? (the face of the neighbour with the lower index
+// first: Morton order of (i, j-1) against (i-1, j)). Element (0, 0) has both neighbours outside: decided per patch.
+inline bool patch_y_first(int i, int j) { return ctz4(j) >= ctz4(i); }
+
 struct TilePlan {
   int32_t N = 0, G = 0, F = 0, B = 0, ndim = 3, tmax = 256, fcap = 512;
   int32_t max_halo = 0, max_faces = 0, max_elems = 0, n_interior = 0, max_slots = 0, n_deep = 0;
@@ -42,6 +67,11 @@ struct TilePlan {
   std::vector<uint16_t> geo_idx;                       // per tile face: row of geo_table (13 bits) | direction code << 13
                                                        // (empty if more than 8191 distinct rows)
   std::vector<double>   geo_table;                     // [n_geo][12]: n, area, t1, 0, t2, 0
+  // structured patches (see find_patches): tiles the patch kernel evaluates without face records
+  int32_t want_patches = 0;
+  std::vector<Patch>   patches;                        // in element order
+  std::vector<int32_t> tile_patch;                     // [ntiles] index into patches, or -1 (generic tile)
+  int32_t n_patch_class[3] = {0, 0, 0};                // leading patch tiles of the deep / near / ghost-reading class
 };
 
 // Direction code of a unit normal: 2 * axis + (1 if it points along +axis) for an EXACT axis normal (one component
@@ -55,6 +85,80 @@ inline int direction_code(const double* n, int ndim) {
     axis = k;
   }
   return axis < 0 ? 6 : 2 * axis + (n[axis] > 0.0 ? 1 : 0);
+}
+
+// The patches of the mesh, found from the reference-format arrays alone. deg / ef: the faces of every owned element in
+// ascending face id. Anything unexpected (a hanging face, a wall, a periodic wrap that turns a face round, another
+// face numbering) fails a check and leaves the elements to the generic tiles.
+void find_patches(TilePlan& P, const int32_t* fn, const double* normals, const double* areas, const std::vector<int32_t>& deg,
+                  const std::vector<int32_t>& ef) {
+  const int32_t N = P.N, F = P.F, nd = P.ndim;
+  int li[kPatchElems], lj[kPatchElems];
+  for (int t = 0; t < kPatchElems; t++) {
+    li[t] = lj[t] = 0;
+    for (int b = 0; b < 4; b++) {
+      li[t] |= ((t >> (2 * b)) & 1) << b;
+      lj[t] |= ((t >> (2 * b + 1)) & 1) << b;
+    }
+  }
+  auto axis_of = [&](int32_t f) -> int {   // 0: exactly +e_x, 1: exactly +e_y, -1: anything else
+    const double* n = normals + static_cast<size_t>(nd) * f;
+    if (nd == 3 && n[2] != 0.0) return -1;
+    if (n[0] == 1.0 && n[1] == 0.0) return 0;
+    if (n[0] == 0.0 && n[1] == 1.0) return 1;
+    return -1;
+  };
+  int32_t e0 = 0;
+  while (e0 + kPatchElems <= N) {
+    Patch pt;
+    bool  ok = true;
+    for (int t = 0; t < kPatchElems && ok; t++) {
+      const int32_t e = e0 + t;
+      ok = deg[e + 1] - deg[e] == 4;
+      if (!ok) break;
+      const int32_t* fl = &ef[deg[e]];
+      int32_t        own[2] = {-1, -1}, far[2] = {-1, -1};   // the element's +x / +y faces, its -x / -y faces
+      for (int q = 0; q < 4 && ok; q++) {
+        const int32_t f = fl[q];
+        const int     ax = f < F ? axis_of(f) : -1;
+        if (ax < 0) { ok = false; break; }
+        const int32_t l = fn[2 * static_cast<size_t>(f)], r = fn[2 * static_cast<size_t>(f) + 1];
+        if (l == r) ok = false;
+        else if (l == e && own[ax] < 0) own[ax] = f;
+        else if (r == e && far[ax] < 0) far[ax] = f;
+        else ok = false;
+      }
+      if (!ok || own[0] < 0 || own[1] < 0 || far[0] < 0 || far[1] < 0) { ok = false; break; }
+      if (t == 0) {
+        pt.e0    = e0;
+        pt.fbase = own[0];
+        pt.area  = areas[own[0]];
+      }
+      for (int q = 0; q < 4; q++) ok = ok && areas[fl[q]] == pt.area;
+      ok = ok && own[0] == pt.fbase + 2 * t && own[1] == pt.fbase + 2 * t + 1 && fl[2] == own[0] && fl[3] == own[1];
+      if (!ok) break;
+      const int  i = li[t], j = lj[t];
+      const bool yfirst = fl[0] == far[1];
+      if (t == 0) pt.flags = yfirst ? 1 : 0;
+      else ok = yfirst == patch_y_first(i, j);
+      const int32_t px = fn[2 * static_cast<size_t>(own[0]) + 1], py = fn[2 * static_cast<size_t>(own[1]) + 1];
+      const int32_t mx = fn[2 * static_cast<size_t>(far[0])], my = fn[2 * static_cast<size_t>(far[1])];
+      auto outside = [&](int32_t s) { return s < e0 || s >= e0 + kPatchElems; };
+      // (a - side face whose left element is a ghost is reported -- speed estimate -- by the tile of its right element,
+      // which a patch cannot do: such blocks stay generic tiles. Ghosts across the + sides are fine.)
+      auto owned_outside = [&](int32_t s) { return s < N && (s < e0 || s >= e0 + kPatchElems); };
+      if (i < kPatchSide - 1) ok = ok && px == e0 + morton2(i + 1, j); else { ok = ok && outside(px); pt.halo[16 + j] = px; }
+      if (i > 0)              ok = ok && mx == e0 + morton2(i - 1, j); else { ok = ok && owned_outside(mx); pt.halo[j] = mx; }
+      if (j < kPatchSide - 1) ok = ok && py == e0 + morton2(i, j + 1); else { ok = ok && outside(py); pt.halo[48 + i] = py; }
+      if (j > 0)              ok = ok && my == e0 + morton2(i, j - 1); else { ok = ok && owned_outside(my); pt.halo[32 + i] = my; }
+    }
+    if (ok) {
+      P.patches.push_back(pt);
+      e0 += kPatchElems;
+    } else {
+      e0++;
+    }
+  }
 }
 
 void build(TilePlan& P, const int32_t* fn, const double* normals, const double* areas) {
@@ -92,6 +196,10 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
   };
 
   lap("element -> faces");
+  if (P.want_patches) find_patches(P, fn, normals, areas, deg, ef);
+  std::vector<int32_t> patch_at(static_cast<size_t>(N) + 1, -1);   // patch that starts at an element
+  for (size_t k = 0; k < P.patches.size(); k++) patch_at[P.patches[k].e0] = static_cast<int32_t>(k);
+  lap("patches");
   // greedy tiling: grow the element range while elements <= tmax, distinct faces <= fcap and own + halo
   // elements <= lecap (the kernel's LDS window). The halo count is tracked incrementally: an element that
   // joins the tile stops being halo, its neighbours outside the range become halo.
@@ -101,8 +209,14 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
     std::vector<int32_t> hstamp(static_cast<size_t>(N) + P.G, -1);
     int32_t e = 0, tile = 0;
     while (e < N) {
+      if (patch_at[e] >= 0) {   // a patch is a tile of its own
+        e += kPatchElems;
+        P.elem_off.push_back(e);
+        tile++;
+        continue;
+      }
       int32_t nf = 0, nh = 0, start = e;
-      while (e < N && e - start < P.tmax) {
+      while (e < N && e - start < P.tmax && patch_at[e] < 0) {
         int32_t add = 0, dh = hstamp[e] == tile ? -1 : 0;
         for (int32_t j = deg[e]; j < deg[e + 1]; j++) {
           if (seen[ef[j]] != tile) add++;
@@ -147,7 +261,7 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
             }
           }
       id++;
-      if ((b - a) + nh > P.lecap && b - a > 1) {
+      if (patch_at[a] < 0 && (b - a) + nh > P.lecap && b - a > 1) {
         const int32_t m = a + (b - a) / 2;
         work.push_back({m, b});
         work.push_back({a, m});
@@ -166,8 +280,15 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
   P.face_off.assign(static_cast<size_t>(ntiles) + 1, 0);
   P.csr_off.assign(static_cast<size_t>(N) + 1, 0);
   std::vector<uint8_t> reads_ghost(ntiles, 0);
+  P.tile_patch.assign(ntiles, -1);
+  for (int32_t t = 0; t < ntiles; t++) P.tile_patch[t] = patch_at[P.elem_off[t]];
   auto tile_lists = [&](int32_t t, std::vector<int32_t>& tf, std::vector<int32_t>& halo) {
     const int32_t e0 = P.elem_off[t], e1 = P.elem_off[t + 1];
+    if (P.tile_patch[t] >= 0) {   // no face records; the 64 elements across the sides in the patch kernel's fixed order
+      tf.clear();
+      halo.assign(P.patches[P.tile_patch[t]].halo, P.patches[P.tile_patch[t]].halo + kPatchHalo);
+      return;
+    }
     tf.assign(ef.begin() + deg[e0], ef.begin() + deg[e1]);
     std::sort(tf.begin(), tf.end());
     tf.erase(std::unique(tf.begin(), tf.end()), tf.end());
@@ -188,15 +309,17 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
       tile_lists(t, tf, halo);
       P.face_off[t + 1] = static_cast<int32_t>(tf.size());
       P.halo_off[t + 1] = static_cast<int32_t>(halo.size());
-      reads_ghost[t]    = !halo.empty() && halo.back() >= N;
+      reads_ghost[t]    = !halo.empty() && *std::max_element(halo.begin(), halo.end()) >= N;
     }
   }
   for (int32_t t = 0; t < ntiles; t++) {
     const int32_t ne = P.elem_off[t + 1] - P.elem_off[t], nh = P.halo_off[t + 1], nf = P.face_off[t + 1];
-    P.max_halo  = std::max(P.max_halo, nh);
-    P.max_faces = std::max(P.max_faces, nf);
-    P.max_elems = std::max(P.max_elems, ne);
-    P.max_slots = std::max(P.max_slots, ne + nh);
+    if (P.tile_patch[t] < 0) {   // the maxima size the generic kernels' LDS windows: patch tiles are not theirs
+      P.max_halo  = std::max(P.max_halo, nh);
+      P.max_faces = std::max(P.max_faces, nf);
+      P.max_elems = std::max(P.max_elems, ne);
+      P.max_slots = std::max(P.max_slots, ne + nh);
+    }
     P.halo_off[t + 1] += P.halo_off[t];
     P.face_off[t + 1] += P.face_off[t];
   }
@@ -214,6 +337,11 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
     for (int32_t t = 0; t < ntiles; t++) {
       const int32_t e0 = P.elem_off[t], e1 = P.elem_off[t + 1], ne = e1 - e0;
       tile_lists(t, tf, halo);
+      if (P.tile_patch[t] >= 0) {
+        for (int32_t j = deg[e0]; j < deg[e1]; j++) P.csr_ent[j] = static_cast<uint16_t>(0xFFFFu);   // (never read)
+        std::copy(halo.begin(), halo.end(), P.halo_ids.begin() + P.halo_off[t]);
+        continue;
+      }
       auto loc = [&](int32_t s) -> uint32_t {
         if (s >= e0 && s < e1) return static_cast<uint32_t>(s - e0);
         return static_cast<uint32_t>(ne + (std::lower_bound(halo.begin(), halo.end(), s) - halo.begin()));
@@ -273,15 +401,25 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
         if (reads_ghost[owner[P.halo_ids[j]]]) near_boundary[t] = 1;   // (no ghost ids here: the tile reads none)
     }
   }
+  // (inside every class the patch tiles come first: a launch over a range of tile_order is a patch-kernel launch over
+  // the patch tiles in it and a generic launch over the rest)
   P.tile_order.clear();
-  for (int32_t t = 0; t < ntiles; t++)
-    if (!reads_ghost[t] && !near_boundary[t]) P.tile_order.push_back(t);
+  auto append_class = [&](int cls) {
+    for (int pass = 0; pass < 2; pass++) {
+      for (int32_t t = 0; t < ntiles; t++) {
+        const int c = reads_ghost[t] ? 2 : (near_boundary[t] ? 1 : 0);
+        if (c == cls && (P.tile_patch[t] >= 0) == (pass == 0)) P.tile_order.push_back(t);
+      }
+      if (pass == 0) P.n_patch_class[cls] = static_cast<int32_t>(P.tile_order.size());
+    }
+  };
+  append_class(0);
   P.n_deep = static_cast<int32_t>(P.tile_order.size());
-  for (int32_t t = 0; t < ntiles; t++)
-    if (!reads_ghost[t] && near_boundary[t]) P.tile_order.push_back(t);
+  append_class(1);
+  P.n_patch_class[1] -= P.n_deep;
   P.n_interior = static_cast<int32_t>(P.tile_order.size());
-  for (int32_t t = 0; t < ntiles; t++)
-    if (reads_ghost[t]) P.tile_order.push_back(t);
+  append_class(2);
+  P.n_patch_class[2] -= P.n_interior;
 
   lap("tile classes");
   // fixed-width (ELL) copy of the element face lists: one aligned 16-byte load per 8 entries
@@ -364,11 +502,13 @@ extern "C" {
 
 // fn = [2F + B] reference face_neighbors (local slots), normals = [ndim * (F + B)], areas = [F + B].
 // Returns null if a limit of the packed format is exceeded (tile-local index >= 0xFFFF, > 32767 faces).
-void* t8gpu_plan_plain_create(int32_t N, int32_t G, int32_t F, int32_t B, int32_t ndim, const int32_t* fn,
-                              const double* normals, const double* areas, int32_t tmax, int32_t fcap) {
+// flags bit 0: cut structured patches (find_patches) out of the tiling
+void* t8gpu_plan_plain_create_ex(int32_t N, int32_t G, int32_t F, int32_t B, int32_t ndim, const int32_t* fn,
+                                 const double* normals, const double* areas, int32_t tmax, int32_t fcap, int32_t flags) {
   if (N < 0 || F < 0 || B < 0 || ndim < 2 || ndim > 3 || tmax < 1 || tmax > 1024 || fcap < 1) return nullptr;
   TilePlan* P = new TilePlan;
   P->N = N; P->G = G; P->F = F; P->B = B; P->ndim = ndim; P->tmax = tmax; P->fcap = fcap;
+  P->want_patches = flags & 1;
   build(*P, fn, normals, areas);
   if (P->max_elems + P->max_halo >= 0xFFFF || P->max_faces > 0x7FFE) {
     delete P;
@@ -376,10 +516,22 @@ void* t8gpu_plan_plain_create(int32_t N, int32_t G, int32_t F, int32_t B, int32_
   }
   return P;
 }
+void* t8gpu_plan_plain_create(int32_t N, int32_t G, int32_t F, int32_t B, int32_t ndim, const int32_t* fn,
+                              const double* normals, const double* areas, int32_t tmax, int32_t fcap) {
+  return t8gpu_plan_plain_create_ex(N, G, F, B, ndim, fn, normals, areas, tmax, fcap, 0);
+}
 void t8gpu_plan_plain_destroy(void* h) { delete static_cast<TilePlan*>(h); }
 
+// counts[4] = leading patch tiles of the deep / near-boundary / ghost-reading class of tile_order, and their total
+void t8gpu_plan_plain_patch_counts(const void* h, int32_t* counts) {
+  const TilePlan* P = static_cast<const TilePlan*>(h);
+  for (int c = 0; c < 3; c++) counts[c] = P->n_patch_class[c];
+  counts[3] = static_cast<int32_t>(P->patches.size());
+}
+
 // sizes[16] = {ntiles, n_halo, n_faces, n_csr, max_elems, max_halo, max_faces, n_interior_tiles, N, F,
-//              ell_width, n_geo (0: no dictionary)}
+//              ell_width, n_geo (0: no dictionary), max_slots, n_deep_tiles, n_patches, 0}; the maxima are over the
+//              generic tiles only
 void t8gpu_plan_plain_sizes(const void* h, int64_t* sizes) {
   const TilePlan* P = static_cast<const TilePlan*>(h);
   sizes[0] = static_cast<int64_t>(P->elem_off.size()) - 1;
@@ -396,7 +548,8 @@ void t8gpu_plan_plain_sizes(const void* h, int64_t* sizes) {
   sizes[11] = static_cast<int64_t>(P->geo_table.size() / 12);
   sizes[12] = P->max_slots;
   sizes[13] = P->n_deep;
-  sizes[14] = sizes[15] = 0;
+  sizes[14] = static_cast<int64_t>(P->patches.size());
+  sizes[15] = 0;
 }
 
 void t8gpu_plan_plain_compressed(const void* h, uint16_t* ell, uint16_t* geo_idx, double* geo_table) {
@@ -415,6 +568,12 @@ void t8gpu_plan_plain_tile_desc(const void* h, int32_t* tile_desc) {
     d[2] = P->halo_off[t]; d[3] = P->halo_off[t + 1] - P->halo_off[t];
     d[4] = P->face_off[t]; d[5] = P->face_off[t + 1] - P->face_off[t];
     d[6] = d[7] = 0;
+    if (!P->tile_patch.empty() && P->tile_patch[t] >= 0) {   // patch tile: {e0, 256, first halo entry, 64, fbase, 0x100 | flags, area}
+      const Patch& pt = P->patches[P->tile_patch[t]];
+      d[4] = pt.fbase;
+      d[5] = 0x100 | pt.flags;
+      std::memcpy(d + 6, &pt.area, 8);
+    }
   }
 }
 

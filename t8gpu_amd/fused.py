@@ -13,14 +13,19 @@ class T8gpuPlainPlan(C.Structure):
         ("ntiles", C.c_int32), ("n_interior_tiles", C.c_int32), ("max_elems", C.c_int32), ("max_halo", C.c_int32),
         ("max_faces", C.c_int32), ("ell_width", C.c_int32), ("ell", C.c_void_p), ("geo_idx", C.c_void_p),
         ("geo_table", C.c_void_p), ("n_geo", C.c_int32), ("max_slots", C.c_int32), ("n_deep_tiles", C.c_int32),
-        ("reserved", C.c_int32), ("tile_desc", C.c_void_p)]
+        ("reserved", C.c_int32), ("tile_desc", C.c_void_p), ("n_patch_tiles", C.c_int32 * 3), ("reserved2", C.c_int32)]
 
 
 class PlainPlan:
-    def __init__(self, part, dtype, tmax=None, fcap=None, compressed=True, dictionary=True):
+    def __init__(self, part, dtype, tmax=None, fcap=None, compressed=True, dictionary=True, patches=None):
         """compressed=False: generic kernel (CSR lists, full geometry). dictionary=False: pipelined kernel
-        with per-face geometry rows even where the mesh has few distinct ones (what curved meshes get anyway)."""
+        with per-face geometry rows even where the mesh has few distinct ones (what curved meshes get anyway).
+        patches: cut structured 16 x 16 patches out of the tiling for the patch kernel (default: yes for the compressed
+        plan; T8GPU_PATCH=0 switches it off -- same results bit for bit, every element through the tile kernels)."""
         import os
+        if patches is None:
+            patches = compressed and os.environ.get("T8GPU_PATCH", "1") != "0"
+        self.patches = bool(patches and compressed)
         # tuning knobs of the tiling. A mesh that would give fewer than 512 tiles (two per CU) gets half-size tiles:
         # c1 (65 536 elements) runs 16 % faster on 512 tiles of 128 than on 256 tiles of 256.
         given_fcap = fcap
@@ -56,13 +61,13 @@ class PlainPlan:
                     self.auto_fcap = 480
         fcap = int(os.environ.get("T8GPU_FCAP", 512)) if fcap is None else fcap
         # the per-face geometry rows are only read by the kernels without a dictionary (generic kernel, dictionary=False)
-        self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary))
+        self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary), patches=self.patches)
         if retry_768:
             h = self.host   # does the persistent kernel take this plan (kernels_fused_persistent.hip: its launcher's test)?
             lds = 8 * (5 * 512 + 12 * h.geo_table.shape[0] + 10 * h.max_slots) + 2048
             if not (compressed and dictionary and 0 < h.geo_table.shape[0] <= 128 and h.ell_width <= 24 and 3 * lds <= 156 * 1024):
                 fcap = self.auto_fcap = 768
-                self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary))
+                self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary), patches=self.patches)
         self.dtype = dtype
         self._keep = {}
         c = T8gpuPlainPlan()
@@ -71,7 +76,7 @@ class PlainPlan:
         skip_geo = (compressed and dictionary and h.geo_table.shape[0] > 0 and h.max_elems <= 256 and h.max_slots <= 512
                     and h.max_faces <= 1024)
         if not skip_geo and h.face_geo.shape[0] == 0 and h.face_lr.size:     # the kernels this plan gets do read the rows
-            self.host = h = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=True)
+            self.host = h = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=True, patches=self.patches)
         for name in HostPlainPlan.FIELDS:
             a = getattr(self.host, name)
             if name == "face_geo":
@@ -100,6 +105,8 @@ class PlainPlan:
         c.ntiles, c.n_interior_tiles = self.host.ntiles, self.host.n_interior
         c.max_elems, c.max_halo, c.max_faces = self.host.max_elems, self.host.max_halo, self.host.max_faces
         c.max_slots, c.n_deep_tiles = self.host.max_slots, self.host.n_deep
+        for k in range(3):
+            c.n_patch_tiles[k] = self.host.n_patch_class[k]
         self.c = c
 
     @staticmethod

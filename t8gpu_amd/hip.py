@@ -6,6 +6,7 @@ import numpy as np
 
 from . import build as _build
 
+ABI_VERSION = 4   # t8gpu_hip_abi_version() of include/t8gpu_hip.h: the layout of the plan structs mirrored in fused.py
 KEPES, HLL, HLLC = 0, 1, 2   # HLLC is an addition: the reference has none
 
 
@@ -35,6 +36,11 @@ def lib():
             raise T8gpuHipError(f"{path} is missing: run `python -m t8gpu_amd.build` (hipcc --offload-arch=gfx950). "
                                 "There is no CPU fallback for the hot path.")
         _lib = C.CDLL(path)
+        _lib.t8gpu_hip_abi_version.restype = C.c_int
+        if _lib.t8gpu_hip_abi_version() != ABI_VERSION:   # a stale build would misread the plan structs
+            got, _lib = _lib.t8gpu_hip_abi_version(), None
+            raise T8gpuHipError(f"{path} has ABI version {got}, this package needs {ABI_VERSION}: rebuild it "
+                                "(`python -m t8gpu_amd.build`)")
         _lib.t8gpu_hip_error_string.restype = C.c_char_p
         _lib.t8gpu_hip_error_string.argtypes = [C.c_int]
     return _lib

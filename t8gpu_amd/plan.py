@@ -14,6 +14,9 @@ def _lib():
     if not _ready:
         lib.t8gpu_plan_plain_create.restype = C.c_void_p
         lib.t8gpu_plan_plain_create.argtypes = [C.c_int32] * 5 + [C.c_void_p] * 3 + [C.c_int32] * 2
+        lib.t8gpu_plan_plain_create_ex.restype = C.c_void_p
+        lib.t8gpu_plan_plain_create_ex.argtypes = [C.c_int32] * 5 + [C.c_void_p] * 3 + [C.c_int32] * 3
+        lib.t8gpu_plan_plain_patch_counts.argtypes = [C.c_void_p] * 2
         lib.t8gpu_plan_plain_destroy.argtypes = [C.c_void_p]
         lib.t8gpu_plan_plain_sizes.argtypes = [C.c_void_p, C.c_void_p]
         lib.t8gpu_plan_plain_arrays.argtypes = [C.c_void_p] * 11
@@ -29,8 +32,11 @@ class HostPlainPlan:
     FIELDS = ("elem_off", "halo_off", "face_off", "halo_ids", "face_lr", "face_geo", "face_orig", "csr_off",
               "csr_ent", "tile_order")
 
-    def __init__(self, N, G, F, B, ndim, face_neighbors, normals, areas, tmax=256, fcap=512, want_face_geo=True):
-        """want_face_geo=False: leave `face_geo` (32 bytes per tile face, only read by the kernels that have no geometry
+    def __init__(self, N, G, F, B, ndim, face_neighbors, normals, areas, tmax=256, fcap=512, want_face_geo=True,
+                 patches=False):
+        """patches=True: structured 16 x 16 patches are cut out of the tiling (tile_plan.cpp: find_patches); they are
+        tiles without face records (`tile_patch[t]` = 1), first inside every class of `tile_order` (`n_patch_class`).
+        want_face_geo=False: leave `face_geo` (32 bytes per tile face, only read by the kernels that have no geometry
         dictionary) empty when the plan has a dictionary -- at c4 size that is 700 MB of host copying per plan."""
         lib = _lib()
         fn = np.ascontiguousarray(face_neighbors, np.int32)
@@ -38,7 +44,7 @@ class HostPlainPlan:
         ar = np.ascontiguousarray(areas, np.float64)
         assert fn.size == 2 * F + B and nr.size == ndim * (F + B) and ar.size == F + B
         p = _synth._p
-        h = lib.t8gpu_plan_plain_create(N, G, F, B, ndim, p(fn), p(nr), p(ar), tmax, fcap)
+        h = lib.t8gpu_plan_plain_create_ex(N, G, F, B, ndim, p(fn), p(nr), p(ar), tmax, fcap, 1 if patches else 0)
         if not h:
             raise ValueError("tile plan exceeds the packed index format (use smaller tmax / fcap)")
         try:
@@ -68,6 +74,13 @@ class HostPlainPlan:
             self.tile_desc = np.zeros((max(1, self.ntiles), 8), np.int32)
             if self.ntiles:
                 lib.t8gpu_plan_plain_tile_desc(h, p(self.tile_desc))
+            cnt = np.zeros(4, np.int32)
+            lib.t8gpu_plan_plain_patch_counts(h, p(cnt))
+            self.n_patch_class, self.n_patches = tuple(int(x) for x in cnt[:3]), int(cnt[3])
+            # per tile (index, not position): is it a patch tile? (tile_desc is in tile_order order)
+            self.tile_patch = np.zeros(self.ntiles, bool)
+            if self.ntiles:
+                self.tile_patch[self.tile_order] = (self.tile_desc[:self.ntiles, 5] & 0x100) != 0
         finally:
             lib.t8gpu_plan_plain_destroy(h)
 

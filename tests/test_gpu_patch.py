@@ -1,0 +1,124 @@
+"""-m gpu: the structured-patch kernel (kernels_fused_patch.hip) against the CPU oracle and against the tile kernels.
+
+A plan built with patches sends 16 x 16 same-level blocks through the patch kernel and everything else through the tile
+kernels; built without (patches=False / T8GPU_PATCH=0) every element goes through the tile kernels. Both evaluate every
+face with the same function on the same operands and add a cell's fluxes in ascending face id, so the two agree BIT FOR
+BIT -- states and speed estimates -- and both meet the oracle within the parity tolerance
+(examples/compressible_euler/kernels.cu:135-309, ssp_runge_kutta.inl:30-99)."""
+import numpy as np
+import pytest
+import torch
+
+import _oracle as O
+from _gpu import NP, TOL1, TOL10, perturbed_state, rel_err
+from t8gpu_amd import hip
+from t8gpu_amd.solver import PlainSolver
+from t8gpu_amd.synth import SynthMesh
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float64, torch.float32]
+# uniform (inner patches only: the periodic wrap turns the outermost faces round), AMR bands (patches next to coarser and
+# finer tiles), walls all round
+MESHES = [dict(dim=2, base_level=7, max_level=7), dict(dim=2, base_level=4, max_level=8, band=0.12),
+          dict(dim=2, base_level=5, max_level=7, band=0.2, periodic=False)]
+
+
+def _pair(part, dtype, kind, st, **plan_options):
+    a = PlainSolver(part, dtype, flux_kind=kind, mode="fused", state=st, plan_options=dict(patches=True, **plan_options))
+    b = PlainSolver(part, dtype, flux_kind=kind, mode="fused", state=st, plan_options=dict(patches=False, **plan_options))
+    assert a.plan.host.n_patches > 0 and b.plan.host.n_patches == 0
+    return a, b
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kind", [hip.KEPES, hip.HLL, hip.HLLC])
+@pytest.mark.parametrize("mesh_args", MESHES)
+def test_patch_kernel_vs_oracle_and_bitwise_vs_tile_kernels(dtype, kind, mesh_args):
+    mesh = SynthMesh(**mesh_args)
+    part = mesh.partition()
+    st = perturbed_state(part, 31)
+    a, b = _pair(part, dtype, kind, st)
+    o = O.PlainCase(part, NP[dtype], state=st)
+    dt = 0.1 * 2.0 ** -mesh.finest_level
+    a.iterate(dt)
+    b.iterate(dt)
+    o.iterate(dt, kind=kind)
+    torch.cuda.synchronize()
+    assert rel_err(a.state().cpu().numpy(), o.current()[:, :part.N]) < TOL1[dtype]
+    assert rel_err(a.speed.cpu().numpy()[None, :part.F + part.B], o.speed[None]) < TOL1[dtype] * 10
+    assert torch.equal(a.state(), b.state()) and torch.equal(a.speed, b.speed)
+    assert (a.planes[20:25] == 0).all()
+    for _ in range(9):
+        a.iterate(dt)
+        b.iterate(dt)
+        o.iterate(dt, kind=kind)
+    assert rel_err(a.state().cpu().numpy(), o.current()[:, :part.N]) < TOL10[dtype]
+    assert torch.equal(a.state(), b.state()) and torch.equal(a.speed, b.speed)
+
+
+def test_patch_kernel_through_the_native_stepper_and_one_patch_per_workgroup():
+    """The C++ step driver (whole-plan launches: persistent grids) and explicit partial ranges (one patch per workgroup,
+    what a class-split multi-rank stage launches) give the same bits."""
+    mesh = SynthMesh(2, 4, 8, band=0.12)
+    part = mesh.partition()
+    st = perturbed_state(part, 5)
+    a, b = _pair(part, torch.float64, hip.KEPES, st)
+    a.use_native_stepper()
+    dt = 0.1 * 2.0 ** -8
+    a.iterate_steps(3, dt)
+    for _ in range(3):
+        b.iterate(dt)
+    torch.cuda.synchronize()
+    assert torch.equal(a.state(), b.state()) and torch.equal(a.speed, b.speed)
+    # the same stage in three pieces that cut through the patch tiles and the generic tiles
+    c = PlainSolver(part, torch.float64, mode="fused", state=st, plan_options=dict(patches=True))
+    d = PlainSolver(part, torch.float64, mode="fused", state=st, plan_options=dict(patches=True))
+    nt, npatch = c.plan.host.ntiles, c.plan.host.n_patches
+    cuts = [0, npatch // 3, npatch + (nt - npatch) // 2, nt]
+    s = hip.stream_ptr()
+    c.begin_step()                                             # (prev = the planes that hold the state, solver.cu:76)
+    d.begin_step()
+    c.plan.stage(c, 1, c.prev, 1, dt, s)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        d.plan.stage(d, 1, d.prev, 1, dt, s, tile_begin=lo, tile_count=hi - lo)
+    torch.cuda.synchronize()
+    assert not torch.isnan(c.planes).any() and torch.equal(c.planes, d.planes)
+
+
+def test_patch_plan_on_a_partition_is_bitwise_the_single_rank_run():
+    """A 3-way SFC partition with patches on every rank (ghosts across the + sides of patches, patch tiles in several
+    tile classes, interior / ghost-reading ranges launched separately) through the loopback transport of
+    tests/test_gpu_halo.py: bitwise the single-rank run without patches."""
+    from test_gpu_halo import loopback
+    from t8gpu_amd.halo import HaloExchange
+    mesh = SynthMesh(2, 4, 8, band=0.12)
+    whole = mesh.partition()
+    st = perturbed_state(whole, 17)
+    ref = PlainSolver(whole, torch.float64, mode="fused", state=st, plan_options=dict(patches=False))
+    world = 3
+    parts = [mesh.partition(r, world) for r in range(world)]
+    solvers, halos = [], []
+    for part in parts:
+        gidx = np.concatenate([part.first_global + np.arange(part.N), part.ghost_global])
+        local = st[:, gidx].copy()
+        local[:, part.N:] = np.nan
+        solvers.append(PlainSolver(part, torch.float64, mode="fused", state=local, plan_options=dict(patches=True)))
+        halos.append(HaloExchange(part, torch.float64, dist=None, overlap=False))
+    assert all(s.plan.host.n_patches > 0 for s in solvers)
+    assert sum(s.plan.host.n_patch_class[1] + s.plan.host.n_patch_class[2] for s in solvers) > 0   # not only deep patches
+    dt = 0.1 * 2.0 ** -8
+    for _ in range(3):
+        ref.iterate(dt)
+        for s in solvers:
+            s.begin_step()
+        for k in range(3):
+            for s, h in zip(solvers, halos):
+                h._pack(s.step_planes(s.stage_steps(k)[0]))
+            loopback(halos)
+            for s, h in zip(solvers, halos):
+                h._unpack(s.step_planes(s.stage_steps(k)[0]))
+            for s in solvers:
+                s.run_stage(k, dt, split=True)
+    torch.cuda.synchronize()
+    full = torch.cat([s.state() for s in solvers], dim=1)
+    assert torch.equal(full, ref.state())

@@ -11,11 +11,54 @@ from t8gpu_amd.plan import HostPlainPlan
 from t8gpu_amd.synth import SynthMesh
 
 
-def interpret(plan, part, state, speed_out=None):
-    """Net flux per owned element exactly as the fused kernel accumulates it (fp64, oracle flux)."""
+def _morton(i, j):
+    t = 0
+    for b in range(4):
+        t |= ((i >> b) & 1) << (2 * b) | ((j >> b) & 1) << (2 * b + 1)
+    return t
+
+
+def _ctz4(v):
+    return 4 if v == 0 else (v & -v).bit_length() - 1
+
+
+def interpret_patch(plan, t, state, net, reporters):
+    """A patch tile as kernels_fused_patch.hip evaluates it: nothing but the descriptor and the 64 elements across the
+    sides; neighbours, face ids and the summation order follow from the position (i, j) in the 16 x 16 block."""
+    pos = int(np.flatnonzero(plan.tile_order == t)[0])
+    d = plan.tile_desc[pos]
+    e0, ne, h0, nh, fbase, flags = (int(x) for x in d[:6])
+    assert ne == 256 and nh == 64 and (flags & 0x100) and e0 == plan.elem_off[t] and h0 == plan.halo_off[t]
+    area = float(d[6:8].copy().view(np.float64)[0])
+    halo = plan.halo_ids[h0:h0 + 64]
+    ex, ey = np.array([[1.0, 0.0, 0.0]]), np.array([[0.0, 1.0, 0.0]])
+
+    def flux(n, l, r):
+        return area * O.xyz_face_flux(0, n, state[:, [l]].T.copy(), state[:, [r]].T.copy())[0]
+
+    for i in range(16):
+        for j in range(16):
+            e = e0 + _morton(i, j)
+            px = e0 + _morton(i + 1, j) if i < 15 else halo[16 + j]
+            mx = e0 + _morton(i - 1, j) if i > 0 else halo[j]
+            py = e0 + _morton(i, j + 1) if j < 15 else halo[48 + i]
+            my = e0 + _morton(i, j - 1) if j > 0 else halo[32 + i]
+            f_mx, f_my, f_px, f_py = flux(ex, mx, e), flux(ey, my, e), flux(ex, e, px), flux(ey, e, py)
+            yfirst = bool(flags & 1) if (i, j) == (0, 0) else _ctz4(j) >= _ctz4(i)
+            first, second = (f_my, f_mx) if yfirst else (f_mx, f_my)
+            net[:, e] = ((first + second) - f_px) - f_py
+            reporters += [fbase + 2 * _morton(i, j), fbase + 2 * _morton(i, j) + 1]
+
+
+def interpret(plan, part, state, reporters=None):
+    """Net flux per owned element exactly as the fused kernels accumulate it (fp64, oracle flux)."""
     N = part.N
     net = np.zeros((5, N))
+    reporters = [] if reporters is None else reporters
     for t in range(plan.ntiles):
+        if plan.tile_patch[t]:
+            interpret_patch(plan, t, state, net, reporters)
+            continue
         e0, e1 = plan.elem_off[t], plan.elem_off[t + 1]
         halo = plan.halo_ids[plan.halo_off[t]:plan.halo_off[t + 1]]
         slots = np.concatenate([np.arange(e0, e1), halo])
@@ -36,18 +79,26 @@ def interpret(plan, part, state, speed_out=None):
             for ent in plan.csr_ent[plan.csr_off[e]:plan.csr_off[e + 1]]:
                 f = int(ent) & 0x7FFF
                 net[:, e] += ff[f] if (int(ent) & 0x8000) else -ff[f]
+        orig = plan.face_orig[f0:f1]
+        reporters += [int(x) for x in orig[orig >= 0]]
     return net
 
 
-@pytest.mark.parametrize("mesh_args,ranks", [(dict(dim=2, base_level=3, max_level=6, band=0.06), 1),
-                                             (dict(dim=2, base_level=3, max_level=5, band=0.06, periodic=False), 1),
-                                             (dict(dim=3, base_level=2, max_level=3, band=0.2), 1),
-                                             (dict(dim=2, base_level=3, max_level=6, band=0.06), 3)])
-def test_plan_reproduces_the_face_loop(mesh_args, ranks):
+@pytest.mark.parametrize("mesh_args,ranks,patches", [(dict(dim=2, base_level=3, max_level=6, band=0.06), 1, False),
+                                                     (dict(dim=2, base_level=3, max_level=5, band=0.06, periodic=False), 1, False),
+                                                     (dict(dim=3, base_level=2, max_level=3, band=0.2), 1, False),
+                                                     (dict(dim=2, base_level=3, max_level=6, band=0.06), 3, False),
+                                                     (dict(dim=2, base_level=4, max_level=7, band=0.12), 1, True),
+                                                     (dict(dim=2, base_level=6, max_level=6, periodic=False), 1, True),
+                                                     (dict(dim=2, base_level=4, max_level=7, band=0.12), 3, True)])
+def test_plan_reproduces_the_face_loop(mesh_args, ranks, patches):
     mesh = SynthMesh(**mesh_args)
+    n_patches = 0
     for rk in range(ranks):
         part = mesh.partition(rk, ranks)
-        plan = HostPlainPlan.from_partition(part, tmax=64, fcap=150)
+        plan = HostPlainPlan.from_partition(part, tmax=64, fcap=150, patches=patches)
+        n_patches += plan.n_patches
+        assert plan.n_patches == int(plan.tile_patch.sum()) == sum(plan.n_patch_class) and (plan.n_patches > 0) == patches
         st = perturbed_state(part, 11 + rk)
         o = O.PlainCase(part, np.float64, state=st)
         getattr(O.lib(), "oracle_plain_interior_faces_f64")(0, part.F, 3, O.p(o.fn), O.p(part.indices), O.p(o.normals), O.p(o.areas),
@@ -56,12 +107,14 @@ def test_plan_reproduces_the_face_loop(mesh_args, ranks):
             getattr(O.lib(), "oracle_plain_boundary_faces_f64")(0, part.F, part.B, 3, O.p(o.fn), O.p(o.normals), O.p(o.areas),
                                                                 O.p(o.planes[0:5]), O.p(o.planes[20:25]), C.c_size_t(o.stride), O.p(o.speed))
         want = o.planes[20:25, :part.N]
-        got = interpret(plan, part, st)
+        rep = []
+        got = interpret(plan, part, st, rep)
         assert np.abs(got - want).max() < 1e-13 * max(1.0, np.abs(want).max())
         # invariants of the packed format
         assert plan.elem_off[0] == 0 and plan.elem_off[-1] == part.N and (np.diff(plan.elem_off) > 0).all()
-        assert np.diff(plan.elem_off).max() <= 64 and plan.max_faces <= max(150, np.diff(plan.csr_off).max())
-        rep = plan.face_orig[plan.face_orig >= 0]
+        generic = ~plan.tile_patch
+        assert np.diff(plan.elem_off)[generic].max() <= 64 and plan.max_faces <= max(150, np.diff(plan.csr_off).max())
+        assert (np.diff(plan.elem_off)[plan.tile_patch] == 256).all() and (np.diff(plan.face_off)[plan.tile_patch] == 0).all()
         assert np.array_equal(np.sort(rep), np.arange(part.F + part.B))      # every face has exactly one reporter
         order = plan.tile_order
         assert np.array_equal(np.sort(order), np.arange(plan.ntiles))
@@ -69,6 +122,11 @@ def test_plan_reproduces_the_face_loop(mesh_args, ranks):
         assert not reads_ghost[order[:plan.n_interior]].any() and reads_ghost[order[plan.n_interior:]].all()
         if ranks == 1:
             assert plan.n_interior == plan.ntiles
+        # inside every class of tile_order the patch tiles come first
+        for c, (a, b) in enumerate(((0, plan.n_deep), (plan.n_deep, plan.n_interior), (plan.n_interior, plan.ntiles))):
+            flags = plan.tile_patch[order[a:b]]
+            assert flags[:plan.n_patch_class[c]].all() and not flags[plan.n_patch_class[c]:].any()
+    assert (n_patches > 0) == patches
 
 
 def test_plan_rejects_oversized_tiles():
