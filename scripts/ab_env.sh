@@ -1,17 +1,13 @@
 #!/bin/bash
-# like ab_variants.sh, but varies an environment variable for one library variant
-# usage: scripts/ab_env.sh "<bench args>" <variant> <ENVVAR> value1 value2 ...
-ARGS=$1; V=$2; VAR=$3; shift 3
-ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-mkdir -p "$ROOT/gpurun_out/ab"
-if [ "$V" = default ]; then unset T8GPU_HIP_LIB; else export T8GPU_HIP_LIB=$ROOT/t8gpu_amd/lib/variants/libt8gpu_hip_$V.so; fi
-for val in "$@"; do
-  export $VAR=$val
-  python3 "$ROOT/bench.py" $ARGS --no-cpu-baseline > "$ROOT/gpurun_out/ab/$V.$val.json" 2> "$ROOT/gpurun_out/ab/$V.$val.err" || { echo "$V $VAR=$val FAILED"; tail -3 "$ROOT/gpurun_out/ab/$V.$val.err"; continue; }
-  python3 - "$V $VAR=$val" "$ROOT/gpurun_out/ab/$V.$val.json" <<'PY'
-import json, sys
-j = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
-r = j["roofline"]
-print(f"{sys.argv[1]:>40}: {j['value']:9.1f} M/s  {j['ms_per_step']:.4f} ms/step  stage kernel {r['avg_launch_ms']:.4f} ms")
-PY
+# On the GPU box: one bench line per value of an environment variable, same box.
+# usage: scripts/ab_env.sh VAR "v1 v2 ..." <bench args...>
+set -o pipefail
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+VAR=$1; VALS=$2; shift 2
+mkdir -p gpurun_out
+for v in $VALS; do
+  env $VAR=$v timeout -k 10 300 python bench.py "$@" --no-cpu-baseline 2> gpurun_out/ab_env.err | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline()); r = d.get('roofline', {})
+print(json.dumps({'$VAR': '$v', 'value': d['value'], 'ms_per_step': d['ms_per_step'], 'avg_launch_ms': r.get('avg_launch_ms'), 'frac': r.get('frac')}))" | tee -a gpurun_out/ab_env.jsonl || { tail -5 gpurun_out/ab_env.err; exit 1; }
 done

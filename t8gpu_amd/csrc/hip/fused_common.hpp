@@ -111,10 +111,11 @@ template <class T>
 int plain_persistent_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count, FVars<T> prev,
                            FVars<T> mid, FVars<T> out, const T* volume, T dt, T* speed, hipStream_t stream);
 
-// structured-patch kernel (kernels_fused_patch.hip): [tile_begin, tile_begin + tile_count) of tile_order are patch tiles
+// structured-patch kernel (kernels_fused_patch.hip): [patch_begin, +patch_count) of tile_order are patch tiles; the generic
+// tiles [tile_begin, +tile_count) ride in the same launch where the mixed kernel takes them (-1: it does not; launch apart)
 template <class T>
-int plain_patch_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count, FVars<T> prev, FVars<T> mid,
-                      FVars<T> out, const T* volume, T dt, T* speed, bool persistent, hipStream_t stream);
+int plain_patch_stage(int kind, int stage, const T8gpuPlainPlan* plan, int patch_begin, int patch_count, int tile_begin, int tile_count,
+                      FVars<T> prev, FVars<T> mid, FVars<T> out, const T* volume, T dt, T* speed, bool persistent, hipStream_t stream);
 
 }  // namespace t8gpu_hip
 

@@ -29,6 +29,7 @@
 #include <cstdlib>
 
 #include "fused_common.hpp"
+#include "fused_tile_body.hpp"
 
 namespace t8gpu_hip {
 
@@ -93,11 +94,10 @@ T8_DEV void patch_face(bool y, const T* wl, const T* wr, T area, T g[5], T& spd)
   frame_out<T>(y, f, g);
 }
 
-// (second launch bound = waves per SIMD the register allocation must allow: 3 workgroups per CU in fp64, 5 in fp32)
+// workgroup `wg` of the `nwg` that share the patch tiles [tile_begin, tile_begin + tile_count) of tile_order
 template <class T, int KIND, int STAGE>
-__global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_patch(T8gpuPlainPlan P, int tile_begin, int tile_count, FVars<T> prev,
-                                                                                FVars<T> src, FVars<T> out, const T* __restrict__ vol, T dt,
-                                                                                T* __restrict__ speed) {
+T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_count, int wg, int nwg, const FVars<T>& prev,
+                             const FVars<T>& src, const FVars<T>& out, const T* __restrict__ vol, T dt, T* __restrict__ speed) {
   constexpr int NW  = KIND == 0 ? kPrimWords : 5;
   constexpr int REC = rec_words<T, NW>();
   extern __shared__ __attribute__((aligned(16))) double lds_raw[];
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_patch(T8g
 
   // this workgroup's patches (same walk as k_plain_persistent: XCD x takes one contiguous eighth of the range, its
   // workgroups walk it together)
-  const int G = gridDim.x, xcd = blockIdx.x & 7, jw = blockIdx.x >> 3;
+  const int G = nwg, xcd = wg & 7, jw = wg >> 3;
   const int nxcd = G < 8 ? G : 8, nx = (G - xcd + 7) >> 3;
   const int per = tile_count / nxcd, rem = tile_count % nxcd;
   const int x0   = tile_begin + xcd * per + (xcd < rem ? xcd : rem);
@@ -147,7 +147,11 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_patch(T8g
     double area;
   };
   auto load_desc = [&](int tt) {   // scalar load through the constant address space (see k_plain_persistent)
+#ifdef T8GPU_EXP_TILEMOD   // experiment builds only: every patch is one of the first few, all traffic stays in the caches
+    const size_t k = static_cast<size_t>(tile_begin + (tt < tend ? tt : tend - 1) % T8GPU_EXP_TILEMOD);
+#else
     const size_t k = static_cast<size_t>(tt < tend ? tt : tend - 1);
+#endif
     const int8v  r = *reinterpret_cast<const __attribute__((address_space(4))) int8v*>(
         reinterpret_cast<const __attribute__((address_space(4))) char*>(reinterpret_cast<uintptr_t>(P.tile_desc)) + 32 * k);
     Desc d;
@@ -273,17 +277,61 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_patch(T8g
   }
 }
 
-// tiles [tile_begin, tile_begin + tile_count) of tile_order must all be patch tiles. persistent = false: one patch per
-// workgroup (class-split multi-rank launches: slots free up continuously, see plain_fused_stage).
+// (second launch bound = waves per SIMD the register allocation must allow: 3 workgroups per CU in fp64, 5 in fp32)
+template <class T, int KIND, int STAGE>
+__global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_patch(T8gpuPlainPlan P, int tile_begin, int tile_count, FVars<T> prev,
+                                                                                FVars<T> src, FVars<T> out, const T* __restrict__ vol, T dt,
+                                                                                T* __restrict__ speed) {
+  plain_patch_body<T, KIND, STAGE>(P, tile_begin, tile_count, blockIdx.x, gridDim.x, prev, src, out, vol, dt, speed);
+}
+
+// ONE launch per stage for a range of tile_order that holds patch tiles AND generic tiles: the first `patch_wgs`
+// workgroups walk the patch tiles, every further workgroup takes one generic tile (fused_tile_body.hpp). As two launches
+// the generic tiles of the benchmark mesh -- 3 % of its elements -- cost 9 % of the stage: a launch of their own, started
+// when the patch launch has drained. Here they start as the persistent patch workgroups finish and fill the ragged end.
+template <class T, int KIND, int STAGE>
+__global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_stage(T8gpuPlainPlan P, int patch_begin, int patch_count, int patch_wgs,
+                                                                                int tile_begin, int tile_count, FVars<T> prev, FVars<T> src,
+                                                                                FVars<T> out, const T* __restrict__ vol, T dt,
+                                                                                T* __restrict__ speed) {
+  const int b = blockIdx.x;
+  if (b < patch_wgs) {
+    plain_patch_body<T, KIND, STAGE>(P, patch_begin, patch_count, b, patch_wgs, prev, src, out, vol, dt, speed);
+  } else {
+#ifdef T8GPU_EXP_TILEMOD
+    const int pos = tile_begin + xcd_position(b - patch_wgs, tile_count) % T8GPU_EXP_TILEMOD;
+#else
+    const int pos = tile_begin + xcd_position(b - patch_wgs, tile_count);
+#endif
+    plain_tile_body<T, KIND, STAGE, true, 2>(P, pos, prev, src, out, vol, dt, speed);
+  }
+}
+
+// Patch tiles [patch_begin, patch_begin + patch_count) of tile_order, and -- in the same launch -- the generic tiles
+// [tile_begin, tile_begin + tile_count) (tile_count = 0: none). persistent = false: one patch per workgroup (class-split
+// multi-rank launches: slots free up continuously, see plain_fused_stage). Returns -1 when generic tiles were handed in
+// that the mixed kernel does not take (the caller then launches the two parts separately), else 0 or a hipError_t.
 template <class T>
-int plain_patch_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count, FVars<T> prev, FVars<T> mid,
-                      FVars<T> out, const T* volume, T dt, T* speed, bool persistent, hipStream_t stream) {
-  if (tile_count <= 0) return 0;
+int plain_patch_stage(int kind, int stage, const T8gpuPlainPlan* plan, int patch_begin, int patch_count, int tile_begin, int tile_count,
+                      FVars<T> prev, FVars<T> mid, FVars<T> out, const T* volume, T dt, T* speed, bool persistent, hipStream_t stream) {
+  if (patch_count <= 0) return tile_count > 0 ? -1 : 0;
   if (!plan->tile_desc) return static_cast<int>(hipErrorInvalidValue);
   const int    nw  = kind == 0 ? kPrimWords : 5;
   const int    rec = sizeof(T) == 8 ? (nw > 5 ? 10 : 6) : 12;
-  const size_t lds = sizeof(T) * (static_cast<size_t>(5) * kPatchFF + static_cast<size_t>(rec) * 320) +
-                     ((sizeof(T) == 8 && kind == 0) ? 2 * kLogTabEntries * sizeof(double) : 0);
+  const size_t tab = (sizeof(T) == 8 && kind == 0) ? 2 * kLogTabEntries * sizeof(double) : 0;
+  size_t       lds = sizeof(T) * (static_cast<size_t>(5) * kPatchFF + static_cast<size_t>(rec) * 320) + tab;
+  if (tile_count > 0) {
+    // what plain_tile_body<T, K, S, true, 2> takes (kernels_fused.hip: the pipelined kernel with a geometry dictionary, two
+    // passes of 256 faces), and its LDS window
+    const int  slots = plan->max_slots > 0 ? plan->max_slots : plan->max_elems + plan->max_halo;
+    const bool ok = plan->ell && plan->ell_width >= 8 && plan->ell_width % 8 == 0 && plan->max_elems <= 256 && slots <= 512 &&
+                    plan->max_faces <= 512 && plan->geo_idx && plan->geo_table && plan->n_geo > 0;
+    static const bool off = std::getenv("T8GPU_PATCH_MIXED") && std::getenv("T8GPU_PATCH_MIXED")[0] == '0';   // (measurements)
+    if (!ok || off) return -1;
+    const size_t lds_tile = sizeof(T) * (static_cast<size_t>(nw) * slots + static_cast<size_t>(5) * 256) + (tab ? tab + 16 : 0);
+    if (lds_tile > lds) lds = lds_tile;
+    if (sizeof(T) == 8 && 3 * lds > static_cast<size_t>(156) * 1024) return -1;   // (the kernel lives on three workgroups per CU)
+  }
   static int per_cu_env = -1, cus = 0;
   if (cus == 0) {
     int             dev = 0;
@@ -294,11 +342,19 @@ int plain_patch_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
     per_cu_env      = env ? std::atoi(env) : 0;
     if (per_cu_env < 0 || per_cu_env > 8) per_cu_env = 0;
   }
-  const int  per_cu   = per_cu_env > 0 ? per_cu_env : (sizeof(T) == 8 ? 3 : 5);
-  const int  resident = cus * per_cu;
-  const int  grid_size = (!persistent || tile_count < resident) ? tile_count : resident;
-  const dim3 grid(grid_size), block(256);
-#define T8_PA(K, S) hipLaunchKernelGGL((k_plain_patch<T, K, S>), grid, block, lds, stream, *plan, tile_begin, tile_count, prev, mid, out, volume, dt, speed)
+  const int  per_cu    = per_cu_env > 0 ? per_cu_env : (sizeof(T) == 8 ? 3 : 5);
+  const int  resident  = cus * per_cu;
+  const int  patch_wgs = (!persistent || patch_count < resident) ? patch_count : resident;
+  const dim3 grid(patch_wgs + (tile_count > 0 ? tile_count : 0)), block(256);
+#define T8_PA(K, S)                                                                                                               \
+  do {                                                                                                                            \
+    if (tile_count > 0)                                                                                                           \
+      hipLaunchKernelGGL((k_plain_stage<T, K, S>), grid, block, lds, stream, *plan, patch_begin, patch_count, patch_wgs, tile_begin, \
+                         tile_count, prev, mid, out, volume, dt, speed);                                                          \
+    else                                                                                                                          \
+      hipLaunchKernelGGL((k_plain_patch<T, K, S>), grid, block, lds, stream, *plan, patch_begin, patch_count, prev, mid, out, volume, dt, \
+                         speed);                                                                                                  \
+  } while (0)
 #define T8_PAS(K)          \
   do {                     \
     if (stage == 1)        \
@@ -319,9 +375,9 @@ int plain_patch_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
   return static_cast<int>(hipGetLastError());
 }
 
-template int plain_patch_stage<float>(int, int, const T8gpuPlainPlan*, int, int, FVars<float>, FVars<float>, FVars<float>, const float*,
-                                      float, float*, bool, hipStream_t);
-template int plain_patch_stage<double>(int, int, const T8gpuPlainPlan*, int, int, FVars<double>, FVars<double>, FVars<double>,
+template int plain_patch_stage<float>(int, int, const T8gpuPlainPlan*, int, int, int, int, FVars<float>, FVars<float>, FVars<float>,
+                                      const float*, float, float*, bool, hipStream_t);
+template int plain_patch_stage<double>(int, int, const T8gpuPlainPlan*, int, int, int, int, FVars<double>, FVars<double>, FVars<double>,
                                        const double*, double, double*, bool, hipStream_t);
 
 }  // namespace t8gpu_hip
