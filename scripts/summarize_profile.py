@@ -57,7 +57,15 @@ def main(out):
         w = ws[0] / ws[1] if ws[1] else 0.0
         print(f"| {k} | {f:.0f} | {2 * f * 1024 / 1e6:.1f} | {w:.0f} | {w * 1024 / 1e6:.1f} | {(2 * f + w) * 1024 / 1e6:.1f} |")
     # machine-readable traffic per launch of the dominant kernel family (bench.py reports it as roofline.traffic)
-    dom = [k for k in sorted(set(fetch) | set(write)) if k.startswith(("k_plain_patch", "k_plain_stage", "k_plain_persistent", "k_plain_fused", "k_subgrid_family", "k_subgrid444_fused", "k_subgrid_fused", "k_flux_faces", "k_subgrid_inner"))]
+    # the dominant kernel FAMILY (name up to '<') = the one with the largest total duration in the kernel trace; its
+    # instances (one per RK stage) are what bench.py's roofline refers to
+    fam_ns = defaultdict(float)
+    for r in kernel_stats(os.path.join(out, "stats")):
+        n = short(r["Name"])
+        if n.startswith("k_"):
+            fam_ns[n.split("<")[0]] += float(r["TotalDurationNs"])
+    top = max(fam_ns, key=fam_ns.get) if fam_ns else None
+    dom = [k for k in sorted(set(fetch) | set(write)) if top and k.split("<")[0] == top]
     if dom:
         tot = 0.0
         for k in dom:

@@ -54,10 +54,11 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-munsafe-fp
              "-Wno-unused-function"]
 
 
-def build_hip(force=False, variant=None, defines=()):
+def build_hip(force=False, variant=None, defines=(), only=None):
     """One object per .hip file (compiled in parallel, rebuilt only when the file or a header changed), then one link.
     variant / defines: an experiment build with extra -D flags into lib/variants/libt8gpu_hip_<variant>.so
-    (load it with T8GPU_HIP_LIB=...; used for A/B measurements, never by the product path)."""
+    (load it with T8GPU_HIP_LIB=...; used for A/B measurements and diagnostics, never by the product path).
+    only: basenames of the sources the defines matter for -- the other objects are taken from the default build."""
     from concurrent.futures import ThreadPoolExecutor
     srcs = _glob(os.path.join(CSRC, "hip"), (".hip", ".cpp"))
     hdrs = _glob(os.path.join(CSRC, "hip"), (".h", ".hpp")) + _glob(os.path.join(ROOT, "include"), (".h",))
@@ -71,15 +72,23 @@ def build_hip(force=False, variant=None, defines=()):
     if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
         force = True
     jobs = []
+    default_objdir = os.path.join(LIB, "obj", "default")
+    if variant is not None and only is not None:
+        build_hip()                                            # the shared objects must be current
+    def objpath(src):
+        shared = variant is not None and only is not None and os.path.basename(src) not in only
+        return os.path.join(default_objdir if shared else objdir, os.path.basename(src) + ".o")
     for src in srcs:
-        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        obj = objpath(src)
+        if obj.startswith(default_objdir + os.sep) and variant is not None:
+            continue
         if force or _newer(obj, [src] + hdrs):
             jobs.append([hipcc] + flags + ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(CSRC, "hip"), "-c", src, "-o", obj])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
             list(pool.map(_run, jobs))
         open(stamp, "w").write(" ".join(flags))
-    objs = [os.path.join(objdir, os.path.basename(src) + ".o") for src in srcs]
+    objs = [objpath(src) for src in srcs]
     if jobs or _newer(target, objs):
         _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs + ["-L/opt/rocm/lib", "-lrccl"])
     return target
@@ -93,9 +102,19 @@ def build_oracle(force=False):
     return ORACLE_LIB
 
 
+NO_RCCL_LIB = os.path.join(LIB, "variants", "libt8gpu_hip_norccl.so")
+
+
+def build_diagnostic_variants(force=False):
+    """Diagnostic builds the GPU test-suite loads in child processes (never the product path): `norccl` = the step driver
+    with the RCCL group compiled out (tests/test_gpu_graph.py: the three-stream capture without RCCL)."""
+    return build_hip(force, variant="norccl", defines=["-DT8GPU_EXP_NO_RCCL"], only=["stepper.hip"])
+
+
 def build_all(force=False):
     build_host(force)
     build_hip(force)
+    build_diagnostic_variants(force)
     build_oracle(force)
 
 

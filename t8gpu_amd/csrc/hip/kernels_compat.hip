@@ -11,6 +11,7 @@
 #pragma clang fp contract(off)
 
 #include "flux_math.hpp"
+#include "stage_kernel_note.hpp"
 #include "t8gpu_hip.h"
 
 namespace t8gpu_hip {
@@ -348,10 +349,18 @@ int subgrid_faces(int kind, int rank, int F, int count, const int32_t* fn, const
 
 }  // namespace t8gpu_hip
 
+namespace t8gpu_hip {
+StageKernelNote& stage_kernel_note() {
+  static StageKernelNote note = {{0}, -1};
+  return note;
+}
+}  // namespace t8gpu_hip
+
 using namespace t8gpu_hip;
 
 extern "C" {
 
+const char* t8gpu_hip_last_stage_kernel(void) { return stage_kernel_note().name; }
 int t8gpu_hip_abi_version(void) { return 4; }   // 2: T8gpuPlainPlan.tile_desc; 3: T8gpuSubgridPlan row format (far-cell recipes), n_blocks_addressed, family records; 4: T8gpuPlainPlan.n_patch_tiles
 int t8gpu_hip_device_count(int* count) { return static_cast<int>(hipGetDeviceCount(count)); }
 int t8gpu_hip_set_device(int device) { return static_cast<int>(hipSetDevice(device)); }

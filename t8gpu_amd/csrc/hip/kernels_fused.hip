@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "fused_common.hpp"
+#include "stage_kernel_note.hpp"
 
 namespace t8gpu_hip {
 
@@ -171,8 +172,9 @@ int plain_generic_stage(int kind, int stage, const T8gpuPlainPlan* plan, int til
   const bool  dense = pipelined && !scatter && kind == 0 && sizeof(T) == 8 && plan->geo_idx && plan->geo_table && plan->n_geo > 0 &&
                      plan->max_faces <= 512 && (dense_env >= 0 ? dense_env != 0 : lds - lds_table <= static_cast<size_t>(36) * 1024);
   if (dense) lds -= lds_table;   // (the DENSE kernel reads the logarithm table from global memory)
-#define T8_LAUNCH(KERNEL)                                                                                    \
+#define T8_LAUNCH(KERNEL, NAME)                                                                              \
   do {                                                                                                       \
+    note_stage_kernel(tile_count, NAME, static_cast<int>(sizeof(T)), kind, stage);                           \
     if (lds > 64 * 1024) {                                                                                   \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL),                             \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
@@ -184,21 +186,21 @@ int plain_generic_stage(int kind, int stage, const T8gpuPlainPlan* plan, int til
 #define T8_FUSED(K, S)                                              \
   do {                                                              \
     if (scatter && dict && !four)                                   \
-      T8_LAUNCH((k_plain_fused_p<T, K, S, true, 2, true>));         \
+      T8_LAUNCH((k_plain_fused_p<T, K, S, true, 2, true>), "k_plain_fused_p<T, K, S, true, 2, true, false>");         \
     else if (scatter && pipelined && !four)                         \
-      T8_LAUNCH((k_plain_fused_p<T, K, S, false, 2, true>));        \
+      T8_LAUNCH((k_plain_fused_p<T, K, S, false, 2, true>), "k_plain_fused_p<T, K, S, false, 2, true, false>");        \
     else if (dict && !four && dense)                                \
-      T8_LAUNCH((k_plain_fused_p<T, K, S, true, 2, false, true>));  \
+      T8_LAUNCH((k_plain_fused_p<T, K, S, true, 2, false, true>), "k_plain_fused_p<T, K, S, true, 2, false, true>");  \
     else if (dict && !four)                                         \
-      T8_LAUNCH((k_plain_fused_p<T, K, S, true, 2>));               \
+      T8_LAUNCH((k_plain_fused_p<T, K, S, true, 2>), "k_plain_fused_p<T, K, S, true, 2, false, false>");               \
     else if (dict)                                                  \
-      T8_LAUNCH((k_plain_fused_p<T, K, S, true, 4>));               \
+      T8_LAUNCH((k_plain_fused_p<T, K, S, true, 4>), "k_plain_fused_p<T, K, S, true, 4, false, false>");               \
     else if (pipelined && !four)                                    \
-      T8_LAUNCH((k_plain_fused_p<T, K, S, false, 2>));              \
+      T8_LAUNCH((k_plain_fused_p<T, K, S, false, 2>), "k_plain_fused_p<T, K, S, false, 2, false, false>");              \
     else if (pipelined)                                             \
-      T8_LAUNCH((k_plain_fused_p<T, K, S, false, 4>));              \
+      T8_LAUNCH((k_plain_fused_p<T, K, S, false, 4>), "k_plain_fused_p<T, K, S, false, 4, false, false>");              \
     else                                                            \
-      T8_LAUNCH((k_plain_fused<T, K, S>));                          \
+      T8_LAUNCH((k_plain_fused<T, K, S>), "k_plain_fused<T, K, S>");                          \
   } while (0)
   if (kind == 0) {
     if (stage == 1) T8_FUSED(0, 1); else if (stage == 2) T8_FUSED(0, 2); else T8_FUSED(0, 3);
@@ -227,6 +229,7 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
     for (int k = 0; k < 5; k++)
       if (prev.p[k] != mid.p[k]) return static_cast<int>(hipErrorInvalidValue);
   if (tile_count == 0) return 0;
+  stage_kernel_note_reset();
   const bool whole = tile_begin == 0 && tile_count == plan->ntiles;
   const int  np_total = plan->n_patch_tiles[0] + plan->n_patch_tiles[1] + plan->n_patch_tiles[2];
   if (np_total == 0) return plain_generic_stage<T, V>(kind, stage, plan, tile_begin, tile_count, prev, mid, out, volume, dt, speed, whole, stream);

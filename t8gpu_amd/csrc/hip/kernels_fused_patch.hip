@@ -30,6 +30,7 @@
 
 #include "fused_common.hpp"
 #include "fused_tile_body.hpp"
+#include "stage_kernel_note.hpp"
 
 namespace t8gpu_hip {
 
@@ -346,6 +347,8 @@ int plain_patch_stage(int kind, int stage, const T8gpuPlainPlan* plan, int patch
   const int  resident  = cus * per_cu;
   const int  patch_wgs = (!persistent || patch_count < resident) ? patch_count : resident;
   const dim3 grid(patch_wgs + (tile_count > 0 ? tile_count : 0)), block(256);
+  note_stage_kernel(patch_count + (tile_count > 0 ? tile_count : 0), tile_count > 0 ? "k_plain_stage<T, K, S>" : "k_plain_patch<T, K, S>",
+                    static_cast<int>(sizeof(T)), kind, stage);
 #define T8_PA(K, S)                                                                                                               \
   do {                                                                                                                            \
     if (tile_count > 0)                                                                                                           \

@@ -28,6 +28,7 @@
 #include <cstdlib>
 
 #include "fused_common.hpp"
+#include "stage_kernel_note.hpp"
 
 namespace t8gpu_hip {
 
@@ -336,9 +337,11 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_persisten
   }
 }
 
+// Does the persistent kernel take a launch of `tile_count` tiles of this plan? (One definition for the launcher below and
+// for t8gpu_hip_plain_persistent_accepts, which the host-side tile-cap heuristics ask -- ADVICE r2: they used to repeat a
+// part of this test.) On success *lds = dynamic LDS bytes, *resident = workgroups that fill the chip.
 template <class T>
-int plain_persistent_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count, FVars<T> prev,
-                           FVars<T> mid, FVars<T> out, const T* volume, T dt, T* speed, hipStream_t stream) {
+bool plain_persistent_accepts(int kind, const T8gpuPlainPlan* plan, int tile_count, size_t* lds_out, int* resident_out) {
   static const bool off = std::getenv("T8GPU_PERSISTENT") && std::getenv("T8GPU_PERSISTENT")[0] == '0';
   const int slots = plan->max_slots;
   // what this kernel takes: the compressed plan with a geometry dictionary small enough for LDS, ELL rows of 8, 16 or 24
@@ -346,24 +349,26 @@ int plain_persistent_stage(int kind, int stage, const T8gpuPlainPlan* plan, int 
   // faces), tiles of <= 256 elements, <= 512 own + halo slots and <= 512 faces
   if (off || !plan->tile_desc || !plan->ell || (plan->ell_width != 8 && plan->ell_width != 16 && plan->ell_width != 24) || !plan->geo_idx || !plan->geo_table || plan->n_geo <= 0 || plan->n_geo > 128 ||
       plan->max_elems > 256 || slots <= 0 || slots > 512 || plan->max_faces > 512)
-    return -1;
+    return false;
   const int    nw  = kind == 0 ? kPrimWords : 5;
   const int    rec = sizeof(T) == 8 ? (nw > 5 ? 10 : 6) : 12;
   const size_t lds = sizeof(T) * (static_cast<size_t>(5) * 512 + static_cast<size_t>(12) * plan->n_geo + static_cast<size_t>(rec) * slots) +
                      ((sizeof(T) == 8 && kind == 0) ? 2 * kLogTabEntries * sizeof(double) : 0);
-  if (lds > 64 * 1024) return -1;
+  if (lds > 64 * 1024) return false;
   // fp64: the kernel lives on three workgroups per CU. 3 x 53.1 KB (a 3D tile of 376 slots) is nominally inside the 160 KB
   // and yet only two become resident (c5 on 512-face tiles: 3 950 against 4 110 M/s for the one-tile kernel); with a margin
   // the third fits (480-face tiles, 51.7 KB: 4 770). Plans above the margin go to the one-tile kernel.
-  if (sizeof(T) == 8 && 3 * lds > static_cast<size_t>(156) * 1024) return -1;
+  if (sizeof(T) == 8 && 3 * lds > static_cast<size_t>(156) * 1024) return false;
   // persistent grid: enough workgroups to fill the chip at the occupancy the kernel reaches, never more than there are
   // tiles. T8GPU_PERSISTENT_WGS overrides the per-CU count (tuning).
   static int per_cu_env = 0, cus = 0;
   if (cus == 0) {
     int            dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
-    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+    else
+      cus = 256;   // (no device: the build container asking through the C-ABI; MI355X has 256 CUs)
     const char* env = std::getenv("T8GPU_PERSISTENT_WGS");
     per_cu_env = env ? std::atoi(env) : 0;
     if (per_cu_env < 0 || per_cu_env > 8) per_cu_env = 0;
@@ -376,9 +381,22 @@ int plain_persistent_stage(int kind, int stage, const T8gpuPlainPlan* plan, int 
   // 0.047 vs 0.044 ms per stage, so those launches go back to the one-tile kernel.
   // (fp64 KEPES: small launches too -- there the one-tile kernel has its denser register budget: c1 2 270 -> 2 400 M/s)
   const int resident = cus * per_cu;
-  if (per_cu_env == 0 && tile_count < 8 * resident && (tile_count > resident || (kind == 0 && sizeof(T) == 8))) return -1;
+  if (per_cu_env == 0 && tile_count < 8 * resident && (tile_count > resident || (kind == 0 && sizeof(T) == 8))) return false;
+  if (lds_out) *lds_out = lds;
+  if (resident_out) *resident_out = resident;
+  return true;
+}
+
+template <class T>
+int plain_persistent_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count, FVars<T> prev,
+                           FVars<T> mid, FVars<T> out, const T* volume, T dt, T* speed, hipStream_t stream) {
+  size_t lds      = 0;
+  int    resident = 0;
+  if (!plain_persistent_accepts<T>(kind, plan, tile_count, &lds, &resident)) return -1;
   const int  grid_size = tile_count < resident ? tile_count : resident;
   const dim3 grid(grid_size), block(256);
+  note_stage_kernel(tile_count, plan->ell_width == 8 ? "k_plain_persistent<T, K, S, 1>" : "k_plain_persistent<T, K, S, 3>", static_cast<int>(sizeof(T)), kind,
+                    stage);
 #define T8_PE(K, S, C) hipLaunchKernelGGL((k_plain_persistent<T, K, S, C>), grid, block, lds, stream, *plan, tile_begin, tile_count, prev, mid, out, volume, dt, speed)
 #define T8_P(K, S)          \
   do {                      \
@@ -414,3 +432,9 @@ template int plain_persistent_stage<double>(int, int, const T8gpuPlainPlan*, int
                                             const double*, double, double*, hipStream_t);
 
 }  // namespace t8gpu_hip
+
+extern "C" int t8gpu_hip_plain_persistent_accepts(const T8gpuPlainPlan* plan, int flux_kind, int float_size, int tile_count) {
+  if (!plan || flux_kind < 0 || flux_kind > 2 || (float_size != 4 && float_size != 8) || tile_count < 0) return 0;
+  return float_size == 8 ? (t8gpu_hip::plain_persistent_accepts<double>(flux_kind, plan, tile_count, nullptr, nullptr) ? 1 : 0)
+                         : (t8gpu_hip::plain_persistent_accepts<float>(flux_kind, plan, tile_count, nullptr, nullptr) ? 1 : 0);
+}

@@ -36,6 +36,7 @@
 #include <cstdlib>
 
 #include "flux_math.hpp"
+#include "stage_kernel_note.hpp"
 #include "t8gpu_hip.h"
 
 namespace t8gpu_hip {
@@ -818,6 +819,7 @@ int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, int b
     return static_cast<int>(hipErrorInvalidValue);
   if (block_begin < 0 || block_count < 0 || block_begin + block_count > plan->num_elements) return static_cast<int>(hipErrorInvalidValue);
   if (block_count == 0) return 0;
+  stage_kernel_note_reset();
   hipStream_t s = static_cast<hipStream_t>(stream);
   // fp32 requests the previous-step state up front (one round trip less per wavefront); fp64 keeps fetching it last:
   // it is bound by DP instruction issue and the 10 extra registers would cost it a wavefront per SIMD (measured both ways).
@@ -829,6 +831,11 @@ int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, int b
   // one launch of the block kernel over records `pl.block_rec[begin, begin + count)`
   auto blocks = [&](const T8gpuSubgridPlan& pl, int begin, int count) {
     const dim3 grid(pl.rank == 3 ? count : (count + 3) / 4), block(64);
+    {
+      char pat[96];
+      std::snprintf(pat, sizeof(pat), "k_subgrid_fused<T, K, S, %d, %s, %s>", pl.rank == 3 ? 3 : 2, early ? "true" : "false", wide ? "true" : "false");
+      note_stage_kernel(count, pat, static_cast<int>(sizeof(T)), kind, stage);
+    }
 #define T8_SG(K, S, R)                                                                                                     \
   do {                                                                                                                     \
     if (wide)                                                                                                              \
@@ -885,6 +892,11 @@ int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, int b
   // per square, four leftover blocks per wavefront
   const int  restb = plan->rank == 3 ? (sizeof(T) == 8 ? 4 : 8) : 4;   // (k_subgrid_family: RESTB)
   const dim3 grid(plan->n_families + (n_rest_here + restb - 1) / restb), block(plan->rank == 3 ? 512 : 64);
+  {
+    char pat[96];
+    std::snprintf(pat, sizeof(pat), "%s<T, K, S, %s>", plan->rank == 3 ? "k_subgrid_family" : "k_subgrid_family2", wide ? "true" : "false");
+    note_stage_kernel(block_count, pat, static_cast<int>(sizeof(T)), kind, stage);
+  }
 #define T8_FM(K, S)                                                                                                          \
   do {                                                                                                                       \
     if (plan->rank == 3 && wide)                                                                                             \

@@ -55,11 +55,17 @@ struct Stepper {
   int             graph_mode = 0;       // 0 off, 1 on
   hipStream_t     graph_stream = nullptr;
   hipEvent_t      ev_graph_in = nullptr, ev_graph_out = nullptr;
-  hipGraphExec_t  graph_exec = nullptr;
-  unsigned char   graph_key[96] = {0};
+  struct GraphEntry {               // one executable per argument set; a step loop alternates between two (the roles of
+    hipGraphExec_t exec = nullptr;  // prev / next swap with every odd n_steps), so the cache holds a few
+    unsigned char  key[96] = {0};
+    unsigned long  used = 0;
+  };
+  GraphEntry      graph_cache[4];
+  unsigned long   graph_clock = 0;
   int             graph_captures = 0, graph_replays = 0;
   bool            capturing = false;    // iterate() is being recorded into a graph
-  int             capture_variant = 0;  // diagnostics (T8GPU_GRAPH_VARIANT): 1 = node before the fork, 2 = + global capture mode
+  int             capture_variant = 0;  // diagnostics (T8GPU_GRAPH_VARIANT): 1 = node before the fork, 2 = global capture mode, 3 = thread-local
+                                        // capture mode, 4 = exchange + ghost-reading tiles on the capture's origin stream
   void*           scratch = nullptr;
   std::vector<hipEvent_t> capture_events;   // one event per (stage, role) of a captured call (see stage_event)
 };
@@ -103,11 +109,12 @@ int exchange(const T8gpuHalo& h, const int32_t* peers, const int32_t* send_off, 
   } else {
     T8_TRY(t8gpu_hip_halo_pack_f64(h.n_send, cells, h.send_idx, state, sb, s));
   }
-  // diagnostic only (tests/test_gpu_graph.py): leave the RCCL group out, to tell a capture that fails because of RCCL
-  // from one that fails because of the three-stream fork / join (the ghosts are then stale: results are wrong)
-  static const bool no_rccl = std::getenv("T8GPU_DEBUG_NO_RCCL") != nullptr;
+  // T8GPU_EXP_NO_RCCL: experiment builds only (build.py variants, tests/test_gpu_graph.py): the RCCL group is left out, to
+  // tell a capture that fails because of RCCL from one that fails because of the three-stream fork / join. The ghosts are
+  // then stale and the results wrong, so the product library has no run-time switch for it.
   ncclComm_t comm = static_cast<ncclComm_t>(h.comm);
-  if (!no_rccl) {
+#ifndef T8GPU_EXP_NO_RCCL
+  {
   T8_TRY(nccl_code(ncclGroupStart()));
   for (int j = 0; j < h.n_peers; j++) {
     const size_t w  = 5 * static_cast<size_t>(cells);   // values per element on the wire
@@ -118,6 +125,10 @@ int exchange(const T8gpuHalo& h, const int32_t* peers, const int32_t* send_off, 
   }
   T8_TRY(nccl_code(ncclGroupEnd()));
   }
+#else
+  (void)comm;
+  (void)peers; (void)send_off; (void)recv_off; (void)rb;
+#endif
   if constexpr (sizeof(T) == 4) {
     T8_TRY(t8gpu_hip_halo_unpack_f32(h.num_ghosts, h.num_elements, cells, rb, state, s));
   } else {
@@ -238,10 +249,13 @@ int iterate(Stepper* S, int kind, T* planes, size_t stride, const T* vol, int pr
     }
     T8_TRY(launch(0, nd, s));                                              // C_g
     T8_HIP_TRY(hipEventRecord(deep_c, s));
-    T8_TRY((exchange<T, V>(S->halo, S->peers.data(), S->send_off.data(), S->recv_off.data(), sv, S->comm_stream)));
+    // (capture diagnostics, T8GPU_GRAPH_VARIANT=4: the exchange and the ghost-reading tiles on the ORIGIN stream of the
+    //  capture instead of a forked one -- one of the variants tried against the RCCL-in-capture crash)
+    const hipStream_t xs = (S->capturing && S->capture_variant == 4) ? s : S->comm_stream;
+    T8_TRY((exchange<T, V>(S->halo, S->peers.data(), S->send_off.data(), S->recv_off.data(), sv, xs)));
     if (g > 0 && !S->capturing) T8_HIP_TRY(hipStreamWaitEvent(S->comm_stream, inter_p, 0));   // A_g <- B_(g-1)
-    T8_TRY(launch(ni, nt - ni, S->comm_stream));                           // A_g
-    T8_HIP_TRY(hipEventRecord(ghost_c, S->comm_stream));
+    T8_TRY(launch(ni, nt - ni, xs));                                       // A_g
+    T8_HIP_TRY(hipEventRecord(ghost_c, xs));
     T8_TRY(launch(nd, ni - nd, S->near_stream));                           // B_g
     T8_HIP_TRY(hipEventRecord(inter_c, S->near_stream));
     last_ghost = ghost_c;
@@ -263,22 +277,35 @@ template <class T, class V>
 int iterate_graph(Stepper* S, int kind, T* planes, size_t stride, const T* vol, int prev, int next, T dt, T* speed, int n_steps,
                   hipStream_t s) {
   if (!S->graph_mode || S->timing > 0 || n_steps <= 0) return iterate<T, V>(S, kind, planes, stride, vol, prev, next, dt, speed, n_steps, s);
+  // Multi-rank stages have an RCCL group in the middle, and a capture that contains one ends in a segmentation fault inside
+  // hipStreamEndCapture on this stack (HIP 7.0 / RCCL 2.26 of the torch wheel; tests/test_gpu_graph.py):
+  // with a halo the driver keeps the direct enqueue. T8GPU_GRAPH_RCCL=1 opts in to the capture (diagnostics only).
+  static const bool rccl_capture = std::getenv("T8GPU_GRAPH_RCCL") && std::getenv("T8GPU_GRAPH_RCCL")[0] == '1';
+  if (S->has_halo && S->halo.n_peers > 0 && !rccl_capture) return iterate<T, V>(S, kind, planes, stride, vol, prev, next, dt, speed, n_steps, s);
   struct Key {
     int kind, prev, next, n_steps, tsize, subgrid;
     const void *planes, *vol, *speed;
     size_t stride;
     double dt;
   } key{kind, prev, next, n_steps, static_cast<int>(sizeof(T)), S->subgrid ? 1 : 0, planes, vol, speed, stride, static_cast<double>(dt)};
-  static_assert(sizeof(Key) <= sizeof(S->graph_key), "graph key");
+  static_assert(sizeof(Key) <= sizeof(S->graph_cache[0].key), "graph key");
   if (!S->graph_stream) {
     T8_HIP_TRY(hipStreamCreateWithFlags(&S->graph_stream, hipStreamNonBlocking));
     T8_HIP_TRY(hipEventCreateWithFlags(&S->ev_graph_in, hipEventDisableTiming));
     T8_HIP_TRY(hipEventCreateWithFlags(&S->ev_graph_out, hipEventDisableTiming));
   }
-  if (!S->graph_exec || std::memcmp(&key, S->graph_key, sizeof(Key)) != 0) {
-    if (S->graph_exec) {
-      (void)hipGraphExecDestroy(S->graph_exec);
-      S->graph_exec = nullptr;
+  // look the argument set up; on a miss the least recently used entry is replaced. (delta_t is part of the key: a
+  // CFL-adaptive step size re-captures per value -- use the direct enqueue for such loops.)
+  Stepper::GraphEntry* hit = nullptr;
+  Stepper::GraphEntry* lru = &S->graph_cache[0];
+  for (auto& ge : S->graph_cache) {
+    if (ge.exec && std::memcmp(&key, ge.key, sizeof(Key)) == 0) hit = &ge;
+    if (!ge.exec || (lru->exec && ge.used < lru->used)) lru = &ge;
+  }
+  if (!hit) {
+    if (lru->exec) {
+      (void)hipGraphExecDestroy(lru->exec);
+      lru->exec = nullptr;
     }
     hipGraph_t g = nullptr;
     static const bool trace = std::getenv("T8GPU_DEBUG_GRAPH") != nullptr;   // progress marks on stderr (diagnostics)
@@ -287,13 +314,18 @@ int iterate_graph(Stepper* S, int kind, T* planes, size_t stride, const T* vol, 
     S->capture_variant = std::getenv("T8GPU_GRAPH_VARIANT") ? std::atoi(std::getenv("T8GPU_GRAPH_VARIANT")) : 0;
     if (!S->scratch) T8_HIP_TRY(hipMalloc(&S->scratch, 64));
     {   // every event a capture of this length needs exists before the capture starts
-      S->capturing = true;
+      struct Capturing {   // (reset on every way out of this block, early error returns included)
+        Stepper* s;
+        explicit Capturing(Stepper* p) : s(p) { s->capturing = true; }
+        ~Capturing() { s->capturing = false; }
+      } guard(S);
       hipEvent_t e;
       for (int g2 = 0; g2 < 3 * n_steps; g2++)
         for (int r = 0; r < 4; r++) T8_TRY(stage_event(S, g2, static_cast<EventRole>(r), &e));
-      S->capturing = false;
     }
-    T8_HIP_TRY(hipStreamBeginCapture(S->graph_stream, S->capture_variant >= 2 ? hipStreamCaptureModeGlobal : hipStreamCaptureModeRelaxed));
+    const hipStreamCaptureMode cmode = S->capture_variant == 2 ? hipStreamCaptureModeGlobal
+                                                                : (S->capture_variant == 3 ? hipStreamCaptureModeThreadLocal : hipStreamCaptureModeRelaxed);
+    T8_HIP_TRY(hipStreamBeginCapture(S->graph_stream, cmode));
     S->capturing  = true;
     const int  rc = iterate<T, V>(S, kind, planes, stride, vol, prev, next, dt, speed, n_steps, S->graph_stream);
     S->capturing  = false;
@@ -304,20 +336,22 @@ int iterate_graph(Stepper* S, int kind, T* planes, size_t stride, const T* vol, 
       if (g) (void)hipGraphDestroy(g);
       return rc != 0 ? rc : static_cast<int>(e != hipSuccess ? e : hipErrorStreamCaptureInvalidated);
     }
-    e = hipGraphInstantiate(&S->graph_exec, g, nullptr, nullptr, 0);
+    e = hipGraphInstantiate(&lru->exec, g, nullptr, nullptr, 0);
     T8_MARK("instantiated");
     (void)hipGraphDestroy(g);
     if (e != hipSuccess) {
-      S->graph_exec = nullptr;
+      lru->exec = nullptr;
       return static_cast<int>(e);
     }
-    std::memset(S->graph_key, 0, sizeof(S->graph_key));
-    std::memcpy(S->graph_key, &key, sizeof(Key));
+    std::memset(lru->key, 0, sizeof(lru->key));
+    std::memcpy(lru->key, &key, sizeof(Key));
     S->graph_captures++;
+    hit = lru;
   }
+  hit->used = ++S->graph_clock;
   T8_HIP_TRY(hipEventRecord(S->ev_graph_in, s));                         // the graph starts behind the caller's work ...
   T8_HIP_TRY(hipStreamWaitEvent(S->graph_stream, S->ev_graph_in, 0));
-  T8_HIP_TRY(hipGraphLaunch(S->graph_exec, S->graph_stream));
+  T8_HIP_TRY(hipGraphLaunch(hit->exec, S->graph_stream));
   if (std::getenv("T8GPU_DEBUG_GRAPH")) { std::fprintf(stderr, "[t8gpu graph] launched\n"); std::fflush(stderr); }
   T8_HIP_TRY(hipEventRecord(S->ev_graph_out, S->graph_stream));
   T8_HIP_TRY(hipStreamWaitEvent(s, S->ev_graph_out, 0));                 // ... and the caller's stream continues behind it
@@ -446,7 +480,8 @@ int t8gpu_hip_plain_stepper_destroy(void* h) {
   if (S->ev_deep) (void)hipEventDestroy(S->ev_deep);
   if (S->comm_stream) (void)hipStreamDestroy(S->comm_stream);
   if (S->near_stream) (void)hipStreamDestroy(S->near_stream);
-  if (S->graph_exec) (void)hipGraphExecDestroy(S->graph_exec);
+  for (auto& ge : S->graph_cache)
+    if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
   for (hipEvent_t e : S->capture_events) (void)hipEventDestroy(e);
   if (S->scratch) (void)hipFree(S->scratch);
   if (S->ev_graph_in) (void)hipEventDestroy(S->ev_graph_in);

@@ -17,7 +17,7 @@ class T8gpuPlainPlan(C.Structure):
 
 
 class PlainPlan:
-    def __init__(self, part, dtype, tmax=None, fcap=None, compressed=True, dictionary=True, patches=None):
+    def __init__(self, part, dtype, tmax=None, fcap=None, compressed=True, dictionary=True, patches=None, flux_kind=None):
         """compressed=False: generic kernel (CSR lists, full geometry). dictionary=False: pipelined kernel
         with per-face geometry rows even where the mesh has few distinct ones (what curved meshes get anyway).
         patches: cut structured 16 x 16 patches out of the tiling for the patch kernel (default: yes for the compressed
@@ -63,9 +63,11 @@ class PlainPlan:
         # the per-face geometry rows are only read by the kernels without a dictionary (generic kernel, dictionary=False)
         self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary), patches=self.patches)
         if retry_768:
-            h = self.host   # does the persistent kernel take this plan (kernels_fused_persistent.hip: its launcher's test)?
-            lds = 8 * (5 * 512 + 12 * h.geo_table.shape[0] + 10 * h.max_slots) + 2048
-            if not (compressed and dictionary and 0 < h.geo_table.shape[0] <= 128 and h.ell_width <= 24 and 3 * lds <= 156 * 1024):
+            # 480-face tiles only pay if the persistent kernel takes the plan: the LAUNCHER'S OWN test is asked (C-ABI query;
+            # it covers the LDS margin, the tile-count gate for mid-size meshes, the flux kind and T8GPU_PERSISTENT=0 --
+            # a partial copy of that test used to live here). Otherwise the one-tile kernel runs, which does
+            # better on 768-face tiles.
+            if not (compressed and dictionary and self._persistent_accepts(self.host, dtype, flux_kind)):
                 fcap = self.auto_fcap = 768
                 self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary), patches=self.patches)
         self.dtype = dtype
@@ -108,6 +110,23 @@ class PlainPlan:
         for k in range(3):
             c.n_patch_tiles[k] = self.host.n_patch_class[k]
         self.c = c
+
+    @staticmethod
+    def _persistent_accepts(h, dtype, flux_kind=None):
+        """Would a whole-plan launch of host plan `h` run the persistent tile kernel? (t8gpu_hip_plain_persistent_accepts:
+        the launcher's decision; only integer fields and the presence of the compressed arrays matter, so it can be asked
+        before anything is uploaded -- and without a GPU.)"""
+        c = T8gpuPlainPlan()
+        one = C.c_void_p(1)                                     # "present": never dereferenced by the query
+        c.tile_desc, c.ell = one, one
+        if h.geo_table.shape[0] > 0:
+            c.geo_idx, c.geo_table = one, one
+        c.n_geo, c.ell_width = h.geo_table.shape[0], h.ell_width
+        c.ntiles, c.max_elems, c.max_halo, c.max_faces, c.max_slots = h.ntiles, h.max_elems, h.max_halo, h.max_faces, h.max_slots
+        fn = hip.lib().t8gpu_hip_plain_persistent_accepts
+        fn.restype = C.c_int
+        n_generic = h.ntiles - h.n_patches
+        return bool(fn(C.byref(c), int(hip.KEPES if flux_kind is None else flux_kind), 4 if dtype == torch.float32 else 8, int(n_generic)))
 
     @staticmethod
     def _wide_rows(part):

@@ -67,7 +67,7 @@ class PlainSolver:
         self.plan = None
         if mode == "fused":
             from . import fused
-            self.plan = fused.PlainPlan(part, dtype, **(plan_options or {}))
+            self.plan = fused.PlainPlan(part, dtype, **dict(dict(flux_kind=flux_kind), **(plan_options or {})))
         elif mode != "compat":
             raise ValueError(mode)
 

@@ -9,16 +9,19 @@ script -- tests read the committed .npz). What it does, exactly as SURVEY.md sec
     compute_total_kepes_flux, compute_total_hll_flux) into a TEMPORARY directory -- nothing of the reference is
     written into this repository, only the numbers it produces;
   * compiles them for the host with `g++ -std=c++17 -O0 -ffp-contract=off` behind three empty macros
-    (__device__, __host__, __global__), `using std::{min,max,abs,sqrt,log}` and a 5-line stand-in for
-    t8gpu::variable_traits + the VariableList enum (the fragment's only outside dependencies), once with
-    float_type = float and once with double;
+    (__device__, __host__, __global__), `using std::{min,max,abs,sqrt,log}`, the VariableList enum of the examples and
+    THE REFERENCE'S OWN t8gpu::variable_traits (t8gpu/memory/memory_manager.h:24-33, also only into the temporary directory;
+    round 2 used a stand-in for it). The reference's trait says `float_type = float` and nothing else: the fp32 build
+    takes it verbatim, the fp64 build with that one token replaced by `double` -- the reference has no fp64 configuration of
+    its own (SURVEY F2), so this is the smallest possible edit;
   * feeds it seeded state pairs: generic (rho in [0.5,2], v in [-1,1]^3, p in [0.5,5]), near-equal pairs
     (the u < 1e-4 series branch of ln_mean), strong jumps (pressure / density ratios up to 1e3), supersonic pairs,
     and for the xyz pipeline axis-aligned and oblique unit normals, interior faces and reflective walls;
   * stores inputs and outputs as arrays.
 
-Because the build uses a stand-in for variable_traits this does not count as a reference build under the project
-rules (parity stays "unpinned"); it is the strongest evidence available, and
+Because the fragment is compiled behind three CUDA-qualifier macros outside the reference's own build this does not count
+as a reference build under the project rules (parity stays "unpinned"); it is the strongest evidence
+available, and
 tests/test_oracle_golden.py demands BIT-EXACT agreement of the oracle with every vector.
 
 Also records whether examples/compressible_euler/kernels.cu:24-133 (the plain example's copy of ln_mean /
@@ -46,8 +49,12 @@ DRIVER = r"""
 #define __host__
 #define __global__
 using std::abs; using std::log; using std::max; using std::min; using std::sqrt;
-enum VariableList { Rho, Rho_v1, Rho_v2, Rho_v3, Rho_e, nb_variables };
-namespace t8gpu { template<typename V> struct variable_traits { using float_type = FT; }; }
+#include <cstddef>
+#include <type_traits>
+enum VariableList { Rho, Rho_v1, Rho_v2, Rho_v3, Rho_e, nb_variables };   // examples/compressible_euler/solver.h:14-21
+namespace t8gpu {
+#include "ref_traits.inl"   // t8gpu/memory/memory_manager.h:24-33, the reference's variable_traits
+}
 #include "ref_math.inl"
 template<class T> static std::vector<T> rd(const char* path) {
   FILE* f = std::fopen(path, "rb"); if (!f) std::exit(2);
@@ -167,11 +174,19 @@ def main():
     b = a * np.where(rng.random(n_lm) < 0.5, 1 + 10.0 ** rng.uniform(-14, -1, n_lm) * rng.choice([-1, 1], n_lm), 10.0 ** rng.uniform(-3, 3, n_lm))
     b[:64] = a[:64]
     out = {"lm_a": a, "lm_b": b, "ff_L": L, "ff_R": R, "xyz_n": N, "xyz_L": XL, "xyz_R": XR}
+    mm = open(os.path.join(REF, "t8gpu/memory/memory_manager.h")).read().split("\n")
+    traits = mm[23:33]                                   # lines 24-33: variable_traits and its enum specialisation
+    assert traits[0].strip().startswith("template<class VariableList") and "float_type" in traits[5], traits
     with tempfile.TemporaryDirectory(prefix="t8gpu_refvec_") as tmp:
         open(os.path.join(tmp, "ref_math.inl"), "w").write("\n".join(math_lines) + "\n")
         open(os.path.join(tmp, "driver.cpp"), "w").write(DRIVER)
         res = {}
         for ft, npdt, tag in (("double", np.float64, "f64"), ("float", np.float32, "f32")):
+            text = "\n".join(traits) + "\n"
+            if ft == "double":                           # the one token the fp64 build changes (see the docstring)
+                assert text.count("= float;") == 1
+                text = text.replace("= float;", "= double;")
+            open(os.path.join(tmp, "ref_traits.inl"), "w").write(text)
             exe = os.path.join(tmp, "drv_" + tag)
             subprocess.check_call(["g++", "-std=c++17", "-O0", "-ffp-contract=off", f"-DFT={ft}", "-I", tmp,
                                    os.path.join(tmp, "driver.cpp"), "-o", exe])
@@ -188,7 +203,8 @@ def main():
                 res[f"{k}_{tag}"] = np.ascontiguousarray(v, npdt)
     res["meta"] = np.array([
         "reference: /root/reference/examples/subgrid/kernels.inl lines 1-332, host build g++ -std=c++17 -O0 -ffp-contract=off, "
-        "stand-in for t8gpu::variable_traits (parity stays 'unpinned', DESIGN.md section 2); seed 20261004; "
+        "the reference's own t8gpu::variable_traits (memory_manager.h:24-33; fp64: its `float` replaced by `double`), three empty "
+        "CUDA-qualifier macros (parity stays 'unpinned', DESIGN.md section 2); seed 20261004; "
         f"kernels.cu:24-133 identical to kernels.inl:21-130 modulo whitespace: {duplicate}"])
     path = os.path.join(HERE, "reference_flux_vectors.npz")
     np.savez_compressed(path, **res)

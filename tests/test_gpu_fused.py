@@ -162,6 +162,32 @@ def test_c4_full_size_properties():
     assert torch.equal(b.state(), first)                             # native driver == python driver, run-to-run identical
 
 
+def test_c5_full_size_properties():
+    """BASELINE config 5's family at size -- 3D hexahedral AMR forest, levels 6-8, 3.93 M elements, 6-24 faces per element,
+    fp64 (the mesh `bench.py --workload c5` times): run-to-run bitwise identical, conservative on the periodic domain,
+    finite, and the fused tier equals the reference data flow (compat tier: face kernel + atomics + RK kernel,
+    examples/compressible_euler/kernels.cu:135-309) within the fp64 parity tolerance."""
+    mesh = SynthMesh(3, 6, 8, band=0.05)
+    part = mesh.partition()
+    assert part.N == 3932160
+    a = PlainSolver(part, torch.float64, mode="fused")
+    b = PlainSolver(part, torch.float64, mode="fused")
+    c = PlainSolver(part, torch.float64, mode="compat")
+    a.use_native_stepper()
+    m0 = [a.compute_integral(k) for k in range(5)]
+    dt = 0.1 * 2.0 ** -8
+    a.iterate_steps(3, dt)
+    for _ in range(3):
+        b.iterate(dt)
+        c.iterate(dt)
+    torch.cuda.synchronize()
+    m1 = [a.compute_integral(k) for k in range(5)]
+    assert bool(torch.isfinite(a.state()).all())
+    assert torch.equal(a.state(), b.state()) and torch.equal(a.speed, b.speed)      # native driver == python driver, bitwise
+    assert max(abs(x - y) for x, y in zip(m0, m1)) < 1e-12 * max(abs(x) for x in m0)
+    assert rel_err(a.state().cpu().numpy(), c.state().cpu().numpy()) < 1e-12
+
+
 def test_lds_scatter_add_variant_matches_the_oracle():
     """T8GPU_LDS_SCATTER=1: the accumulation the project brief sketches (ds_add_f64 into per-element LDS
     accumulators instead of the ELL gather). Not bitwise reproducible by construction, so it is checked against
@@ -277,7 +303,9 @@ for dim, args in ((2, dict(base_level=4, max_level=7, band=0.05)), (2, dict(base
     part = mesh.partition()
     for dtype in (torch.float32, torch.float64):
         for kind in (hip.KEPES, hip.HLL):
-            g = PlainSolver(part, dtype, flux_kind=kind, mode="fused", state=perturbed_state(part, 5))
+            # (patches=False: every tile is a generic tile, i.e. the persistent tile kernel's -- the 2D meshes would
+            #  otherwise go through the patch kernel, tests/test_gpu_patch.py)
+            g = PlainSolver(part, dtype, flux_kind=kind, mode="fused", state=perturbed_state(part, 5), plan_options=dict(patches=False))
             for _ in range(3):
                 g.iterate(0.1 * 2.0 ** -(mesh.finest_level + 2))
             out.append(g.state().double().cpu().numpy().ravel())
@@ -305,3 +333,58 @@ def test_persistent_and_one_tile_kernels_agree_bitwise(tmp_path):
         res.append(np.load(out))
     assert np.isfinite(res[0]).all()
     assert np.array_equal(res[0], res[1]), int((res[0] != res[1]).sum())
+
+
+_PERSISTENT_ORACLE_CHILD = """
+import ctypes, sys, numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import _oracle as O
+from _gpu import NP, TOL1, TOL10, perturbed_state, rel_err
+from t8gpu_amd import hip
+from t8gpu_amd.solver import PlainSolver
+from t8gpu_amd.synth import SynthMesh
+q = hip.lib().t8gpu_hip_last_stage_kernel
+q.restype = ctypes.c_char_p
+worst = 0.0
+for dim, args in ((2, dict(base_level=4, max_level=7, band=0.05)), (2, dict(base_level=4, max_level=6, band=0.05, periodic=False)),
+                  (3, dict(base_level=3, max_level=5, band=0.05)), (3, dict(base_level=2, max_level=4, band=0.08, periodic=False))):
+    mesh = SynthMesh(dim, **args)
+    part = mesh.partition()
+    st = perturbed_state(part, 23)
+    for dtype in (torch.float64, torch.float32):
+        for kind in (hip.KEPES, hip.HLL):
+            g = PlainSolver(part, dtype, flux_kind=kind, mode="fused", state=st, plan_options=dict(patches=False))
+            o = O.PlainCase(part, NP[dtype], state=st)
+            dt = 0.1 * 2.0 ** -mesh.finest_level
+            g.iterate(dt)
+            o.iterate(dt, kind=kind)
+            torch.cuda.synchronize()
+            assert q().decode().startswith("k_plain_persistent<"), q()          # the headline kernel of round 2, directly
+            e1 = rel_err(g.state().cpu().numpy(), o.current()[:, :part.N])
+            es = rel_err(g.speed.cpu().numpy()[None, :part.F + part.B], o.speed[None])
+            assert e1 < TOL1[dtype] and es < 10 * TOL1[dtype], (dim, args, dtype, kind, e1, es)
+            for _ in range(9):
+                g.iterate(dt)
+                o.iterate(dt, kind=kind)
+            e10 = rel_err(g.state().cpu().numpy(), o.current()[:, :part.N])
+            assert e10 < TOL10[dtype], (dim, args, dtype, kind, e10)
+            worst = max(worst, e1 / TOL1[dtype], e10 / TOL10[dtype])
+print("worst error / tolerance:", worst)
+"""
+
+
+def test_persistent_kernel_vs_oracle(tmp_path):
+    """The persistent tile kernel (T8GPU_PERSISTENT=2: every whole-plan launch, whatever the mesh size) against the CPU
+    oracle DIRECTLY -- 2D and 3D AMR meshes, periodic and walled, KEPES / HLL, both precisions, 1 and 10 steps, speed
+    estimates included -- not only through its bitwise agreement with the one-tile kernels.
+    Reference: examples/compressible_euler/kernels.cu:135-469, ssp_runge_kutta.inl:30-99."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    script = tmp_path / "child.py"
+    script.write_text(_PERSISTENT_ORACLE_CHILD.format(root=os.path.dirname(here), tests=here))
+    res = subprocess.run([sys.executable, str(script)], env=dict(os.environ, T8GPU_PERSISTENT="2", T8GPU_PERSISTENT_WGS="3"),
+                         capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "worst error / tolerance:" in res.stdout

@@ -162,3 +162,30 @@ def test_tet_hex_partitioned_run_equals_single_rank_bitwise():
                 s.run_stage(k, dt, split=True)
     torch.cuda.synchronize()
     assert torch.equal(torch.cat([s.state() for s in solvers], dim=1), ref.state())
+
+
+def test_c5t_full_size_properties():
+    """BASELINE config 5's mesh class at size: `bench.py --workload c5t` -- 4.13 M tetrahedra + hexahedra on a curved shell
+    sector (4 / 6-12 faces per element, every normal oblique, reflective walls all round), fp64. Size-independent
+    properties: run-to-run bitwise identical, mass and energy conserved between walls, finite, fused tier = reference data
+    flow (compat tier) within the fp64 tolerance. (The real t8code cmesh of examples/compressible_euler/main.cu:23 needs
+    t8code; this is its geometry-synthetic stand-in)"""
+    from t8gpu_amd.unstructured import TetHexMesh
+    part = TetHexMesh((96, 96, 128), tets="blocks").partition()
+    assert part.N == 4128768 and part.B > 0
+    a = PlainSolver(part, torch.float64, mode="fused")
+    b = PlainSolver(part, torch.float64, mode="fused")
+    c = PlainSolver(part, torch.float64, mode="compat")
+    a.use_native_stepper()
+    m0 = [a.compute_integral(k) for k in (0, 4)]
+    dt = 0.05 * float(part.volumes.min()) ** (1 / 3)
+    a.iterate_steps(3, dt)
+    for _ in range(3):
+        b.iterate(dt)
+        c.iterate(dt)
+    torch.cuda.synchronize()
+    m1 = [a.compute_integral(k) for k in (0, 4)]
+    assert bool(torch.isfinite(a.state()).all())
+    assert torch.equal(a.state(), b.state()) and torch.equal(a.speed, b.speed)
+    assert max(abs(x - y) / abs(x) for x, y in zip(m0, m1)) < 1e-12                  # reflective walls: no mass / energy flux
+    assert rel_err(a.state().cpu().numpy(), c.state().cpu().numpy()) < 1e-12

@@ -149,3 +149,23 @@ def test_tile_cap_heuristics_of_the_device_plan():
     assert PlainPlan._wide_rows(amr3) and not PlainPlan._many_geometries(amr3)
     assert not PlainPlan._wide_rows(uni3) and not PlainPlan._many_geometries(uni3)
     assert not PlainPlan._wide_rows(curved) and PlainPlan._many_geometries(curved)
+
+
+def test_tile_cap_heuristics_ask_the_launchers_own_test():
+    """fused.PlainPlan keeps 480-face tiles on a 3D AMR mesh only if the persistent tile kernel will take the plan, and asks
+    the launcher itself (t8gpu_hip_plain_persistent_accepts; no GPU needed): small launches (at most one tile per resident
+    workgroup) go to it except fp64 KEPES, MID-SIZE launches (fewer than 8 tiles per resident workgroup) never do, large ones
+    do (the Python copy of the test missed the tile-count gate and the flux kind)."""
+    import torch
+    from t8gpu_amd import hip
+    from t8gpu_amd.fused import PlainPlan
+    small = HostPlainPlan.from_partition(SynthMesh(3, 3, 5, band=0.05).partition(), tmax=256, fcap=480, want_face_geo=False)
+    mid = HostPlainPlan.from_partition(SynthMesh(3, 5, 7, band=0.05).partition(), tmax=256, fcap=480, want_face_geo=False)
+    large = HostPlainPlan.from_partition(SynthMesh(3, 6, 8, band=0.05).partition(), tmax=256, fcap=480, want_face_geo=False)
+    assert small.ntiles < 768 < mid.ntiles < 8 * 768 < large.ntiles
+    acc = PlainPlan._persistent_accepts
+    assert not acc(small, torch.float64, hip.KEPES) and acc(small, torch.float64, hip.HLL) and acc(small, torch.float32, hip.KEPES)
+    assert not acc(mid, torch.float64, hip.KEPES) and not acc(mid, torch.float64, hip.HLL) and not acc(mid, torch.float32, hip.KEPES)
+    assert acc(large, torch.float64, hip.KEPES) and acc(large, torch.float64, hip.HLL)
+    wide = HostPlainPlan.from_partition(SynthMesh(3, 6, 8, band=0.05).partition(), tmax=256, fcap=512, want_face_geo=False)
+    assert not acc(wide, torch.float64, hip.KEPES)          # 512-face 3D tiles: the third workgroup per CU does not fit
