@@ -254,14 +254,15 @@ int t8gpu_hip_plain_stepper_iterate_steps_f64(void* stepper, int flux_kind, doub
 /* optional HIP-event timing of the stage kernels (for roofline accounting): enable = 0 off, n > 0 = the stage
  * kernels of every n-th step of a call are bracketed by events (n > 1 keeps the host-side cost of the
  * events out of latency-bound multi-rank runs); elapsed() sums what has been recorded since. */
-/* hipGraph replay ("hipGraph capture of the 3-stage step"): enable = 1 -> an iterate_steps() call of a
- * SINGLE-RANK stepper is captured once per argument set (the four most recent sets are kept: a step loop alternates
- * between two) and replayed with ONE hipGraphLaunch afterwards; enable = 0 -> direct enqueue (default); enable < 0 ->
- * query only. counts (may be NULL) receives {captures, replays}. A capture the runtime refuses returns its error code.
- * delta_t is part of the argument set (a CFL-adaptive step size re-captures per value: use the direct enqueue there).
- * A stepper WITH a halo (n_peers > 0) always enqueues directly, whatever `enable` says: every stage has an RCCL group in
- * the middle, and a capture that contains one crashes inside hipStreamEndCapture on this stack (HIP 7.0 / RCCL 2.26 of
- * the torch wheel). T8GPU_GRAPH_RCCL=1 in the environment opts in to that capture (diagnostics). */
+/* hipGraph replay ("hipGraph capture of the 3-stage step"): enable = 1 -> an iterate_steps() call is captured
+ * once per argument set (the four most recent sets are kept: a step loop alternates between two) and replayed with ONE
+ * hipGraphLaunch afterwards; enable = 0 -> direct enqueue (default); enable < 0 -> query only. counts (may be NULL)
+ * receives {captures, replays}. A capture the runtime refuses returns its error code. delta_t is part of the argument set
+ * (a CFL-adaptive step size re-captures per value: use the direct enqueue there).
+ * With a halo the RCCL groups are captured too, on the ORIGIN stream of the capture (the deep tiles fork off instead): an
+ * RCCL group on a forked stream of a capture crashes hipStreamEndCapture on this stack (HIP 7.0.51831 / RCCL 2.26.6 of the
+ * torch wheel). Exercised on one GPU with a one-rank communicator exchanging with itself
+ * (tests/test_gpu_graph.py), never yet across xGMI. T8GPU_GRAPH_RCCL=0 keeps the direct enqueue for steppers with a halo. */
 int t8gpu_hip_plain_stepper_graph(void* stepper, int enable, int* counts);
 int t8gpu_hip_plain_stepper_timing(void* stepper, int enable);
 int t8gpu_hip_plain_stepper_elapsed(void* stepper, double* total_ms, int* launches);

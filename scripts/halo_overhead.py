@@ -7,7 +7,7 @@ grouped send/recv, unpack kernel, event, interior tiles || exchange, ghost-readi
 peer is mapped onto this rank itself (RCCL self send/recv, message sizes made symmetric). The payload does
 not cross xGMI, so (b) - (a) is the launch / synchronisation overhead of the overlap scheme, not link time;
 the ghost VALUES are meaningless here and the result of (b) is not checked.
-usage: halo_overhead.py [world=8] [rank=3] [steps=200]"""
+usage: halo_overhead.py [world=8] [rank=3] [steps=200] [one_gpu_ms_per_step=0.92]"""
 import sys
 import time
 import types
@@ -83,13 +83,22 @@ def main():
           f"{b.plan.host.n_deep} deep / {b.plan.host.n_interior - b.plan.host.n_deep} near-boundary / "
           f"{b.plan.host.ntiles - b.plan.host.n_interior} ghost-reading tiles)", flush=True)
     tc = timed(b, many=True)
-    print(f"(c) same, all steps in one call: {tc:.4f} ms/step -> {1.40 / tc:.2f}x projected; the host needs "
-          f"{timed.host_ms:.4f} ms to enqueue a step", flush=True)
+    print(f"(c) same, all steps in one call: {tc:.4f} ms/step; the host needs {timed.host_ms:.4f} ms to enqueue a step", flush=True)
+    # (d) the same call through a hipGraph: captured once (RCCL groups included, on the capture's origin stream), then ONE
+    # hipGraphLaunch per call -- the host cost of a step drops to the replay's
+    b.stepper.graph(True)
+    b.iterate_steps(steps, dt)                       # capture
+    torch.cuda.synchronize()
+    td = timed(b, many=True)
+    print(f"(d) same through a hipGraph replay: {td:.4f} ms/step; the host needs {timed.host_ms:.4f} ms per step; "
+          f"captures / replays = {b.stepper.graph()}", flush=True)
+    b.stepper.graph(False)
     print(f"overhead of the overlap scheme: {tb - ta:+.4f} ms/step = {(tb - ta) / 3 * 1e3:+.1f} us/stage; "
           f"8-way ideal would be {1.0:.2f}x of (a), this is {tb / ta:.3f}x", flush=True)
-    one = 1.40   # ms/step of the whole mesh on one GPU (bench.py c4)
+    one = float(sys.argv[4]) if len(sys.argv) > 4 else 0.92   # ms/step of the whole mesh on one GPU (bench.py c4, round 3)
     print(f"projected strong-scaling speedup at {world} ranks if every rank behaves like this one: "
-          f"{one / tb:.2f}x (no exchange: {one / ta:.2f}x)", flush=True)
+          f"{one / tb:.2f}x direct enqueue per step, {one / tc:.2f}x all steps in one call, {one / td:.2f}x graph replay "
+          f"(no exchange: {one / ta:.2f}x) -- a PROJECTION from one GPU: no byte crosses xGMI here", flush=True)
     comm.destroy()
 
 

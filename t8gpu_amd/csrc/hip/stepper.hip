@@ -64,8 +64,8 @@ struct Stepper {
   unsigned long   graph_clock = 0;
   int             graph_captures = 0, graph_replays = 0;
   bool            capturing = false;    // iterate() is being recorded into a graph
-  int             capture_variant = 0;  // diagnostics (T8GPU_GRAPH_VARIANT): 1 = node before the fork, 2 = global capture mode, 3 = thread-local
-                                        // capture mode, 4 = exchange + ghost-reading tiles on the capture's origin stream
+  int             capture_variant = 0;  // diagnostics (T8GPU_GRAPH_VARIANT): 2 = global capture mode, 3 = thread-local capture mode,
+                                        // 5 = exchange chain on a FORKED stream of the capture (the layout that crashes)
   void*           scratch = nullptr;
   std::vector<hipEvent_t> capture_events;   // one event per (stage, role) of a captured call (see stage_event)
 };
@@ -214,6 +214,16 @@ int iterate(Stepper* S, int kind, T* planes, size_t stride, const T* vol, int pr
       T8_TRY(launch(0, nt, s));
       continue;
     }
+    // Roles of the three streams. Direct enqueue: the caller's stream carries the deep tiles (the long launch), the comm
+    // stream the exchange chain. Inside a capture the ORIGIN stream of the capture must carry the exchange chain: an RCCL
+    // group issued on a FORKED stream of a capture ends in a segmentation fault inside hipStreamEndCapture on this stack
+    // (HIP 7.0.51831 / RCCL 2.26.6; relaxed, global and thread-local capture modes alike -- T8GPU_GRAPH_VARIANT=5 keeps
+    // that layout for the opt-in diagnostic of tests/test_gpu_graph.py), issued on the origin stream it is captured and
+    // replayed correctly. A graph only knows dependencies, so the replayed pipeline has the same shape either way.
+    const bool        swap = S->capturing && S->capture_variant != 5;
+    const hipStream_t sc = swap ? S->comm_stream : s;    // C_g: deep tiles
+    const hipStream_t sx = swap ? s : S->comm_stream;    // pack_g -> RCCL_g -> unpack_g -> A_g
+    const hipStream_t sb = S->near_stream;               // B_g
     if (g == 0) {  // entry: the other streams must see everything the caller queued on s
       if (S->capturing && S->scratch) T8_HIP_TRY(hipMemsetAsync(S->scratch, 0, 64, s));   // a first node for the fork event
       T8_HIP_TRY(hipEventRecord(S->ev_state, s));
@@ -230,35 +240,36 @@ int iterate(Stepper* S, int kind, T* planes, size_t stride, const T* vol, int pr
     T8_TRY(stage_event(S, g, kDeep, &deep_c));
     T8_TRY(stage_event(S, g, kGhost, &ghost_c));
     T8_TRY(stage_event(S, g, kInterior, &inter_c));
+    // (Measured and dropped in round 3: a TWO-class pipeline -- B and A tiles in one launch behind the unpack, 9 host calls
+    //  per stage instead of 13. The host cost fell from 170 to 146 us per step, but C_g then has to wait for the previous
+    //  stage's exchange chain and the step rose from 0.175 to 0.256 ms on rank 3 of the 8-way c4 split with an RCCL
+    //  self-exchange: the third class IS what keeps the long launch from waiting. profiles/r03_halo_overhead.md)
     if (g > 0 && S->capturing) {
-      // Inside a capture every dependency goes through the origin stream: it joins the two other streams' previous
-      // stage, records one event, and they fork from that (forked streams waiting on each other's events -- what the
-      // direct enqueue below does -- is one of the things tried against the capture crash of this stack, see
-      // iterate_graph). Costs one edge the pipeline does not need: C_g now also follows A_(g-1).
+      // Inside a capture every dependency goes through the origin stream: it joins the other streams' previous stage,
+      // records one event, and they fork from that (forked streams waiting on each other's events -- what the direct
+      // enqueue below does -- crashes the end of the capture as well, with or without RCCL in it). Costs edges the
+      // pipeline does not need: stage g starts when all of stage g-1 is done.
       hipEvent_t join;
       T8_TRY(stage_event(S, g, kJoin, &join));
       T8_HIP_TRY(hipStreamWaitEvent(s, inter_p, 0));
-      T8_HIP_TRY(hipStreamWaitEvent(s, ghost_p, 0));
+      T8_HIP_TRY(hipStreamWaitEvent(s, swap ? deep_p : ghost_p, 0));   // (the third class of g-1 ran on s itself)
       T8_HIP_TRY(hipEventRecord(join, s));
       T8_HIP_TRY(hipStreamWaitEvent(S->near_stream, join, 0));
       T8_HIP_TRY(hipStreamWaitEvent(S->comm_stream, join, 0));
     } else if (g > 0) {
-      T8_HIP_TRY(hipStreamWaitEvent(S->near_stream, deep_p, 0));           // B_g <- C_(g-1)
-      T8_HIP_TRY(hipStreamWaitEvent(S->near_stream, ghost_p, 0));          // B_g <- A_(g-1)
-      T8_HIP_TRY(hipStreamWaitEvent(s, inter_p, 0));                       // C_g <- B_(g-1)
+      T8_HIP_TRY(hipStreamWaitEvent(sb, deep_p, 0));                       // B_g <- C_(g-1)
+      T8_HIP_TRY(hipStreamWaitEvent(sb, ghost_p, 0));                      // B_g <- A_(g-1)
+      T8_HIP_TRY(hipStreamWaitEvent(sc, inter_p, 0));                      // C_g <- B_(g-1)
     }
-    T8_TRY(launch(0, nd, s));                                              // C_g
-    T8_HIP_TRY(hipEventRecord(deep_c, s));
-    // (capture diagnostics, T8GPU_GRAPH_VARIANT=4: the exchange and the ghost-reading tiles on the ORIGIN stream of the
-    //  capture instead of a forked one -- one of the variants tried against the RCCL-in-capture crash)
-    const hipStream_t xs = (S->capturing && S->capture_variant == 4) ? s : S->comm_stream;
-    T8_TRY((exchange<T, V>(S->halo, S->peers.data(), S->send_off.data(), S->recv_off.data(), sv, xs)));
-    if (g > 0 && !S->capturing) T8_HIP_TRY(hipStreamWaitEvent(S->comm_stream, inter_p, 0));   // A_g <- B_(g-1)
-    T8_TRY(launch(ni, nt - ni, xs));                                       // A_g
-    T8_HIP_TRY(hipEventRecord(ghost_c, xs));
-    T8_TRY(launch(nd, ni - nd, S->near_stream));                           // B_g
-    T8_HIP_TRY(hipEventRecord(inter_c, S->near_stream));
-    last_ghost = ghost_c;
+    T8_TRY(launch(0, nd, sc));                                             // C_g
+    T8_HIP_TRY(hipEventRecord(deep_c, sc));
+    T8_TRY((exchange<T, V>(S->halo, S->peers.data(), S->send_off.data(), S->recv_off.data(), sv, sx)));
+    if (g > 0 && !S->capturing) T8_HIP_TRY(hipStreamWaitEvent(sx, inter_p, 0));               // A_g <- B_(g-1)
+    T8_TRY(launch(ni, nt - ni, sx));                                       // A_g
+    T8_HIP_TRY(hipEventRecord(ghost_c, sx));
+    T8_TRY(launch(nd, ni - nd, sb));                                       // B_g
+    T8_HIP_TRY(hipEventRecord(inter_c, sb));
+    last_ghost    = swap ? deep_c : ghost_c;   // (what the exit below joins: the two streams that are not s)
     last_interior = inter_c;
   }
   if (comm && n_steps > 0) {  // exit: everything is ordered on s again
@@ -277,11 +288,10 @@ template <class T, class V>
 int iterate_graph(Stepper* S, int kind, T* planes, size_t stride, const T* vol, int prev, int next, T dt, T* speed, int n_steps,
                   hipStream_t s) {
   if (!S->graph_mode || S->timing > 0 || n_steps <= 0) return iterate<T, V>(S, kind, planes, stride, vol, prev, next, dt, speed, n_steps, s);
-  // Multi-rank stages have an RCCL group in the middle, and a capture that contains one ends in a segmentation fault inside
-  // hipStreamEndCapture on this stack (HIP 7.0 / RCCL 2.26 of the torch wheel; tests/test_gpu_graph.py):
-  // with a halo the driver keeps the direct enqueue. T8GPU_GRAPH_RCCL=1 opts in to the capture (diagnostics only).
-  static const bool rccl_capture = std::getenv("T8GPU_GRAPH_RCCL") && std::getenv("T8GPU_GRAPH_RCCL")[0] == '1';
-  if (S->has_halo && S->halo.n_peers > 0 && !rccl_capture) return iterate<T, V>(S, kind, planes, stride, vol, prev, next, dt, speed, n_steps, s);
+  // Multi-rank stages have an RCCL group in the middle. It is captured with the rest (on the capture's origin stream: see
+  // iterate()); T8GPU_GRAPH_RCCL=0 keeps the direct enqueue for steppers with a halo.
+  static const bool no_rccl_capture = std::getenv("T8GPU_GRAPH_RCCL") && std::getenv("T8GPU_GRAPH_RCCL")[0] == '0';
+  if (S->has_halo && S->halo.n_peers > 0 && no_rccl_capture) return iterate<T, V>(S, kind, planes, stride, vol, prev, next, dt, speed, n_steps, s);
   struct Key {
     int kind, prev, next, n_steps, tsize, subgrid;
     const void *planes, *vol, *speed;

@@ -185,7 +185,10 @@ def test_c5_full_size_properties():
     assert bool(torch.isfinite(a.state()).all())
     assert torch.equal(a.state(), b.state()) and torch.equal(a.speed, b.speed)      # native driver == python driver, bitwise
     assert max(abs(x - y) for x, y in zip(m0, m1)) < 1e-12 * max(abs(x) for x in m0)
-    assert rel_err(a.state().cpu().numpy(), c.state().cpu().numpy()) < 1e-12
+    # (normalised by the largest value of the whole state: the z-momentum of this z-independent flow is rounding noise in
+    #  both tiers, a per-variable norm would compare noise with noise)
+    fa, fc = a.state().cpu().numpy(), c.state().cpu().numpy()
+    assert np.abs(fa - fc).max() < 1e-12 * np.abs(fc).max()
 
 
 def test_lds_scatter_add_variant_matches_the_oracle():
