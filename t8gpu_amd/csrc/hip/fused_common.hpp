@@ -25,6 +25,17 @@ struct vec4<double> {
   using type = double4;
 };
 
+template <class T>
+struct vec2;
+template <>
+struct vec2<float> {
+  using type = float2;
+};
+template <>
+struct vec2<double> {
+  using type = double2;
+};
+
 // XCD-aware bijection block -> position in [0, nb): XCD x (= b % 8) owns a contiguous run.
 T8_DEV int xcd_position(int b, int nb) {
   const int q = nb >> 3, rem = nb & 7, x = b & 7, k = b >> 3;

@@ -236,9 +236,18 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
       patch_face<T, KIND, NW>(true, mine, wr, area, gy, sy);
 #pragma unroll
       for (int k = 0; k < 5; k++) ff[k * kPatchFF + 256 + tid] = gy[k];
-      if (speed) {   // the patch's own faces: ids fbase + 2 t (+x) and fbase + 2 t + 1 (+y)
-        speed[d0.fbase + 2 * tid]     = sx;
-        speed[d0.fbase + 2 * tid + 1] = sy;
+      if (speed) {   // the patch's own faces: ids fbase + 2 t (+x) and fbase + 2 t + 1 (+y): one 16-byte store where aligned
+        T* const sp = speed + d0.fbase + 2 * tid;
+        if ((d0.fbase & 1) == 0 || sizeof(T) == 4) {   // (wave-uniform; fp32: an 8-byte store is aligned for every fbase)
+          using V2 = typename vec2<T>::type;
+          V2 v;
+          v.x = sx;
+          v.y = sy;
+          *reinterpret_cast<V2*>(sp) = v;
+        } else {
+          sp[0] = sx;
+          sp[1] = sy;
+        }
       }
     }
     if (minus_lane) {
