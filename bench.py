@@ -403,6 +403,7 @@ def bench_adaptive(args, w, dts, tdtype, kindf, mode, rank, world, dist, rehears
     halo = attach(solver)
     t_step = t_cycle = 0.0
     cells = cycles = 0
+    split = {}
 
     def sync():
         torch.cuda.synchronize()
@@ -440,6 +441,8 @@ def bench_adaptive(args, w, dts, tdtype, kindf, mode, rank, world, dist, rehears
             sync()
             t_cycle += time.perf_counter() - t1
             cycles += 1
+            for k, v in (getattr(solver, "last_adapt_split", None) or {}).items():
+                split[k] = split.get(k, 0.0) + v
     sync()
     elapsed = total(time.perf_counter() - tstart, "max")
     finite = bool(torch.isfinite(solver.state()).all().item())
@@ -456,6 +459,9 @@ def bench_adaptive(args, w, dts, tdtype, kindf, mode, rank, world, dist, rehears
                        "kernels": mode, "adapt_every": a["every"], "adapt_cycles_timed": cycles,
                        "step_ms": round(step_s / max(1, args.steps) * 1e3, 4),
                        "cycle_ms": round(cycle_s / max(1, cycles) * 1e3, 2) if cycles else None,
+                       # one rank: where a cycle goes -- indicator kernels + read-back / mesh provider (t8code's share in the
+                       # reference) / this backend's tile plan / new planes + uploads / transfer kernel + step driver
+                       "cycle_split_ms": {k: round(v / max(1, cycles) * 1e3, 2) for k, v in split.items()} or None,
                        "stepping_only_M_cell_updates_per_s": round(tot_cells / step_s / 1e6, 2),
                        "partition": f"sfc-contiguous x{world}, repartitioned at every adapt", "finite": finite,
                        "setup_s": round(setup_s, 1)},

@@ -38,6 +38,8 @@ void t8gpu_synth_part_halo(const void* part, int64_t* ghost_global, int32_t* gho
                            int32_t* recv_off, int32_t* send_off, int32_t* send_idx);
 /* Kelvin-Helmholtz initial state (values of examples/subgrid/solver.inl:35-56,84-103): out = 5 planes of
  * `stride` doubles; cells_per_dim = 1 (plain) or 4 (Subgrid<4,..>, index e*S + i + 4j + 16k). */
+/* frees the partition's connectivity arrays (already copied out); element queries and the IC stay available */
+void t8gpu_synth_part_release_arrays(void* part);
 void t8gpu_synth_part_kh_ic(const void* part, int cells_per_dim, double* out, size_t stride);
 
 /* ---- adaptation of the synthetic forest (stands where t8_forest adapt + balance run, mesh_manager.inl:196-213) --

@@ -38,16 +38,21 @@ def refinement_criteria(solver):
 def adapt(solver, threshold=10.0, min_level=1, max_level=4, family_members_averaged=4, volume_dim=None):
     """Refine / coarsen the mesh of a single-rank PlainSolver by the reference's criterion and transfer the
     current solution. Returns the new solver (same dtype, flux, kernel tier, step bookkeeping)."""
+    import time
     part = solver.part
     assert part.nranks == 1, "multi-rank adaptation goes through amr.adapt_partitioned"
     mesh = part.mesh
+    t0 = time.perf_counter()
     crit = refinement_criteria(solver).double().cpu().numpy()
+    t1 = time.perf_counter()
     marks = mesh.marks_from_criteria(crit, threshold, min_level, max_level, family_members_averaged)
     new_mesh, adapt_data = mesh.adapt(marks)
     new_part = new_mesh.partition(0, 1, subgrid=False, normal_dim=part.normal_dim)
+    t2 = time.perf_counter()
     dim = mesh.dim if volume_dim is None else volume_dim
     new = PlainSolver(new_part, solver.dtype, flux_kind=solver.kind, mode=solver.mode,
                       state=np.zeros((5, new_part.N + new_part.G)), plan_options=_inherited_plan_options(solver))
+    t3 = time.perf_counter()
     new.next, new.prev = solver.next, solver.prev
     ad = torch.from_numpy(adapt_data).cuda()
     hip.call("t8gpu_hip_adapt_variables_and_volume", solver.dtype, new_part.N, dim, hip.ptr(ad),
@@ -56,7 +61,14 @@ def adapt(solver, threshold=10.0, min_level=1, max_level=4, family_members_avera
     torch.cuda.synchronize()
     if getattr(solver, "stepper", None) is not None:
         new.use_native_stepper()
+    t4 = time.perf_counter()
     new.last_adapt_criteria_sum = float(crit.sum())
+    # where the cycle went (seconds): the indicator kernels + read-back, the mesh provider (forest adapt + balance,
+    # partition + connectivity: t8code's share in the reference), this backend's tile plan + upload + new planes, the
+    # transfer kernel + step driver
+    plan_s = getattr(new, "plan_build_s", 0.0)
+    new.last_adapt_split = {"indicator": t1 - t0, "provider": t2 - t1, "plan": plan_s, "planes_upload": (t3 - t2) - plan_s,
+                            "transfer": t4 - t3}
     return new, marks, adapt_data
 
 

@@ -22,6 +22,8 @@
 #include <cstring>
 #include <vector>
 
+#include "host_threads.hpp"
+
 #include "t8gpu_host.h"
 
 namespace {
@@ -78,8 +80,10 @@ struct Mesh {
   }
 
   void fill_owner() {
-    owner.assign(static_cast<size_t>(1) << (dim * lmax), -1);
-    for (size_t e = 0; e < leaves.size(); e++) {
+    // (the leaves tile the domain, so every entry is rewritten below: no fill; leaves own disjoint boxes of the grid)
+    owner.resize(static_cast<size_t>(1) << (dim * lmax));
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
+    for (int64_t e = 0; e < static_cast<int64_t>(leaves.size()); e++) {
       const Leaf&    l = leaves[e];
       const uint32_t s = 1u << (lmax - l.level);
       const uint32_t z0 = dim == 3 ? l.c[2] * s : 0, z1 = dim == 3 ? z0 + s : 1;
@@ -125,13 +129,15 @@ struct Mesh {
     // 2:1 face balance: a fine leaf marks any face neighbour coarser by >= 2.
     for (;;) {
       std::vector<uint8_t> mark(leaves.size(), 0);
-      bool                 any = false;
-      for (size_t e = 0; e < leaves.size(); e++)
+      int                  any = 0;
+#pragma omp parallel for num_threads(host_threads()) schedule(static) reduction(| : any)
+      for (int64_t e = 0; e < static_cast<int64_t>(leaves.size()); e++)
         for (int f = 0; f < 2 * dim; f++) {
-          const int32_t nb = across(e, f);
+          const int32_t nb = across(static_cast<size_t>(e), f);
           if (nb >= 0 && leaves[nb].level < leaves[e].level - 1) {
+#pragma omp atomic write
             mark[nb] = 1;
-            any      = true;
+            any |= 1;
           }
         }
       if (!any) break;
@@ -184,19 +190,46 @@ void build_part(Part& P) {
     int     f;
   };
   std::vector<RawFace> faces, walls;
-  for (int64_t e = 0; e < n; e++) {
+  // the faces a rank lists, in element order then face order (the single-rank listing rule). Two passes over the
+  // elements that can touch the rank's range -- count, prefix sum, fill -- both parallel over elements.
+  auto visit = [&](int64_t e, RawFace* fo, RawFace* wo, int32_t& nf, int32_t& nw) {
     const bool mine = e >= lo && e < hi;
+    nf = nw = 0;
     for (int f = 0; f < 2 * dim; f++) {
       const int32_t nb = M.across(static_cast<size_t>(e), f);
       if (nb < 0) {
-        if (mine) walls.push_back({e, -1, f});
+        if (mine) {
+          if (wo) wo[nw] = {e, -1, f};
+          nw++;
+        }
         continue;
       }
       const bool nb_mine = nb >= lo && nb < hi;
       if (!mine && !nb_mine) continue;
       const int le = M.leaves[e].level, ln = M.leaves[nb].level;
       if (ln > le) continue;  // several finer neighbours: they list the face
-      if (nb > e || (nb < e && ln < le)) faces.push_back({e, nb, f});
+      if (nb > e || (nb < e && ln < le)) {
+        if (fo) fo[nf] = {e, nb, f};
+        nf++;
+      }
+    }
+  };
+  {
+    std::vector<int32_t> cf(static_cast<size_t>(n) + 1, 0), cw(static_cast<size_t>(n) + 1, 0);
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
+    for (int64_t e = 0; e < n; e++) visit(e, nullptr, nullptr, cf[e + 1], cw[e + 1]);
+    std::vector<int64_t> of(static_cast<size_t>(n) + 1, 0), ow(static_cast<size_t>(n) + 1, 0);
+    for (int64_t e = 0; e < n; e++) {
+      of[e + 1] = of[e] + cf[e + 1];
+      ow[e + 1] = ow[e] + cw[e + 1];
+    }
+    faces.resize(static_cast<size_t>(of[n]));
+    walls.resize(static_cast<size_t>(ow[n]));
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
+    for (int64_t e = 0; e < n; e++) {
+      if (cf[e + 1] == 0 && cw[e + 1] == 0) continue;
+      int32_t a, b;
+      visit(e, faces.data() + of[e], walls.data() + ow[e], a, b);
     }
   }
   // ghosts: referenced elements outside [lo, hi), sorted by global index
@@ -230,6 +263,7 @@ void build_part(Part& P) {
     P.normals[P.ndim * slot + f / 2] = (f & 1) ? 1.0 : -1.0;
     P.areas[slot]                    = dim == 3 ? h * h : h;
   };
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
   for (int32_t i = 0; i < P.F; i++) {
     const RawFace& rf = faces[i];
     P.fn[2 * static_cast<size_t>(i)]     = local(rf.l);
@@ -341,6 +375,16 @@ void* t8gpu_synth_part_create(const void* mesh, int rank, int nranks, int subgri
   return p;
 }
 void t8gpu_synth_part_destroy(void* h) { delete static_cast<Part*>(h); }
+// frees the connectivity arrays of a partition (the caller has copied them) but keeps what the element queries below need
+// (first element, ghost list): the initial condition of a partition can then be evaluated when -- and if -- it is asked for
+void t8gpu_synth_part_release_arrays(void* h) {
+  Part* p = static_cast<Part*>(h);
+  std::vector<int32_t>().swap(p->fn);
+  std::vector<double>().swap(p->normals);
+  std::vector<double>().swap(p->areas);
+  std::vector<int32_t>().swap(p->level_diff);
+  std::vector<int32_t>().swap(p->nb_offset);
+}
 
 // counts[8] = {N, G, F, B, n_peers, n_send, first_global_lo32, first_global_hi32}
 void t8gpu_synth_part_counts(const void* h, int64_t* counts) {
@@ -373,6 +417,7 @@ void t8gpu_synth_part_elements(const void* h, int32_t* level, double* volume, do
   const Part* p   = static_cast<const Part*>(h);
   const Mesh& M   = *p->m;
   const int   tot = p->N + p->G;
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
   for (int i = 0; i < tot; i++) {
     const int64_t g = i < p->N ? p->first + i : p->ghost_global[i - p->N];
     const Leaf&   l = M.leaves[g];
@@ -407,6 +452,7 @@ void t8gpu_synth_part_kh_ic(const void* h, int cells_per_dim, double* out, size_
   const int   E   = cells_per_dim;
   const int   S   = dim == 3 ? E * E * E : E * E;
   const int   tot = p->N + p->G;
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
   for (int i = 0; i < tot; i++) {
     const int64_t g  = i < p->N ? p->first + i : p->ghost_global[i - p->N];
     const Leaf&   l  = M.leaves[g];
@@ -547,13 +593,15 @@ void* t8gpu_synth_mesh_adapt(const void* mesh, const int8_t* marks) {
   //    coarsening goes back to its children (net change 0); a kept leaf is refined once (net +1).
   for (;;) {
     std::vector<uint8_t> mark(M->leaves.size(), 0);
-    bool                 any = false;
-    for (size_t e = 0; e < M->leaves.size(); e++)
+    int                  any = 0;
+#pragma omp parallel for num_threads(host_threads()) schedule(static) reduction(| : any)
+    for (int64_t e = 0; e < static_cast<int64_t>(M->leaves.size()); e++)
       for (int f = 0; f < 2 * M->dim; f++) {
-        const int32_t nb = M->across(e, f);
+        const int32_t nb = M->across(static_cast<size_t>(e), f);
         if (nb >= 0 && M->leaves[nb].level < M->leaves[e].level - 1) {
+#pragma omp atomic write
           mark[nb] = 1;
-          any      = true;
+          any |= 1;
         }
       }
     if (!any) break;

@@ -22,6 +22,8 @@
 #include <unordered_set>
 #include <vector>
 
+#include "host_threads.hpp"
+
 namespace {
 
 // A structured patch: kPatchSide x kPatchSide same-size quadrilaterals that are kPatchElems CONSECUTIVE elements in
@@ -239,35 +241,46 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
     }
   }
   lap("greedy tiling");
-  // a tile must fit the kernel's LDS window: own + halo elements <= lecap; halve offenders
+  // a tile must fit the kernel's LDS window: own + halo elements <= lecap; halve offenders (per greedy tile, in parallel)
   {
-    std::vector<int32_t> stamp(static_cast<size_t>(N) + P.G, -1);
-    std::vector<int32_t> off;
-    int32_t              id = 0;
-    std::vector<std::pair<int32_t, int32_t>> work;
-    for (size_t t = P.elem_off.size() - 1; t-- > 0;) work.push_back({P.elem_off[t], P.elem_off[t + 1]});
-    off.push_back(0);
-    while (!work.empty()) {
-      const auto [a, b] = work.back();
-      work.pop_back();
-      int32_t nh = 0;
-      for (int32_t e = a; e < b; e++)
-        for (int32_t j = deg[e]; j < deg[e + 1]; j++)
-          for (int w = 0; w < 2; w++) {
-            const int32_t o = side(ef[j], w);
-            if (o >= 0 && (o < a || o >= b) && stamp[o] != id) {
-              stamp[o] = id;
-              nh++;
-            }
+    const int32_t nt0 = static_cast<int32_t>(P.elem_off.size()) - 1;
+    std::vector<std::vector<int32_t>> cuts(nt0);   // extra offsets inside a greedy tile (almost always none)
+#pragma omp parallel num_threads(host_threads())
+    {
+      std::vector<int32_t>                     out;
+      std::vector<std::pair<int32_t, int32_t>> work;
+#pragma omp for schedule(static)
+      for (int32_t t = 0; t < nt0; t++) {
+        if (patch_at[P.elem_off[t]] >= 0) continue;
+        work.assign(1, {P.elem_off[t], P.elem_off[t + 1]});
+        while (!work.empty()) {
+          const auto [a, b] = work.back();
+          work.pop_back();
+          out.clear();
+          for (int32_t e = a; e < b; e++)
+            for (int32_t j = deg[e]; j < deg[e + 1]; j++)
+              for (int w = 0; w < 2; w++) {
+                const int32_t o = side(ef[j], w);
+                if (o >= 0 && (o < a || o >= b)) out.push_back(o);
+              }
+          std::sort(out.begin(), out.end());
+          const int32_t nh = static_cast<int32_t>(std::unique(out.begin(), out.end()) - out.begin());
+          if ((b - a) + nh > P.lecap && b - a > 1) {
+            const int32_t m = a + (b - a) / 2;
+            work.push_back({m, b});
+            work.push_back({a, m});
+          } else if (b != P.elem_off[t + 1]) {
+            cuts[t].push_back(b);
           }
-      id++;
-      if (patch_at[a] < 0 && (b - a) + nh > P.lecap && b - a > 1) {
-        const int32_t m = a + (b - a) / 2;
-        work.push_back({m, b});
-        work.push_back({a, m});
-      } else {
-        off.push_back(b);
+        }
       }
+    }
+    std::vector<int32_t> off;
+    off.reserve(P.elem_off.size());
+    off.push_back(0);
+    for (int32_t t = 0; t < nt0; t++) {
+      off.insert(off.end(), cuts[t].begin(), cuts[t].end());
+      off.push_back(P.elem_off[t + 1]);
     }
     P.elem_off.swap(off);
   }
@@ -301,11 +314,13 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
     std::sort(halo.begin(), halo.end());
     halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
   };
-#pragma omp parallel
+  // (the lists of pass 1 are kept for pass 2: sorting them twice was 40 % of this phase)
+  std::vector<std::vector<int32_t>> tfs(ntiles), halos(ntiles);
+#pragma omp parallel num_threads(host_threads())
   {
-    std::vector<int32_t> tf, halo;
 #pragma omp for schedule(static)
     for (int32_t t = 0; t < ntiles; t++) {
+      std::vector<int32_t>&tf = tfs[t], &halo = halos[t];
       tile_lists(t, tf, halo);
       P.face_off[t + 1] = static_cast<int32_t>(tf.size());
       P.halo_off[t + 1] = static_cast<int32_t>(halo.size());
@@ -329,14 +344,14 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
   P.face_geo.resize(4 * static_cast<size_t>(P.face_off[ntiles]));
   P.face_orig.resize(P.face_off[ntiles]);
   P.csr_ent.resize(deg[N]);
-#pragma omp parallel
+#pragma omp parallel num_threads(host_threads())
   {
-    std::vector<int32_t> tf, halo, order, where;
+    std::vector<int32_t> order, where;
     std::vector<uint8_t> codes;
 #pragma omp for schedule(static)
     for (int32_t t = 0; t < ntiles; t++) {
       const int32_t e0 = P.elem_off[t], e1 = P.elem_off[t + 1], ne = e1 - e0;
-      tile_lists(t, tf, halo);
+      const std::vector<int32_t>&tf = tfs[t], &halo = halos[t];
       if (P.tile_patch[t] >= 0) {
         for (int32_t j = deg[e0]; j < deg[e1]; j++) P.csr_ent[j] = static_cast<uint16_t>(0xFFFFu);   // (never read)
         std::copy(halo.begin(), halo.end(), P.halo_ids.begin() + P.halo_off[t]);
@@ -427,7 +442,7 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
   for (int32_t e = 0; e < N; e++) maxdeg = std::max(maxdeg, P.csr_off[e + 1] - P.csr_off[e]);
   P.ell_width = std::max(8, (maxdeg + 7) / 8 * 8);
   P.ell.resize(static_cast<size_t>(N) * P.ell_width);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
   for (int32_t e = 0; e < N; e++) {
     uint16_t*     row = &P.ell[static_cast<size_t>(e) * P.ell_width];
     const int32_t n   = P.csr_off[e + 1] - P.csr_off[e];
@@ -483,7 +498,7 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
         row[10] = n[0] * row[5] - n[1] * row[4];
       }
       P.geo_idx.resize(nfaces);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
       for (int64_t f = 0; f < static_cast<int64_t>(nfaces); f++) {
         Key k;
         std::memcpy(k.w, &P.face_geo[4 * static_cast<size_t>(f)], 32);

@@ -67,7 +67,10 @@ class PlainSolver:
         self.plan = None
         if mode == "fused":
             from . import fused
+            import time
+            t0 = time.perf_counter()
             self.plan = fused.PlainPlan(part, dtype, **dict(dict(flux_kind=flux_kind), **(plan_options or {})))
+            self.plan_build_s = time.perf_counter() - t0          # host tile plan + its upload (amr.adapt reports it)
         elif mode != "compat":
             raise ValueError(mode)
 

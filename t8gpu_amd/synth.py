@@ -22,6 +22,7 @@ def lib():
         _lib.t8gpu_synth_part_create.restype = C.c_void_p
         _lib.t8gpu_synth_part_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.t8gpu_synth_part_destroy.argtypes = [C.c_void_p]
+        _lib.t8gpu_synth_part_release_arrays.argtypes = [C.c_void_p]
         _lib.t8gpu_synth_part_counts.argtypes = [C.c_void_p, C.c_void_p]
         _lib.t8gpu_synth_part_connectivity.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         _lib.t8gpu_synth_part_elements.argtypes = [C.c_void_p] + [C.c_void_p] * 3
@@ -137,14 +138,12 @@ class Partition:
             self.send_idx = np.zeros(nsend, np.int32)
             lib().t8gpu_synth_part_halo(h, _p(self.ghost_global), _p(self.ghost_owner), _p(self.peers),
                                         _p(self.recv_off), _p(self.send_off), _p(self.send_idx))
-            self._ic = {}
-            for cpd in ((4,) if subgrid else (1,)):
-                S = cpd ** dim
-                out = np.zeros((5, tot * S), np.float64)
-                lib().t8gpu_synth_part_kh_ic(h, cpd, _p(out), tot * S)
-                self._ic[cpd] = out
+            self._ic = {}                                   # evaluated on demand (kh_initial_state): an adapt cycle never asks
+            lib().t8gpu_synth_part_release_arrays(h)
+            self._h, h = h, None
         finally:
-            lib().t8gpu_synth_part_destroy(h)
+            if h:
+                lib().t8gpu_synth_part_destroy(h)
         # ranks[]/indices[] of the reference accessors (mesh_manager.h:141-157): ghosts resolve to local slots.
         self.ranks = np.full(tot, rank, np.int32)
         self.indices = np.arange(tot, dtype=np.int32)
@@ -155,4 +154,18 @@ class Partition:
 
     def kh_initial_state(self):
         """(5, (N+G)*S) float64 Kelvin-Helmholtz state, ghosts included."""
-        return self._ic[4 if self.subgrid else 1]
+        cpd = 4 if self.subgrid else 1
+        if cpd not in self._ic:
+            tot, S = self.N + self.G, cpd ** self.mesh.dim
+            out = np.zeros((5, tot * S), np.float64)
+            lib().t8gpu_synth_part_kh_ic(self._h, cpd, _p(out), tot * S)
+            self._ic[cpd] = out
+        return self._ic[cpd]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            try:
+                lib().t8gpu_synth_part_destroy(self._h)
+            except TypeError:                                   # interpreter shutdown: the module globals are gone
+                pass
+            self._h = None
