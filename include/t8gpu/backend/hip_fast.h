@@ -140,10 +140,10 @@ namespace t8gpu::hip {
     /// them) and the communicator; iterate_fused then exchanges the ghost layer per stage (csrc/hip/stepper.hip).
     explicit PlainFusedPlan(HostMeshArrays const& m, int ndim = 3, int tmax = 256, int fcap = 512, HostHaloArrays const* halo = nullptr,
                             Communicator const* comm = nullptr) {
-      // (flag 1: structured 16 x 16 patches are cut out of the tiling and run through the patch kernel)
+      // (flags 3: structured patches -- 16 x 16 quadrilateral / 8 x 8 x 4 hexahedral blocks -- are cut out of the tiling and run through the patch kernels)
       void* h = t8gpu_plan_plain_create_ex(m.num_local_elements, m.num_ghost_elements, m.num_local_faces,
                                            m.num_local_boundary_faces, ndim, m.face_neighbors.data(), m.face_normals.data(),
-                                           m.face_surfaces.data(), tmax, fcap, 1);
+                                           m.face_surfaces.data(), tmax, fcap, 3);
       if (!h) T8GPU_ABORT("t8gpu_plan_plain_create_ex failed");
       int64_t sz[16];
       t8gpu_plan_plain_sizes(h, sz);
@@ -160,6 +160,7 @@ namespace t8gpu::hip {
       t8gpu_plan_plain_tile_desc(h, tile_desc.data());
       int32_t patch_counts[4];
       t8gpu_plan_plain_patch_counts(h, patch_counts);
+      const int32_t patch_dim = t8gpu_plan_plain_patch_dim(h);
       t8gpu_plan_plain_destroy(h);
       m_plan.elem_off   = up(elem_off);
       m_plan.halo_off   = up(halo_off);
@@ -181,7 +182,7 @@ namespace t8gpu::hip {
       m_plan.n_geo = static_cast<int32_t>(ngeo); m_plan.max_slots = static_cast<int32_t>(sz[12]);
       m_plan.n_deep_tiles = static_cast<int32_t>(sz[13]); m_plan.reserved = 0;
       for (int c = 0; c < 3; c++) m_plan.n_patch_tiles[c] = patch_counts[c];
-      m_plan.reserved2 = 0;
+      m_plan.patch_dim = patch_dim;
       T8gpuHalo  hl{};
       const bool multi = halo && comm && !halo->peers.empty();
       if (multi) {

@@ -165,7 +165,9 @@ typedef struct T8gpuPlainPlan {
    * n_patch_tiles[c] tiles of class c of tile_order (c = 0: [0, n_deep_tiles), 1: [n_deep_tiles, n_interior_tiles),
    * 2: the rest) are patch tiles; they run through kernels_fused_patch.hip. All zero: no patches. */
   int32_t n_patch_tiles[3];
-  int32_t reserved2;
+  int32_t patch_dim;          /* 2: the 16 x 16 patches above; 3: 8 x 8 x 4 blocks of same-size hexahedra (256 halo entries:
+                               * -x 32 | +x 32 | -y 32 | +y 32 | -z 64 | +z 64; own faces fbase + 3 t + {0, 1, 2}; flags bits 0-2:
+                               * -y before -x, -z before -x, -z before -y where both coordinates of the pair are 0); 0: no patches */
 } T8gpuPlainPlan;
 
 /* tile_begin/tile_count select a range of tile_order (0, ntiles = everything; [0, n_interior) can run

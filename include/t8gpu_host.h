@@ -67,6 +67,11 @@ void* t8gpu_plan_plain_create_ex(int32_t N, int32_t G, int32_t F, int32_t B, int
 void  t8gpu_plan_plain_destroy(void* plan);
 /* counts[4] = leading patch tiles of the deep / near-boundary / ghost-reading class of tile_order, total */
 void  t8gpu_plan_plain_patch_counts(const void* plan, int32_t* counts);
+/* flags bit 1 of t8gpu_plan_plain_create_ex: 3D patches -- 8 x 8 x 4 same-size hexahedra that are 256 consecutive elements
+ * in Morton order (find_patches3); tile_desc = {first element, 256, first halo entry, 256, id of the first own face,
+ * 0x300 | flags, area}, halo = [-x 32 | +x 32 | -y 32 | +y 32 | -z 64 | +z 64]. A plan holds one kind of patch.
+ * 2 | 3: the kind of the plan's patch tiles, 0: none */
+int32_t t8gpu_plan_plain_patch_dim(const void* plan);
 /* sizes[16] (12 = max over the generic tiles of own + halo elements, 13 = number of deep-interior tiles, 14 = number of patch tiles, 15 reserved = 0; the maxima 4-6 are over the generic tiles) = {ntiles, n_halo, n_faces, n_csr, max_elems, max_halo, max_faces, n_interior_tiles, N, F,
  *              ell_width, n_geo} */
 void t8gpu_plan_plain_sizes(const void* plan, int64_t* sizes);

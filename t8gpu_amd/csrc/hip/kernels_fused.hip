@@ -254,7 +254,15 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
     if (p1 > s1) return static_cast<int>(hipErrorInvalidValue);
     const int pb = b > s0 ? b : s0, pe = e < p1 ? e : p1;   // patch tiles of this class inside the range
     int       qb = b > p1 ? b : p1, qe = e < s1 ? e : s1;   // its generic tiles
-    if (pe > pb) {
+    if (pe > pb && plan->patch_dim == 3) {   // 8 x 8 x 4 hexahedral patches: their own kernel, the generic tiles apart
+      if (int rc = flush()) return rc;
+      // (Measured and dropped: the generic tiles on a side stream forked from / joined to the caller's stream by events, so
+      //  that they run BESIDE the patches -- c5 5 235 -> 5 078, c5u 5 070 -> 4 716 M/s: the fork / join events cost more than
+      //  the overlap returns, as with the Subgrid leftover blocks of round 2.)
+      const int rc = plain_patch3_stage<T>(kind, stage, plan, pb, pe - pb, fmk<T>(prev), fmk<T>(mid), fmk<T>(out), volume, dt, speed,
+                                           whole || persistent_always, static_cast<hipStream_t>(stream));
+      if (rc != 0) return rc;
+    } else if (pe > pb) {
       if (int rc = flush()) return rc;
       // patches and generic tiles of the class in ONE launch where the patches carry most of it (the generic tiles then
       // run the one-tile body behind the persistent patch workgroups); otherwise the generic tiles keep their own launch

@@ -30,70 +30,10 @@
 
 #include "fused_common.hpp"
 #include "fused_tile_body.hpp"
+#include "patch_common.hpp"
 #include "stage_kernel_note.hpp"
 
 namespace t8gpu_hip {
-
-constexpr int kPatchFF = 544;   // flux slots per variable: 256 +x faces, 256 +y faces, 16 -x side, 16 -y side
-
-T8_DEV int patch_morton(int i, int j) {
-  int t = 0;
-#pragma unroll
-  for (int b = 0; b < 4; b++) t |= (((i >> b) & 1) << (2 * b)) | (((j >> b) & 1) << (2 * b + 1));
-  return t;
-}
-T8_DEV int patch_ctz4(int v) { return v == 0 ? 4 : __builtin_ctz(static_cast<unsigned>(v)); }
-
-// velocity components in the frame of a face with normal +e_AXIS (the frame face_basis() gives that normal, see
-// kepes_axis_fixed in flux_math.hpp), and a frame flux back to xyz. YSEL: per lane (mixed wavefront of the - sides).
-template <class T>
-T8_DEV void frame_in(bool y, T vx, T vy, T vz, T& u, T& v, T& w) {
-  u = y ? vy : vx;
-  v = y ? vx : -vz;
-  w = y ? -vz : vy;
-}
-template <class T>
-T8_DEV void frame_out(bool y, const T f[5], T g[5]) {
-  g[0] = f[0];
-  g[1] = y ? f[2] : f[1];
-  g[2] = y ? f[1] : f[3];
-  g[3] = y ? -f[3] : -f[2];
-  g[4] = f[4];
-}
-
-// one face with normal +e_x (AXIS 0) or +e_y (AXIS 1); KEPES from primitives, HLL / HLLC from the conserved states
-template <class T, int KIND, int NW>
-T8_DEV void patch_face(bool y, const T* wl, const T* wr, T area, T g[5], T& spd) {
-  T f[5];
-  if (KIND == 0) {
-    Prim<T> L, R;
-    words_prim<T>(wl, L);
-    words_prim<T>(wr, R);
-    T uL, vL, wL, uR, vR, wR;
-    frame_in<T>(y, L.vx, L.vy, L.vz, uL, vL, wL);
-    frame_in<T>(y, R.vx, R.vy, R.vz, uR, vR, wR);
-#ifdef T8GPU_EXP_NOMATH
-    f[0] = L.rho + R.rho + uL; f[1] = vL + wL + uR; f[2] = vR + wR + L.beta + R.beta; f[3] = L.lrho + R.lrho;
-    f[4] = L.p + R.p + L.lbeta + R.lbeta + L.v0 + R.v0 + area;
-    spd = f[0];
-#else
-    kepes_core<T>(L, R, uL, vL, wL, uR, vR, wR, area, f, spd);
-#endif
-  } else {
-    T a[5], b[5];
-    a[0] = wl[0]; a[4] = wl[4];
-    b[0] = wr[0]; b[4] = wr[4];
-    frame_in<T>(y, wl[1], wl[2], wl[3], a[1], a[2], a[3]);
-    frame_in<T>(y, wr[1], wr[2], wr[3], b[1], b[2], b[3]);
-    if (KIND == 2)
-      hllc_fast<T>(a, b, f, spd);
-    else
-      hll_fast<T>(a, b, f, spd);
-#pragma unroll
-    for (int k = 0; k < 5; k++) f[k] = area * f[k];
-  }
-  frame_out<T>(y, f, g);
-}
 
 // workgroup `wg` of the `nwg` that share the patch tiles [tile_begin, tile_begin + tile_count) of tile_order
 template <class T, int KIND, int STAGE>

@@ -1,0 +1,289 @@
+// kernels_fused_patch3.hip -- fused RK stage over 3D STRUCTURED PATCHES of a plain-element mesh (round 3).
+//
+// Reference: examples/compressible_euler/kernels.cu:135-309 + ssp_runge_kutta.inl:30-99 (the stage the tile kernels fuse).
+//
+// The 3D analogue of kernels_fused_patch.hip: a Cartesian hexahedral AMR forest is locally structured, and an aligned
+// 8 x 8 x 4 block of same-size hexahedra is 256 CONSECUTIVE elements in Morton order (csrc/host/tile_plan.cpp:
+// find_patches3; 72 % of the elements of the c5 benchmark mesh). On generic 3D tiles the face cap binds at ~134 elements per
+// 256-lane workgroup, half the lanes idle in the per-element phases and every element walks a 16-entry face list; here
+//
+//   512 lanes = 8 wavefronts per patch: wavefronts 0-3 ("cell lanes") own the 256 cells, wavefronts 4-7 ("side lanes")
+//   the 256 cells across the six sides ([-x 32 | +x 32 | -y 32 | +y 32 | -z 64 | +z 64]).
+//   phase 1   every lane: primitives of its cell -> an LDS record (cell lanes keep theirs in registers)
+//   phase 2   cell lanes: the +x and +y face of their cell (left operand in registers);
+//             side lanes: the +z face of cell (tid - 256) -- both operands from LDS --, then wavefronts 6 / 7 the 128 faces of
+//             the - sides (same orientation and values as in the neighbouring tile). Every wavefront has 2 flux rounds:
+//             no wavefront waits at the barrier for another's third round
+//   phase 3   cell lanes: the three - fluxes in ascending face id (the order of the owning neighbours' indices: pairwise
+//             ctz rule, three flag bits per patch for the lanes on two low sides), then -(+x), -(+y), -(+z); RK stage
+//
+// Per 256 cells: 8 + 14 wave-rounds of primitives / fluxes and no face lists (generic 3D tiles: 8 + 8 rounds and a
+// 16-entry list walk per 134 cells). Same flux functions, operand order and summation order as the tile kernels: bitwise
+// their results (tests/test_gpu_patch.py). Persistent and software-pipelined; two barriers per patch.
+#include <cstdlib>
+
+#include "patch_common.hpp"
+#include "stage_kernel_note.hpp"
+
+namespace t8gpu_hip {
+
+constexpr int kP3FF = 896;   // flux slots per variable: +x 256 | +y 256 | +z 256 | - sides 128 (-x 32, -y 32, -z 64)
+
+T8_DEV int patch3_morton(int i, int j, int k) {   // x bits 0, 3, 6; y bits 1, 4, 7; z bits 2, 5
+  int t = 0;
+#pragma unroll
+  for (int b = 0; b < 3; b++) t |= (((i >> b) & 1) << (3 * b)) | (((j >> b) & 1) << (3 * b + 1));
+#pragma unroll
+  for (int b = 0; b < 2; b++) t |= ((k >> b) & 1) << (3 * b + 2);
+  return t;
+}
+T8_DEV int patch3_ctz(int v) { return v == 0 ? 8 : __builtin_ctz(static_cast<unsigned>(v)); }
+
+// (second launch bound = wavefronts per SIMD the register allocation must allow: two 8-wave workgroups per CU in fp64 --
+//  77 KB of LDS each --, three in fp32)
+template <class T, int KIND, int STAGE>
+__global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8gpuPlainPlan P, int tile_begin, int tile_count, FVars<T> prev,
+                                                                                 FVars<T> src, FVars<T> out, const T* __restrict__ vol, T dt,
+                                                                                 T* __restrict__ speed) {
+  constexpr int NW  = KIND == 0 ? kPrimWords : 5;
+  constexpr int REC = rec_words<T, NW>();
+  extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+  T* const  ff = reinterpret_cast<T*>(lds_raw);               // [5][kP3FF] the patch's face fluxes
+  T* const  pe = ff + 5 * kP3FF;                              // [512][REC] primitives (or states): 256 own, 256 across the sides
+  constexpr bool kTab = sizeof(T) == 8 && KIND == 0;          // fp64 KEPES: the logarithm table, behind the records
+  double* const lt = reinterpret_cast<double*>(pe + REC * 512);
+  const int tid = threadIdx.x;
+
+  const int G = gridDim.x, xcd = blockIdx.x & 7, jw = blockIdx.x >> 3;
+  const int nxcd = G < 8 ? G : 8, nx = (G - xcd + 7) >> 3;
+  const int per = tile_count / nxcd, rem = tile_count % nxcd;
+  const int x0   = tile_begin + xcd * per + (xcd < rem ? xcd : rem);
+  const int tend = x0 + per + (xcd < rem ? 1 : 0);
+  int       t    = x0 + jw;
+  if (xcd >= nxcd || t >= tend) return;
+  if (kTab) {
+    if (tid < 2 * kLogTabEntries) lt[tid] = kLogTab[tid];
+    __syncthreads();
+  }
+
+  // ---- lane constants: c = the cell the lane works for (cell lanes: their own; side lanes: the cell whose +z face they take)
+  const bool side = tid >= 256;
+  const int  c    = tid & 255, hl = tid - 256;
+  int        ci = 0, cj = 0, ck = 0;
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    ci |= ((c >> (3 * b)) & 1) << b;
+    cj |= ((c >> (3 * b + 1)) & 1) << b;
+  }
+#pragma unroll
+  for (int b = 0; b < 2; b++) ck |= ((c >> (3 * b + 2)) & 1) << b;
+  // records of the right operands of the cell's + faces; flux slots of its - faces (the + faces of the cells across)
+  const int rx   = ci < 7 ? patch3_morton(ci + 1, cj, ck) : 256 + 32 + cj + 8 * ck;
+  const int ry   = cj < 7 ? patch3_morton(ci, cj + 1, ck) : 256 + 96 + ci + 8 * ck;
+  const int rz   = ck < 3 ? patch3_morton(ci, cj, ck + 1) : 256 + 192 + ci + 8 * cj;
+  const int a_mx = ci > 0 ? patch3_morton(ci - 1, cj, ck) : 768 + cj + 8 * ck;
+  const int a_my = cj > 0 ? 256 + patch3_morton(ci, cj - 1, ck) : 768 + 32 + ci + 8 * ck;
+  const int a_mz = ck > 0 ? 512 + patch3_morton(ci, cj, ck - 1) : 768 + 64 + ci + 8 * cj;
+  // pairwise order of the - faces (true: the second-named axis' face has the smaller id); where both coordinates of the pair
+  // are 0 the patch's flags decide (bits 0 / 1 / 2)
+  const bool r_yx = patch3_ctz(cj) >= patch3_ctz(ci), r_zx = patch3_ctz(ck) >= patch3_ctz(ci), r_zy = patch3_ctz(ck) >= patch3_ctz(cj);
+  const bool f_yx = ci == 0 && cj == 0, f_zx = ci == 0 && ck == 0, f_zy = cj == 0 && ck == 0;
+  // wavefronts 6 / 7: the faces of the - sides. m < 32: -x side (cell (0, j, k)); m < 64: -y side; else -z side (wavefront 7)
+  const int  m       = hl - 128;
+  const bool minus   = hl >= 128;
+  const bool minus_y = m >= 32;                       // (wavefront 6 only: its lanes mix the x and y axes)
+  const int  mq      = m < 32 ? m : (m < 64 ? m - 32 : m - 64);
+  const int  m_l     = 256 + (m < 32 ? mq : (m < 64 ? 64 + mq : 128 + mq));
+  const int  m_r     = m < 32 ? patch3_morton(0, mq & 7, mq >> 3) : (m < 64 ? patch3_morton(mq & 7, 0, mq >> 3) : patch3_morton(mq & 7, mq >> 3, 0));
+
+  typedef int int8v __attribute__((ext_vector_type(8)));
+  struct Desc {
+    int    e0, h0, fbase, flags;
+    double area;
+  };
+  auto load_desc = [&](int tt) {   // scalar load through the constant address space (see k_plain_persistent)
+#ifdef T8GPU_EXP_TILEMOD
+    const size_t kk = static_cast<size_t>(tile_begin + (tt < tend ? tt : tend - 1) % T8GPU_EXP_TILEMOD);
+#else
+    const size_t kk = static_cast<size_t>(tt < tend ? tt : tend - 1);
+#endif
+    const int8v  r = *reinterpret_cast<const __attribute__((address_space(4))) int8v*>(
+        reinterpret_cast<const __attribute__((address_space(4))) char*>(reinterpret_cast<uintptr_t>(P.tile_desc)) + 32 * kk);
+    Desc d;
+    d.e0 = r[0]; d.h0 = r[2]; d.fbase = r[4]; d.flags = r[5];
+    d.area = __hiloint2double(r[7], r[6]);
+    return d;
+  };
+  auto fetch = [&](const Desc& d, int hslot, T s[5]) {   // the state of the lane's cell: its own, or the cell across a side
+    const int slot = side ? hslot : d.e0 + tid;
+#pragma unroll
+    for (int k = 0; k < 5; k++) s[k] = src.p[k][slot];
+  };
+
+  const int stride = nx;
+  Desc      d0 = load_desc(t), d1 = load_desc(t + stride);
+  int       hs_b = side ? P.halo_ids[d1.h0 + hl] : 0;
+  T         cur[5];
+  fetch(d0, side ? P.halo_ids[d0.h0 + hl] : 0, cur);
+  __builtin_amdgcn_s_waitcnt(0);   // (the prologue's loads must not become a wait inside the loop)
+
+  for (; t < tend; t += stride) {
+    const Desc d2   = load_desc(t + 2 * stride);
+    const int  hs_c = side ? P.halo_ids[d2.h0 + hl] : 0;
+    T          nxt[5];
+    if (t + stride < tend) fetch(d1, hs_b, nxt);
+    const int e = d0.e0 + c;
+    T         pv[5] = {T(0), T(0), T(0), T(0), T(0)}, volume = T(1);
+    if (!side) {
+      if (STAGE > 1) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) pv[k] = prev.p[k][e];
+      }
+      volume = vol[e];
+    }
+    const T area = static_cast<T>(d0.area);
+
+    // ---- phase 1: the record of the lane's cell (slot tid: cell lanes 0..255, cells across the sides 256..511) -------------
+    T mine[NW];
+    if (KIND == 0) {
+      prim_words<T>(cur, mine, lt);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 5; k++) mine[k] = cur[k];
+    }
+    rec_store<T, NW>(pe + tid * REC, mine);
+    __syncthreads();
+
+    // ---- phase 2 -----------------------------------------------------------------------------------------------------------
+    if (!side) {
+      T wr[NW], g[5], sx, sy;
+      rec_load<T, NW>(pe + rx * REC, wr);
+      patch_face3<T, KIND, NW>(0, mine, wr, area, g, sx);
+#pragma unroll
+      for (int k = 0; k < 5; k++) ff[k * kP3FF + c] = g[k];
+      rec_load<T, NW>(pe + ry * REC, wr);
+      if (sizeof(T) == 8) rec_load<T, NW>(pe + c * REC, mine);   // (fp64 register budget: the own record is read back, not held)
+      patch_face3<T, KIND, NW>(1, mine, wr, area, g, sy);
+#pragma unroll
+      for (int k = 0; k < 5; k++) ff[k * kP3FF + 256 + c] = g[k];
+      if (speed) {   // own faces: ids fbase + 3 t + {0, 1, 2} (+x, +y, +z)
+        speed[d0.fbase + 3 * c]     = sx;
+        speed[d0.fbase + 3 * c + 1] = sy;
+      }
+    } else {
+      {   // the +z face of cell c = tid - 256
+        T wl[NW], wr[NW], g[5], sz;
+        rec_load<T, NW>(pe + c * REC, wl);
+        rec_load<T, NW>(pe + rz * REC, wr);
+        patch_face3<T, KIND, NW>(2, wl, wr, area, g, sz);
+#pragma unroll
+        for (int k = 0; k < 5; k++) ff[k * kP3FF + 512 + c] = g[k];
+        if (speed) speed[d0.fbase + 3 * c + 2] = sz;
+      }
+      if (minus) {   // the - sides: left operand = the cell across, right = the patch's cell
+        T wl[NW], wr[NW], g[5], sm;
+        rec_load<T, NW>(pe + m_l * REC, wl);
+        rec_load<T, NW>(pe + m_r * REC, wr);
+        if (m < 64)
+          patch_face<T, KIND, NW>(minus_y, wl, wr, area, g, sm);   // wavefront 6: x / y per lane
+        else
+          patch_face3<T, KIND, NW>(2, wl, wr, area, g, sm);        // wavefront 7: z
+#pragma unroll
+        for (int k = 0; k < 5; k++) ff[k * kP3FF + 768 + m] = g[k];
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 3: six fluxes in ascending face id, RK stage ------------------------------------------------------------------
+    if (!side) {
+      const bool yx = f_yx ? (d0.flags & 1) != 0 : r_yx;   // -y before -x
+      const bool zx = f_zx ? (d0.flags & 2) != 0 : r_zx;   // -z before -x
+      const bool zy = f_zy ? (d0.flags & 4) != 0 : r_zy;   // -z before -y
+      const int  px = (yx ? 1 : 0) + (zx ? 1 : 0), py = (yx ? 0 : 1) + (zy ? 1 : 0);   // positions of -x, -y (the third: -z)
+      const int  a0 = px == 0 ? a_mx : (py == 0 ? a_my : a_mz);
+      const int  a1 = px == 1 ? a_mx : (py == 1 ? a_my : a_mz);
+      const int  a2 = px == 2 ? a_mx : (py == 2 ? a_my : a_mz);
+      T          acc[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        acc[k] = __builtin_fma(T(1), ff[k * kP3FF + a0], T(0));
+        acc[k] = __builtin_fma(T(1), ff[k * kP3FF + a1], acc[k]);
+        acc[k] = __builtin_fma(T(1), ff[k * kP3FF + a2], acc[k]);
+        acc[k] = __builtin_fma(T(-1), ff[k * kP3FF + c], acc[k]);
+        acc[k] = __builtin_fma(T(-1), ff[k * kP3FF + 256 + c], acc[k]);
+        acc[k] = __builtin_fma(T(-1), ff[k * kP3FF + 512 + c], acc[k]);
+      }
+      const T scale = dt / volume;
+#pragma unroll
+      for (int k = 0; k < 5; k++) out.p[k][e] = rk_stage_update<T, STAGE>(pv[k], cur[k], scale, acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) cur[k] = nxt[k];
+    d0   = d1;
+    d1   = d2;
+    hs_b = hs_c;
+  }
+}
+
+// tiles [tile_begin, tile_begin + tile_count) of tile_order must all be 3D patch tiles. persistent = false: one patch per
+// workgroup (class-split multi-rank launches).
+template <class T>
+int plain_patch3_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count, FVars<T> prev, FVars<T> mid,
+                       FVars<T> out, const T* volume, T dt, T* speed, bool persistent, hipStream_t stream) {
+  if (tile_count <= 0) return 0;
+  if (!plan->tile_desc) return static_cast<int>(hipErrorInvalidValue);
+  const int    nw  = kind == 0 ? kPrimWords : 5;
+  const int    rec = sizeof(T) == 8 ? (nw > 5 ? 10 : 6) : 12;
+  const size_t lds = sizeof(T) * (static_cast<size_t>(5) * kP3FF + static_cast<size_t>(rec) * 512) +
+                     ((sizeof(T) == 8 && kind == 0) ? 2 * kLogTabEntries * sizeof(double) : 0);
+  static int per_cu_env = -1, cus = 0;
+  if (cus == 0) {
+    int             dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return static_cast<int>(hipErrorInvalidDevice);
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const char* env = std::getenv("T8GPU_PATCH_WGS");
+    per_cu_env      = env ? std::atoi(env) : 0;
+    if (per_cu_env < 0 || per_cu_env > 8) per_cu_env = 0;
+  }
+  const int  per_cu    = per_cu_env > 0 ? per_cu_env : (sizeof(T) == 8 ? 2 : 3);
+  const int  resident  = cus * per_cu;
+  const int  grid_size = (!persistent || tile_count < resident) ? tile_count : resident;
+  const dim3 grid(grid_size), block(512);
+  note_stage_kernel(tile_count, "k_plain_patch3<T, K, S>", static_cast<int>(sizeof(T)), kind, stage);
+#define T8_P3(K, S)                                                                                                          \
+  do {                                                                                                                       \
+    if (lds > 64 * 1024) {                                                                                                   \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_plain_patch3<T, K, S>),                            \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                 \
+      if (e != hipSuccess) return static_cast<int>(e);                                                                       \
+    }                                                                                                                        \
+    hipLaunchKernelGGL((k_plain_patch3<T, K, S>), grid, block, lds, stream, *plan, tile_begin, tile_count, prev, mid, out, volume, dt, \
+                       speed);                                                                                               \
+  } while (0)
+#define T8_P3S(K)          \
+  do {                     \
+    if (stage == 1)        \
+      T8_P3(K, 1);         \
+    else if (stage == 2)   \
+      T8_P3(K, 2);         \
+    else                   \
+      T8_P3(K, 3);         \
+  } while (0)
+  if (kind == 0)
+    T8_P3S(0);
+  else if (kind == 1)
+    T8_P3S(1);
+  else
+    T8_P3S(2);
+#undef T8_P3S
+#undef T8_P3
+  return static_cast<int>(hipGetLastError());
+}
+
+template int plain_patch3_stage<float>(int, int, const T8gpuPlainPlan*, int, int, FVars<float>, FVars<float>, FVars<float>, const float*,
+                                       float, float*, bool, hipStream_t);
+template int plain_patch3_stage<double>(int, int, const T8gpuPlainPlan*, int, int, FVars<double>, FVars<double>, FVars<double>,
+                                        const double*, double, double*, bool, hipStream_t);
+
+}  // namespace t8gpu_hip

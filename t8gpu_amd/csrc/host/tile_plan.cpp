@@ -34,11 +34,19 @@ namespace {
 // the 64 elements across its four sides are listed in `halo` ([-x side by j | +x side by j | -y side by i | +y side by
 // i]), and an element adds its four fluxes in ascending face id: (-x, -y in the order of the owning neighbours' indices,
 // which inside the patch is a function of (i, j) alone -- patch_y_first), then +x, +y.
-constexpr int kPatchSide = 16, kPatchElems = 256, kPatchHalo = 64;
+//
+// 3D (find_patches3): 8 x 8 x 4 same-size hexahedra = 256 consecutive elements in Morton order (x = bit 0, y = bit 1, z =
+// bit 2 of every triple), six interior faces each, own faces +x / +y / +z with ids fbase + 3 t (+1, +2), 256 cells across
+// the six sides ([-x 32 by j + 8 k | +x 32 | -y 32 by i + 8 k | +y 32 | -z 64 by i + 8 j | +z 64]). The three - faces are
+// added in the order of the owning neighbours' indices: pairwise "-y before -x" iff ctz(j) >= ctz(i), "-z before -x" iff
+// ctz(k) >= ctz(i), "-z before -y" iff ctz(k) >= ctz(j); where BOTH coordinates of a pair are 0 the patch's position in
+// the forest decides -- three flag bits per patch (bit 0: y before x, bit 1: z before x, bit 2: z before y).
+constexpr int kPatchSide = 16, kPatchElems = 256, kPatchHalo = 64, kPatchHalo3 = 256;
 struct Patch {
-  int32_t e0 = 0, fbase = 0, flags = 0;   // flags bit 0: element 0 adds its -y face before its -x face
+  int32_t e0 = 0, fbase = 0, flags = 0;   // 2D: flags bit 0: element 0 adds its -y face before its -x face; 3D: see above
+  int32_t dim = 2, nh = kPatchHalo;
   double  area = 0;
-  int32_t halo[kPatchHalo];
+  int32_t halo[kPatchHalo3];
 };
 
 inline int morton2(int i, int j) {
@@ -163,6 +171,102 @@ void find_patches(TilePlan& P, const int32_t* fn, const double* normals, const d
   }
 }
 
+inline int morton3(int i, int j, int k) {   // 8 x 8 x 4: x bits 0, 3, 6; y bits 1, 4, 7; z bits 2, 5
+  int t = 0;
+  for (int b = 0; b < 3; b++) t |= ((i >> b) & 1) << (3 * b) | ((j >> b) & 1) << (3 * b + 1);
+  for (int b = 0; b < 2; b++) t |= ((k >> b) & 1) << (3 * b + 2);
+  return t;
+}
+inline int ctz_or(int v, int big) { return v == 0 ? big : __builtin_ctz(static_cast<unsigned>(v)); }
+
+// 3D structured patches (see the comment at struct Patch). Same policy as find_patches: every expectation is checked per
+// element against the arrays, anything else leaves the block to the generic tiles.
+void find_patches3(TilePlan& P, const int32_t* fn, const double* normals, const double* areas, const std::vector<int32_t>& deg,
+                   const std::vector<int32_t>& ef) {
+  const int32_t N = P.N, F = P.F;
+  if (P.ndim != 3) return;
+  int li[kPatchElems], lj[kPatchElems], lk[kPatchElems];
+  for (int t = 0; t < kPatchElems; t++) {
+    li[t] = lj[t] = lk[t] = 0;
+    for (int b = 0; b < 3; b++) {
+      li[t] |= ((t >> (3 * b)) & 1) << b;
+      lj[t] |= ((t >> (3 * b + 1)) & 1) << b;
+    }
+    for (int b = 0; b < 2; b++) lk[t] |= ((t >> (3 * b + 2)) & 1) << b;
+  }
+  auto axis_of = [&](int32_t f) -> int {   // 0 / 1 / 2: exactly +e_x / +e_y / +e_z, -1: anything else
+    const double* n = normals + static_cast<size_t>(3) * f;
+    const int nz = (n[0] != 0.0) + (n[1] != 0.0) + (n[2] != 0.0);
+    if (nz != 1) return -1;
+    for (int a = 0; a < 3; a++)
+      if (n[a] == 1.0) return a;
+    return -1;
+  };
+  int32_t e0 = 0;
+  while (e0 + kPatchElems <= N) {
+    Patch pt;
+    pt.dim = 3;
+    pt.nh  = kPatchHalo3;
+    bool ok = true;
+    for (int t = 0; t < kPatchElems && ok; t++) {
+      const int32_t e = e0 + t;
+      ok = deg[e + 1] - deg[e] == 6;
+      if (!ok) break;
+      const int32_t* fl = &ef[deg[e]];
+      int32_t        own[3] = {-1, -1, -1}, far[3] = {-1, -1, -1};
+      for (int q = 0; q < 6 && ok; q++) {
+        const int32_t f = fl[q];
+        const int     ax = f < F ? axis_of(f) : -1;
+        if (ax < 0) { ok = false; break; }
+        const int32_t l = fn[2 * static_cast<size_t>(f)], r = fn[2 * static_cast<size_t>(f) + 1];
+        if (l == r) ok = false;
+        else if (l == e && own[ax] < 0) own[ax] = f;
+        else if (r == e && far[ax] < 0) far[ax] = f;
+        else ok = false;
+      }
+      for (int a = 0; a < 3; a++) ok = ok && own[a] >= 0 && far[a] >= 0;
+      if (!ok) break;
+      if (t == 0) {
+        pt.e0    = e0;
+        pt.fbase = own[0];
+        pt.area  = areas[own[0]];
+      }
+      for (int q = 0; q < 6; q++) ok = ok && areas[fl[q]] == pt.area;
+      for (int a = 0; a < 3; a++) ok = ok && own[a] == pt.fbase + 3 * t + a && fl[3 + a] == own[a];
+      if (!ok) break;
+      const int i = li[t], j = lj[t], k = lk[t];
+      // position of every - face among the three (ascending face id = ascending index of the owning neighbour)
+      int pos[3] = {0, 0, 0};
+      for (int a = 0; a < 3; a++)
+        for (int q = 0; q < 3; q++)
+          if (fl[q] == far[a]) pos[a] = q;
+      const bool yx = pos[1] < pos[0], zx = pos[2] < pos[0], zy = pos[2] < pos[1];
+      if (t == 0) pt.flags = (yx ? 1 : 0) | (zx ? 2 : 0) | (zy ? 4 : 0);
+      // the rule, with the patch's flags where both coordinates of a pair are 0 (their ctz is then the forest's business)
+      const bool ryx = (i == 0 && j == 0) ? (pt.flags & 1) != 0 : ctz_or(j, 8) >= ctz_or(i, 8);
+      const bool rzx = (i == 0 && k == 0) ? (pt.flags & 2) != 0 : ctz_or(k, 8) >= ctz_or(i, 8);
+      const bool rzy = (j == 0 && k == 0) ? (pt.flags & 4) != 0 : ctz_or(k, 8) >= ctz_or(j, 8);
+      ok = ok && yx == ryx && zx == rzx && zy == rzy;
+      const int32_t pl[3] = {fn[2 * static_cast<size_t>(own[0]) + 1], fn[2 * static_cast<size_t>(own[1]) + 1], fn[2 * static_cast<size_t>(own[2]) + 1]};
+      const int32_t mi[3] = {fn[2 * static_cast<size_t>(far[0])], fn[2 * static_cast<size_t>(far[1])], fn[2 * static_cast<size_t>(far[2])]};
+      auto outside       = [&](int32_t s) { return s < e0 || s >= e0 + kPatchElems; };
+      auto owned_outside = [&](int32_t s) { return s < N && (s < e0 || s >= e0 + kPatchElems); };   // (see find_patches)
+      if (i < 7) ok = ok && pl[0] == e0 + morton3(i + 1, j, k); else { ok = ok && outside(pl[0]); pt.halo[32 + j + 8 * k] = pl[0]; }
+      if (i > 0) ok = ok && mi[0] == e0 + morton3(i - 1, j, k); else { ok = ok && owned_outside(mi[0]); pt.halo[j + 8 * k] = mi[0]; }
+      if (j < 7) ok = ok && pl[1] == e0 + morton3(i, j + 1, k); else { ok = ok && outside(pl[1]); pt.halo[96 + i + 8 * k] = pl[1]; }
+      if (j > 0) ok = ok && mi[1] == e0 + morton3(i, j - 1, k); else { ok = ok && owned_outside(mi[1]); pt.halo[64 + i + 8 * k] = mi[1]; }
+      if (k < 3) ok = ok && pl[2] == e0 + morton3(i, j, k + 1); else { ok = ok && outside(pl[2]); pt.halo[192 + i + 8 * j] = pl[2]; }
+      if (k > 0) ok = ok && mi[2] == e0 + morton3(i, j, k - 1); else { ok = ok && owned_outside(mi[2]); pt.halo[128 + i + 8 * j] = mi[2]; }
+    }
+    if (ok) {
+      P.patches.push_back(pt);
+      e0 += kPatchElems;
+    } else {
+      e0++;
+    }
+  }
+}
+
 void build(TilePlan& P, const int32_t* fn, const double* normals, const double* areas) {
   const int32_t N = P.N, F = P.F, B = P.B;
   const bool verbose = std::getenv("T8GPU_PLAN_VERBOSE") != nullptr;
@@ -198,7 +302,8 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
   };
 
   lap("element -> faces");
-  if (P.want_patches) find_patches(P, fn, normals, areas, deg, ef);
+  if (P.want_patches & 1) find_patches(P, fn, normals, areas, deg, ef);
+  if ((P.want_patches & 2) && P.patches.empty()) find_patches3(P, fn, normals, areas, deg, ef);
   std::vector<int32_t> patch_at(static_cast<size_t>(N) + 1, -1);   // patch that starts at an element
   for (size_t k = 0; k < P.patches.size(); k++) patch_at[P.patches[k].e0] = static_cast<int32_t>(k);
   lap("patches");
@@ -299,7 +404,7 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
     const int32_t e0 = P.elem_off[t], e1 = P.elem_off[t + 1];
     if (P.tile_patch[t] >= 0) {   // no face records; the 64 elements across the sides in the patch kernel's fixed order
       tf.clear();
-      halo.assign(P.patches[P.tile_patch[t]].halo, P.patches[P.tile_patch[t]].halo + kPatchHalo);
+      halo.assign(P.patches[P.tile_patch[t]].halo, P.patches[P.tile_patch[t]].halo + P.patches[P.tile_patch[t]].nh);
       return;
     }
     tf.assign(ef.begin() + deg[e0], ef.begin() + deg[e1]);
@@ -523,7 +628,7 @@ void* t8gpu_plan_plain_create_ex(int32_t N, int32_t G, int32_t F, int32_t B, int
   if (N < 0 || F < 0 || B < 0 || ndim < 2 || ndim > 3 || tmax < 1 || tmax > 1024 || fcap < 1) return nullptr;
   TilePlan* P = new TilePlan;
   P->N = N; P->G = G; P->F = F; P->B = B; P->ndim = ndim; P->tmax = tmax; P->fcap = fcap;
-  P->want_patches = flags & 1;
+  P->want_patches = flags & 3;   // bit 0: 2D patches (16 x 16), bit 1: 3D patches (8 x 8 x 4)
   build(*P, fn, normals, areas);
   if (P->max_elems + P->max_halo >= 0xFFFF || P->max_faces > 0x7FFE) {
     delete P;
@@ -542,6 +647,11 @@ void t8gpu_plan_plain_patch_counts(const void* h, int32_t* counts) {
   const TilePlan* P = static_cast<const TilePlan*>(h);
   for (int c = 0; c < 3; c++) counts[c] = P->n_patch_class[c];
   counts[3] = static_cast<int32_t>(P->patches.size());
+}
+// 2 or 3: the kind of the plan's patch tiles (one kind per plan); 0: none
+int32_t t8gpu_plan_plain_patch_dim(const void* h) {
+  const TilePlan* P = static_cast<const TilePlan*>(h);
+  return P->patches.empty() ? 0 : P->patches[0].dim;
 }
 
 // sizes[16] = {ntiles, n_halo, n_faces, n_csr, max_elems, max_halo, max_faces, n_interior_tiles, N, F,
@@ -583,10 +693,10 @@ void t8gpu_plan_plain_tile_desc(const void* h, int32_t* tile_desc) {
     d[2] = P->halo_off[t]; d[3] = P->halo_off[t + 1] - P->halo_off[t];
     d[4] = P->face_off[t]; d[5] = P->face_off[t + 1] - P->face_off[t];
     d[6] = d[7] = 0;
-    if (!P->tile_patch.empty() && P->tile_patch[t] >= 0) {   // patch tile: {e0, 256, first halo entry, 64, fbase, 0x100 | flags, area}
+    if (!P->tile_patch.empty() && P->tile_patch[t] >= 0) {   // patch tile: {e0, 256, first halo entry, 64 | 256, fbase, 0x100 | 0x200 (3D) | flags, area}
       const Patch& pt = P->patches[P->tile_patch[t]];
       d[4] = pt.fbase;
-      d[5] = 0x100 | pt.flags;
+      d[5] = 0x100 | (pt.dim == 3 ? 0x200 : 0) | pt.flags;
       std::memcpy(d + 6, &pt.area, 8);
     }
   }

@@ -17,6 +17,8 @@ def _lib():
         lib.t8gpu_plan_plain_create_ex.restype = C.c_void_p
         lib.t8gpu_plan_plain_create_ex.argtypes = [C.c_int32] * 5 + [C.c_void_p] * 3 + [C.c_int32] * 3
         lib.t8gpu_plan_plain_patch_counts.argtypes = [C.c_void_p] * 2
+        lib.t8gpu_plan_plain_patch_dim.argtypes = [C.c_void_p]
+        lib.t8gpu_plan_plain_patch_dim.restype = C.c_int32
         lib.t8gpu_plan_plain_destroy.argtypes = [C.c_void_p]
         lib.t8gpu_plan_plain_sizes.argtypes = [C.c_void_p, C.c_void_p]
         lib.t8gpu_plan_plain_arrays.argtypes = [C.c_void_p] * 11
@@ -44,7 +46,9 @@ class HostPlainPlan:
         ar = np.ascontiguousarray(areas, np.float64)
         assert fn.size == 2 * F + B and nr.size == ndim * (F + B) and ar.size == F + B
         p = _synth._p
-        h = lib.t8gpu_plan_plain_create_ex(N, G, F, B, ndim, p(fn), p(nr), p(ar), tmax, fcap, 1 if patches else 0)
+        # patches: True = both kinds (16 x 16 quadrilateral blocks, 8 x 8 x 4 hexahedral blocks), 2 / 3 = that kind only
+        pflags = {False: 0, True: 3, 2: 1, 3: 2}[patches]
+        h = lib.t8gpu_plan_plain_create_ex(N, G, F, B, ndim, p(fn), p(nr), p(ar), tmax, fcap, pflags)
         if not h:
             raise ValueError("tile plan exceeds the packed index format (use smaller tmax / fcap)")
         try:
@@ -77,6 +81,7 @@ class HostPlainPlan:
             cnt = np.zeros(4, np.int32)
             lib.t8gpu_plan_plain_patch_counts(h, p(cnt))
             self.n_patch_class, self.n_patches = tuple(int(x) for x in cnt[:3]), int(cnt[3])
+            self.patch_dim = int(lib.t8gpu_plan_plain_patch_dim(h))            # 2 | 3 | 0 (no patch tiles)
             # per tile (index, not position): is it a patch tile? (tile_desc is in tile_order order)
             self.tile_patch = np.zeros(self.ntiles, bool)
             if self.ntiles:

@@ -56,6 +56,38 @@ def test_patch_kernel_vs_oracle_and_bitwise_vs_tile_kernels(dtype, kind, mesh_ar
     assert torch.equal(a.state(), b.state()) and torch.equal(a.speed, b.speed)
 
 
+MESHES3 = [dict(dim=3, base_level=5, max_level=5), dict(dim=3, base_level=4, max_level=6, band=0.1),
+           dict(dim=3, base_level=5, max_level=5, periodic=False)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kind", [hip.KEPES, hip.HLL, hip.HLLC])
+@pytest.mark.parametrize("mesh_args", MESHES3)
+def test_patch3_kernel_vs_oracle_and_bitwise_vs_tile_kernels(dtype, kind, mesh_args):
+    """The 3D patch kernel (kernels_fused_patch3.hip: 8 x 8 x 4 blocks of same-size hexahedra) on uniform, 2:1-refined and
+    walled hexahedral meshes: within the parity tolerance of the oracle, bit for bit the tile kernels (states, speeds)."""
+    mesh = SynthMesh(**mesh_args)
+    part = mesh.partition()
+    st = perturbed_state(part, 41)
+    a, b = _pair(part, dtype, kind, st)
+    assert a.plan.host.patch_dim == 3
+    o = O.PlainCase(part, NP[dtype], state=st)
+    dt = 0.1 * 2.0 ** -mesh.finest_level
+    a.iterate(dt)
+    b.iterate(dt)
+    o.iterate(dt, kind=kind)
+    torch.cuda.synchronize()
+    assert rel_err(a.state().cpu().numpy(), o.current()[:, :part.N]) < TOL1[dtype]
+    assert rel_err(a.speed.cpu().numpy()[None, :part.F + part.B], o.speed[None]) < TOL1[dtype] * 10
+    assert torch.equal(a.state(), b.state()) and torch.equal(a.speed, b.speed)
+    for _ in range(9):
+        a.iterate(dt)
+        b.iterate(dt)
+        o.iterate(dt, kind=kind)
+    assert rel_err(a.state().cpu().numpy(), o.current()[:, :part.N]) < TOL10[dtype]
+    assert torch.equal(a.state(), b.state()) and torch.equal(a.speed, b.speed)
+
+
 def test_patch_kernel_through_the_native_stepper_and_one_patch_per_workgroup():
     """The C++ step driver (whole-plan launches: persistent grids) and explicit partial ranges (one patch per workgroup,
     what a class-split multi-rank stage launches) give the same bits."""
@@ -85,13 +117,14 @@ def test_patch_kernel_through_the_native_stepper_and_one_patch_per_workgroup():
     assert not torch.isnan(c.planes).any() and torch.equal(c.planes, d.planes)
 
 
-def test_patch_plan_on_a_partition_is_bitwise_the_single_rank_run():
+@pytest.mark.parametrize("mesh_args", [dict(dim=2, base_level=4, max_level=8, band=0.12), dict(dim=3, base_level=4, max_level=6, band=0.1)])
+def test_patch_plan_on_a_partition_is_bitwise_the_single_rank_run(mesh_args):
     """A 3-way SFC partition with patches on every rank (ghosts across the + sides of patches, patch tiles in several
     tile classes, interior / ghost-reading ranges launched separately) through the loopback transport of
-    tests/test_gpu_halo.py: bitwise the single-rank run without patches."""
+    tests/test_gpu_halo.py: bitwise the single-rank run without patches. 2D and 3D patches."""
     from test_gpu_halo import loopback
     from t8gpu_amd.halo import HaloExchange
-    mesh = SynthMesh(2, 4, 8, band=0.12)
+    mesh = SynthMesh(**mesh_args)
     whole = mesh.partition()
     st = perturbed_state(whole, 17)
     ref = PlainSolver(whole, torch.float64, mode="fused", state=st, plan_options=dict(patches=False))
@@ -106,7 +139,7 @@ def test_patch_plan_on_a_partition_is_bitwise_the_single_rank_run():
         halos.append(HaloExchange(part, torch.float64, dist=None, overlap=False))
     assert all(s.plan.host.n_patches > 0 for s in solvers)
     assert sum(s.plan.host.n_patch_class[1] + s.plan.host.n_patch_class[2] for s in solvers) > 0   # not only deep patches
-    dt = 0.1 * 2.0 ** -8
+    dt = 0.1 * 2.0 ** -mesh.finest_level
     for _ in range(3):
         ref.iterate(dt)
         for s in solvers:

@@ -50,6 +50,57 @@ def interpret_patch(plan, t, state, net, reporters):
             reporters += [fbase + 2 * _morton(i, j), fbase + 2 * _morton(i, j) + 1]
 
 
+def _morton3(i, j, k):
+    t = 0
+    for b in range(3):
+        t |= ((i >> b) & 1) << (3 * b) | ((j >> b) & 1) << (3 * b + 1)
+    for b in range(2):
+        t |= ((k >> b) & 1) << (3 * b + 2)
+    return t
+
+
+def interpret_patch3(plan, t, state, net, reporters):
+    """An 8 x 8 x 4 patch tile as kernels_fused_patch3.hip evaluates it: the descriptor and the 256 cells across the six
+    sides; neighbours, face ids and the order of the three - faces follow from (i, j, k) and three flag bits."""
+    pos = int(np.flatnonzero(plan.tile_order == t)[0])
+    d = plan.tile_desc[pos]
+    e0, ne, h0, nh, fbase, flags = (int(x) for x in d[:6])
+    assert ne == 256 and nh == 256 and (flags & 0x300) == 0x300 and e0 == plan.elem_off[t] and h0 == plan.halo_off[t]
+    area = float(d[6:8].copy().view(np.float64)[0])
+    halo = plan.halo_ids[h0:h0 + 256]
+    ax = [np.array([[1.0, 0.0, 0.0]]), np.array([[0.0, 1.0, 0.0]]), np.array([[0.0, 0.0, 1.0]])]
+
+    def flux(a, l, r):
+        return area * O.xyz_face_flux(0, ax[a], state[:, [l]].T.copy(), state[:, [r]].T.copy())[0]
+
+    def ctz(v):
+        return 8 if v == 0 else (v & -v).bit_length() - 1
+
+    for i in range(8):
+        for j in range(8):
+            for k in range(4):
+                c = _morton3(i, j, k)
+                e = e0 + c
+                plus = [e0 + _morton3(i + 1, j, k) if i < 7 else halo[32 + j + 8 * k],
+                        e0 + _morton3(i, j + 1, k) if j < 7 else halo[96 + i + 8 * k],
+                        e0 + _morton3(i, j, k + 1) if k < 3 else halo[192 + i + 8 * j]]
+                minus = [e0 + _morton3(i - 1, j, k) if i > 0 else halo[j + 8 * k],
+                         e0 + _morton3(i, j - 1, k) if j > 0 else halo[64 + i + 8 * k],
+                         e0 + _morton3(i, j, k - 1) if k > 0 else halo[128 + i + 8 * j]]
+                fm = [flux(a, minus[a], e) for a in range(3)]
+                fp = [flux(a, e, plus[a]) for a in range(3)]
+                yx = bool(flags & 1) if (i == 0 and j == 0) else ctz(j) >= ctz(i)
+                zx = bool(flags & 2) if (i == 0 and k == 0) else ctz(k) >= ctz(i)
+                zy = bool(flags & 4) if (j == 0 and k == 0) else ctz(k) >= ctz(j)
+                px, py = int(yx) + int(zx), int(not yx) + int(zy)
+                pz = 3 - px - py
+                order = sorted(range(3), key=lambda a: (px, py, pz)[a])
+                acc = fm[order[0]] + fm[order[1]]
+                acc = acc + fm[order[2]]
+                net[:, e] = ((acc - fp[0]) - fp[1]) - fp[2]
+                reporters += [fbase + 3 * c, fbase + 3 * c + 1, fbase + 3 * c + 2]
+
+
 def interpret(plan, part, state, reporters=None):
     """Net flux per owned element exactly as the fused kernels accumulate it (fp64, oracle flux)."""
     N = part.N
@@ -57,7 +108,7 @@ def interpret(plan, part, state, reporters=None):
     reporters = [] if reporters is None else reporters
     for t in range(plan.ntiles):
         if plan.tile_patch[t]:
-            interpret_patch(plan, t, state, net, reporters)
+            (interpret_patch3 if plan.patch_dim == 3 else interpret_patch)(plan, t, state, net, reporters)
             continue
         e0, e1 = plan.elem_off[t], plan.elem_off[t + 1]
         halo = plan.halo_ids[plan.halo_off[t]:plan.halo_off[t + 1]]
@@ -90,7 +141,9 @@ def interpret(plan, part, state, reporters=None):
                                                      (dict(dim=2, base_level=3, max_level=6, band=0.06), 3, False),
                                                      (dict(dim=2, base_level=4, max_level=7, band=0.12), 1, True),
                                                      (dict(dim=2, base_level=6, max_level=6, periodic=False), 1, True),
-                                                     (dict(dim=2, base_level=4, max_level=7, band=0.12), 3, True)])
+                                                     (dict(dim=2, base_level=4, max_level=7, band=0.12), 3, True),
+                                                     (dict(dim=3, base_level=3, max_level=5, band=0.12), 1, True),
+                                                     (dict(dim=3, base_level=5, max_level=5, periodic=False), 2, True)])
 def test_plan_reproduces_the_face_loop(mesh_args, ranks, patches):
     mesh = SynthMesh(**mesh_args)
     n_patches = 0
