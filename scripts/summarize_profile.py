@@ -57,20 +57,25 @@ def main(out):
         w = ws[0] / ws[1] if ws[1] else 0.0
         print(f"| {k} | {f:.0f} | {2 * f * 1024 / 1e6:.1f} | {w:.0f} | {w * 1024 / 1e6:.1f} | {(2 * f + w) * 1024 / 1e6:.1f} |")
     # machine-readable traffic per launch of the dominant kernel family (bench.py reports it as roofline.traffic)
-    # the dominant kernel FAMILY (name up to '<') = the one with the largest total duration in the kernel trace; its
-    # instances (one per RK stage) are what bench.py's roofline refers to
-    fam_ns = defaultdict(float)
-    for r in kernel_stats(os.path.join(out, "stats")):
-        n = short(r["Name"])
-        if n.startswith("k_"):
-            fam_ns[n.split("<")[0]] += float(r["TotalDurationNs"])
-    top = max(fam_ns, key=fam_ns.get) if fam_ns else None
-    dom = [k for k in sorted(set(fetch) | set(write)) if top and k.split("<")[0] == top]
+    # The stage kernels: every family (name up to '<') of this library's fused-stage kernels that appears in the trace. One
+    # RK stage launches one kernel of each family (e.g. k_plain_patch3 + k_plain_persistent on a 3D mesh), so the HBM
+    # bytes of a STAGE -- what bench.py divides by its event-timed stage duration -- are the sum over the families of the
+    # family's mean bytes per launch (mean over its three stage instances).
+    stage_prefixes = ("k_plain_stage", "k_plain_patch", "k_plain_persistent", "k_plain_fused", "k_subgrid_family", "k_subgrid_fused",
+                      "k_subgrid444_fused", "k_flux_faces", "k_subgrid_inner")
+    fams = defaultdict(list)
+    for k in sorted(set(fetch) | set(write)):
+        if k.startswith(stage_prefixes):
+            fams[k.split("<")[0]].append(k)
+    dom = [k for ks in fams.values() for k in ks]
     if dom:
         tot = 0.0
-        for k in dom:
-            fs, ws = fetch[k]["FETCH_SIZE"], write[k]["WRITE_SIZE"]
-            tot += (2 * (fs[0] / fs[1] if fs[1] else 0.0) + (ws[0] / ws[1] if ws[1] else 0.0)) * 1024
+        for ks in fams.values():
+            fam_tot = 0.0
+            for k in ks:
+                fs, ws = fetch[k]["FETCH_SIZE"], write[k]["WRITE_SIZE"]
+                fam_tot += (2 * (fs[0] / fs[1] if fs[1] else 0.0) + (ws[0] / ws[1] if ws[1] else 0.0)) * 1024
+            tot += fam_tot / len(ks)
         # utilisation from the SQ pass (MI355X_MICROARCH.md: SQ_* count quad-cycles summed over the chip's 1024 SIMDs;
         # GRBM_GUI_ACTIVE is the sum over the 8 XCDs): VALU busy = ACTIVE_INST_VALU * 4 / 1024 / (GUI_ACTIVE / 8)
         def mean(k, n):
@@ -85,7 +90,7 @@ def main(out):
             if mean(k, "SQ_LDS_IDX_ACTIVE") > 0:
                 confl.append(mean(k, "SQ_LDS_BANK_CONFLICT") / mean(k, "SQ_LDS_IDX_ACTIVE"))
         with open(os.path.join(out, "traffic.json"), "w") as fjs:
-            json.dump({"kernels": dom, "avg_hbm_bytes_per_launch": tot / len(dom),
+            json.dump({"kernels": dom, "avg_hbm_bytes_per_launch": tot,
                        "valu_busy": round(sum(busy) / len(busy), 4) if busy else None,
                        "lds_conflict_frac": round(sum(confl) / len(confl), 4) if confl else None,
                        "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 (gfx950), KiB -> bytes"}, fjs)
