@@ -163,7 +163,10 @@ typedef struct T8gpuPlainPlan {
    * They have no face records; their tile_desc is {first element, 256, first halo entry, 64, id of the first own face,
    * 0x100 | flags, area as a double}, their 64 halo entries the elements across the -x | +x | -y | +y sides. The first
    * n_patch_tiles[c] tiles of class c of tile_order (c = 0: [0, n_deep_tiles), 1: [n_deep_tiles, n_interior_tiles),
-   * 2: the rest) are patch tiles; they run through kernels_fused_patch.hip. All zero: no patches. */
+   * 2: the rest) are patch tiles; they run through kernels_fused_patch.hip. All zero: no patches.
+   * Flag 0x400 in word 5 of a patch descriptor: every element of the patch has one volume, carried as a double in words
+   * 1 and 3 (the planner checked the volumes it was given, t8gpu_plan_plain_patch_volumes); the kernels then do not read
+   * `volume[]` for that patch -- rebuild the plan if the volumes change. */
   int32_t n_patch_tiles[3];
   int32_t patch_dim;          /* 2: the 16 x 16 patches above; 3: 8 x 8 x 4 blocks of same-size hexahedra (256 halo entries:
                                * -x 32 | +x 32 | -y 32 | +y 32 | -z 64 | +z 64; own faces fbase + 3 t + {0, 1, 2}; flags bits 0-2:

@@ -72,6 +72,10 @@ void  t8gpu_plan_plain_patch_counts(const void* plan, int32_t* counts);
  * 0x300 | flags, area}, halo = [-x 32 | +x 32 | -y 32 | +y 32 | -z 64 | +z 64]. A plan holds one kind of patch.
  * 2 | 3: the kind of the plan's patch tiles, 0: none */
 int32_t t8gpu_plan_plain_patch_dim(const void* plan);
+/* Optional, between create and t8gpu_plan_plain_tile_desc: volumes[N] of the owned elements. A patch whose 256 elements
+ * have bit for bit one volume carries it in its descriptor (flag 0x400; words 1 and 3 then hold the double instead of
+ * the implied counts 256 and 64 | 256) and the patch kernels skip the per-element volume load. Returns their number. */
+int32_t t8gpu_plan_plain_patch_volumes(void* plan, const double* volumes);
 /* sizes[16] (12 = max over the generic tiles of own + halo elements, 13 = number of deep-interior tiles, 14 = number of patch tiles, 15 reserved = 0; the maxima 4-6 are over the generic tiles) = {ntiles, n_halo, n_faces, n_csr, max_elems, max_halo, max_faces, n_interior_tiles, N, F,
  *              ell_width, n_geo} */
 void t8gpu_plan_plain_sizes(const void* plan, int64_t* sizes);

@@ -85,7 +85,7 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
   typedef int int8v __attribute__((ext_vector_type(8)));
   struct Desc {
     int    e0, h0, fbase, flags;
-    double area;
+    double area, vol;   // vol: the patch's uniform element volume where flags has 0x400 (tile_plan.cpp), else unused
   };
   auto load_desc = [&](int tt) {   // scalar load through the constant address space (see k_plain_persistent)
 #ifdef T8GPU_EXP_TILEMOD   // experiment builds only: every patch is one of the first few, all traffic stays in the caches
@@ -98,6 +98,7 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
     Desc d;
     d.e0 = r[0]; d.h0 = r[2]; d.fbase = r[4]; d.flags = r[5];
     d.area = __hiloint2double(r[7], r[6]);
+    d.vol  = __hiloint2double(r[3], r[1]);
     return d;
   };
   struct Pre {
@@ -136,7 +137,8 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
 #pragma unroll
       for (int k = 0; k < 5; k++) pv[k] = prev.p[k][e];
     }
-    const T volume = vol[e];
+    // (patches of uniform volume carry it in their descriptor: 8 of ~130 bytes per element and stage less to load)
+    const T volume = (d0.flags & 0x400) ? static_cast<T>(d0.vol) : vol[e];
     const T area   = static_cast<T>(d0.area);
 
     // ---- phase 1: records of the own cell and (wave 3) of the cells across the sides ----------------------------------

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
   typedef int int8v __attribute__((ext_vector_type(8)));
   struct Desc {
     int    e0, h0, fbase, flags;
-    double area;
+    double area, vol;   // vol: the patch's uniform element volume where flags has 0x400 (tile_plan.cpp), else unused
   };
   auto load_desc = [&](int tt) {   // scalar load through the constant address space (see k_plain_persistent)
 #ifdef T8GPU_EXP_TILEMOD
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
     Desc d;
     d.e0 = r[0]; d.h0 = r[2]; d.fbase = r[4]; d.flags = r[5];
     d.area = __hiloint2double(r[7], r[6]);
+    d.vol  = __hiloint2double(r[3], r[1]);
     return d;
   };
   auto fetch = [&](const Desc& d, int hslot, T s[5]) {   // the state of the lane's cell: its own, or the cell across a side
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
 #pragma unroll
         for (int k = 0; k < 5; k++) pv[k] = prev.p[k][e];
       }
-      volume = vol[e];
+      volume = (d0.flags & 0x400) ? static_cast<T>(d0.vol) : vol[e];   // (uniform patch volume from the descriptor)
     }
     const T area = static_cast<T>(d0.area);
 

@@ -46,6 +46,7 @@ struct Patch {
   int32_t e0 = 0, fbase = 0, flags = 0;   // 2D: flags bit 0: element 0 adds its -y face before its -x face; 3D: see above
   int32_t dim = 2, nh = kPatchHalo;
   double  area = 0;
+  double  volume = 0;        // > 0: every element of the patch has exactly this volume (t8gpu_plan_plain_patch_volumes)
   int32_t halo[kPatchHalo3];
 };
 
@@ -648,6 +649,23 @@ void t8gpu_plan_plain_patch_counts(const void* h, int32_t* counts) {
   for (int c = 0; c < 3; c++) counts[c] = P->n_patch_class[c];
   counts[3] = static_cast<int32_t>(P->patches.size());
 }
+// Optional, after create and before t8gpu_plan_plain_tile_desc: volumes[N] of the owned elements. A patch whose 256 elements
+// all have bit for bit the same volume gets it into its descriptor (flag 0x400, words 1 and 3), and the kernels then skip
+// the per-element volume load (8 of ~130 bytes per element and stage); any other patch keeps the load. Returns the number
+// of patches with a uniform volume.
+int32_t t8gpu_plan_plain_patch_volumes(void* h, const double* volumes) {
+  TilePlan* P = static_cast<TilePlan*>(h);
+  int32_t   n = 0;
+  if (!volumes) return 0;
+  for (Patch& pt : P->patches) {
+    const double v = volumes[pt.e0];
+    bool         same = v > 0.0;
+    for (int t = 1; t < kPatchElems && same; t++) same = volumes[pt.e0 + t] == v;
+    pt.volume = same ? v : 0.0;
+    n += same ? 1 : 0;
+  }
+  return n;
+}
 // 2 or 3: the kind of the plan's patch tiles (one kind per plan); 0: none
 int32_t t8gpu_plan_plain_patch_dim(const void* h) {
   const TilePlan* P = static_cast<const TilePlan*>(h);
@@ -698,6 +716,13 @@ void t8gpu_plan_plain_tile_desc(const void* h, int32_t* tile_desc) {
       d[4] = pt.fbase;
       d[5] = 0x100 | (pt.dim == 3 ? 0x200 : 0) | pt.flags;
       std::memcpy(d + 6, &pt.area, 8);
+      if (pt.volume > 0.0) {   // uniform volume: flag 0x400, the double in words 1 and 3 (element / halo counts are implied)
+        int32_t w[2];
+        std::memcpy(w, &pt.volume, 8);
+        d[5] |= 0x400;
+        d[1] = w[0];
+        d[3] = w[1];
+      }
     }
   }
 }

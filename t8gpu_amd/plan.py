@@ -19,6 +19,8 @@ def _lib():
         lib.t8gpu_plan_plain_patch_counts.argtypes = [C.c_void_p] * 2
         lib.t8gpu_plan_plain_patch_dim.argtypes = [C.c_void_p]
         lib.t8gpu_plan_plain_patch_dim.restype = C.c_int32
+        lib.t8gpu_plan_plain_patch_volumes.argtypes = [C.c_void_p, C.c_void_p]
+        lib.t8gpu_plan_plain_patch_volumes.restype = C.c_int32
         lib.t8gpu_plan_plain_destroy.argtypes = [C.c_void_p]
         lib.t8gpu_plan_plain_sizes.argtypes = [C.c_void_p, C.c_void_p]
         lib.t8gpu_plan_plain_arrays.argtypes = [C.c_void_p] * 11
@@ -35,7 +37,7 @@ class HostPlainPlan:
               "csr_ent", "tile_order")
 
     def __init__(self, N, G, F, B, ndim, face_neighbors, normals, areas, tmax=256, fcap=512, want_face_geo=True,
-                 patches=False):
+                 patches=False, volumes=None):
         """patches=True: structured 16 x 16 patches are cut out of the tiling (tile_plan.cpp: find_patches); they are
         tiles without face records (`tile_patch[t]` = 1), first inside every class of `tile_order` (`n_patch_class`).
         want_face_geo=False: leave `face_geo` (32 bytes per tile face, only read by the kernels that have no geometry
@@ -75,6 +77,11 @@ class HostPlainPlan:
             self.geo_table = np.zeros((n_geo, 12), np.float64)
             lib.t8gpu_plan_plain_compressed(h, p(self.ell), p(self.geo_idx) if n_geo else None,
                                             p(self.geo_table) if n_geo else None)
+            # volumes of the owned elements (optional): patches of uniform volume carry it in their descriptor
+            self.n_patches_uniform_volume = 0
+            if volumes is not None and patches:
+                vol = np.ascontiguousarray(np.asarray(volumes, np.float64)[:N])
+                self.n_patches_uniform_volume = int(lib.t8gpu_plan_plain_patch_volumes(h, p(vol)))
             self.tile_desc = np.zeros((max(1, self.ntiles), 8), np.int32)
             if self.ntiles:
                 lib.t8gpu_plan_plain_tile_desc(h, p(self.tile_desc))
@@ -91,6 +98,7 @@ class HostPlainPlan:
 
     @classmethod
     def from_partition(cls, part, **kw):
+        kw.setdefault("volumes", getattr(part, "volumes", None))
         return cls(part.N, part.G, part.F, part.B, part.normal_dim, part.face_neighbors, part.normals, part.areas, **kw)
 
 

@@ -28,7 +28,11 @@ def interpret_patch(plan, t, state, net, reporters):
     pos = int(np.flatnonzero(plan.tile_order == t)[0])
     d = plan.tile_desc[pos]
     e0, ne, h0, nh, fbase, flags = (int(x) for x in d[:6])
-    assert ne == 256 and nh == 64 and (flags & 0x100) and e0 == plan.elem_off[t] and h0 == plan.halo_off[t]
+    assert (flags & 0x100) and e0 == plan.elem_off[t] and h0 == plan.halo_off[t]
+    if flags & 0x400:      # uniform volume in words 1 and 3 (instead of the implied counts 256 and 64)
+        assert float(np.array([d[1], d[3]], np.int32).view(np.float64)[0]) > 0
+    else:
+        assert ne == 256 and nh == 64
     area = float(d[6:8].copy().view(np.float64)[0])
     halo = plan.halo_ids[h0:h0 + 64]
     ex, ey = np.array([[1.0, 0.0, 0.0]]), np.array([[0.0, 1.0, 0.0]])
@@ -65,7 +69,11 @@ def interpret_patch3(plan, t, state, net, reporters):
     pos = int(np.flatnonzero(plan.tile_order == t)[0])
     d = plan.tile_desc[pos]
     e0, ne, h0, nh, fbase, flags = (int(x) for x in d[:6])
-    assert ne == 256 and nh == 256 and (flags & 0x300) == 0x300 and e0 == plan.elem_off[t] and h0 == plan.halo_off[t]
+    assert (flags & 0x300) == 0x300 and e0 == plan.elem_off[t] and h0 == plan.halo_off[t]
+    if flags & 0x400:
+        assert float(np.array([d[1], d[3]], np.int32).view(np.float64)[0]) > 0
+    else:
+        assert ne == 256 and nh == 256
     area = float(d[6:8].copy().view(np.float64)[0])
     halo = plan.halo_ids[h0:h0 + 256]
     ax = [np.array([[1.0, 0.0, 0.0]]), np.array([[0.0, 1.0, 0.0]]), np.array([[0.0, 0.0, 1.0]])]
@@ -152,6 +160,12 @@ def test_plan_reproduces_the_face_loop(mesh_args, ranks, patches):
         plan = HostPlainPlan.from_partition(part, tmax=64, fcap=150, patches=patches)
         n_patches += plan.n_patches
         assert plan.n_patches == int(plan.tile_patch.sum()) == sum(plan.n_patch_class) and (plan.n_patches > 0) == patches
+        if patches:          # the synthetic meshes' patches are blocks of equal cells: every patch carries its volume
+            assert plan.n_patches_uniform_volume == plan.n_patches
+            pd = plan.tile_desc[:plan.ntiles][(plan.tile_desc[:plan.ntiles, 5] & 0x100) != 0]
+            vols = np.stack([pd[:, 1], pd[:, 3]], axis=1).astype(np.int32).copy().view(np.float64)[:, 0]
+            e0s = pd[:, 0]
+            assert np.array_equal(vols, part.volumes[e0s])
         st = perturbed_state(part, 11 + rk)
         o = O.PlainCase(part, np.float64, state=st)
         getattr(O.lib(), "oracle_plain_interior_faces_f64")(0, part.F, 3, O.p(o.fn), O.p(part.indices), O.p(o.normals), O.p(o.areas),
