@@ -36,8 +36,9 @@ def main():
         opts = {}
         if kind in ("plain2", "plain3", "sub2", "sub3"):
             dim = 2 if kind.endswith("2") else 3
-            base = int(rng.integers(1, 5 if dim == 2 else 4))
-            lmax = base + int(rng.integers(0, 3 if dim == 2 else 2))
+            # (round 3: large enough for structured patches -- 16 x 16 blocks from level 6 in 2D, 8 x 8 x 4 from level 5 in 3D)
+            base = int(rng.integers(1, 7 if dim == 2 else 5))
+            lmax = min(base + int(rng.integers(0, 3 if dim == 2 else 2)), 8 if dim == 2 else 5)
             if kind.startswith("sub"):
                 base, lmax = min(base, 3), min(lmax, 3 if dim == 3 else 4)
             mesh = SynthMesh(dim, base, lmax, band=band, periodic=periodic)
@@ -56,7 +57,7 @@ def main():
         mode = "fused" if rng.random() < 0.7 else "compat"
         if not kind.startswith("sub") and mode == "fused" and rng.random() < 0.5:
             opts = dict(tmax=int(rng.choice([16, 50, 256])), fcap=int(rng.choice([40, 130, 512, 1024])),
-                        compressed=bool(rng.random() < 0.8), dictionary=bool(rng.random() < 0.7))
+                        compressed=bool(rng.random() < 0.8), dictionary=bool(rng.random() < 0.7), patches=bool(rng.random() < 0.7))
         if only is not None and n + 1 != only:
             n += 1
             continue

@@ -74,8 +74,8 @@ def main():
             desc = f"prism {n3} periodic {periodic}"
         else:
             dim = 2 if kind.endswith("2") else 3
-            base = int(rng.integers(2, 6 if dim == 2 else 4))
-            lmax = base + int(rng.integers(0, 3 if dim == 2 else 2))
+            base = int(rng.integers(2, 7 if dim == 2 else 5))            # (round 3: large enough for structured patches)
+            lmax = min(base + int(rng.integers(0, 3 if dim == 2 else 2)), 8 if dim == 2 else 5)
             if sub:
                 base, lmax = min(base, 4 if dim == 2 else 3), min(lmax, 5 if dim == 2 else 3)
             mesh = SynthMesh(dim, base, lmax, band=float(rng.choice([0.0, 0.03, 0.08, 0.2])), periodic=bool(rng.random() < 0.5))
@@ -86,9 +86,9 @@ def main():
             desc = f"{kind} base {base} max {lmax}"
         S = whole.cells_per_element
         st = perturbed_state(whole, seed, S)
-        opts = dict(tmax=int(rng.choice([8, 32, 256])), fcap=int(rng.choice([30, 100, 512])))
+        opts = dict(tmax=int(rng.choice([8, 32, 256])), fcap=int(rng.choice([30, 100, 512])), patches=bool(rng.random() < 0.7))
         Solver = SubgridSolver if sub else PlainSolver
-        ref = Solver(whole, torch.float64, mode="fused", state=st)
+        ref = Solver(whole, torch.float64, mode="fused", state=st, **({} if sub else dict(plan_options=dict(patches=False))))
         solvers, halos = [], []
         for p in parts:
             gidx = np.concatenate([p.first_global + np.arange(p.N), p.ghost_global])
