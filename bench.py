@@ -503,8 +503,7 @@ def fused_min_bytes(solver, kind, ft, part):
         geo = 2 * n_tf if h.geo_table.shape[0] else 4 * ft * n_tf
         # speed estimates (+ the original face ids they are scattered by) are written by the third stage only
         # (patch tiles have no face records and read no face-list rows: only the generic tiles' elements count for the ELL rows)
-        n_generic_elems = part.N - 256 * h.n_patches
-        plan = n_tf * (4 + 4 / 3.0) + geo + n_generic_elems * h.ell_width * 2 + int(h.halo_ids.size) * 4 + 32 * h.ntiles
+        plan = n_tf * (4 + 4 / 3.0) + geo + h.n_ell_rows * h.ell_width * 2 + int(h.halo_ids.size) * 4 + 32 * h.ntiles
         state = part.N * ft * (5 + 5 + 10.0 / 3.0 + 1)
         return int(state + (part.F + part.B) * ft / 3.0 + plan)
     cells = part.N * part.cells_per_element

@@ -152,7 +152,7 @@ namespace t8gpu::hip {
           csr_off(N + 1), tile_order(nt);
       std::vector<uint32_t> face_lr(nfaces);
       std::vector<double>   geo(4 * nfaces), table(12 * ngeo);
-      std::vector<uint16_t> csr_ent(ncsr), ell(N * w), geo_idx(ngeo ? nfaces : 0);
+      std::vector<uint16_t> csr_ent(ncsr), ell(std::max<size_t>(1, static_cast<size_t>(sz[15])) * w), geo_idx(ngeo ? nfaces : 0);
       t8gpu_plan_plain_arrays(h, elem_off.data(), halo_off.data(), face_off.data(), halo_ids.data(), face_lr.data(),
                               geo.data(), face_orig.data(), csr_off.data(), csr_ent.data(), tile_order.data());
       t8gpu_plan_plain_compressed(h, ell.data(), ngeo ? geo_idx.data() : nullptr, ngeo ? table.data() : nullptr);

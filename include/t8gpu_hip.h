@@ -146,7 +146,9 @@ typedef struct T8gpuPlainPlan {
   /* optional compressed forms (NULL = absent); with them and tiles of <= 256 elements, <= 512 own+halo
    * elements and <= 1024 faces the software-pipelined kernel variant is used (two passes of 256 faces up
    * to 512 faces per tile, up to four above) */
-  const uint16_t* ell;        /* [N][ell_width] copy of the CSR lists, 0xFFFF-padded, 16-byte rows      */
+  const uint16_t* ell;        /* [rows][ell_width] copy of the CSR lists, 0xFFFF-padded, 16-byte rows. ABI 5: rows exist for the
+                               * elements of GENERIC tiles only; a tile's first row is word 6 of its tile_desc record, element e
+                               * of the tile is row (word 6) + (e - first element)                                  */
   const uint16_t* geo_idx;    /* per tile face: row of geo_table (bits 0-12) | direction code << 13: 2 * axis + (normal
                                * along +axis) for an exact axis normal, 6 otherwise. Inside every block of 256 tile
                                * faces the faces are ordered by that code                                  */
@@ -156,7 +158,7 @@ typedef struct T8gpuPlainPlan {
   int32_t n_deep_tiles;       /* leading tiles of tile_order that read nothing a ghost-reading tile owns (0: unknown) */
   int32_t reserved;
   const int32_t* tile_desc;   /* [ntiles][8], in tile_order order: {first element, elements, first halo entry, halo entries,
-                               * first face, faces, 0, 0} of tile_order[k] -- one 32-byte record per tile for the persistent
+                               * first face, faces, first ELL row, 0} of tile_order[k] -- one 32-byte record per tile for the persistent
                                * kernel, which reads it several tiles ahead (NULL: that kernel is not used) */
   /* STRUCTURED PATCHES (ABI 4; t8gpu_plan_plain_create_ex flag 1, csrc/host/tile_plan.cpp: find_patches): tiles of 256
    * consecutive elements that form an aligned 16 x 16 block of same-size quadrilaterals with the canonical face listing.

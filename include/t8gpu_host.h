@@ -82,7 +82,8 @@ void t8gpu_plan_plain_sizes(const void* plan, int64_t* sizes);
 void t8gpu_plan_plain_arrays(const void* plan, int32_t* elem_off, int32_t* halo_off, int32_t* face_off,
                              int32_t* halo_ids, uint32_t* face_lr, double* face_geo, int32_t* face_orig,
                              int32_t* csr_off, uint16_t* csr_ent, int32_t* tile_order);
-/* ell[N*ell_width], geo_idx[n_faces], geo_table[n_geo*12] = {n, area, t1, 0, t2, 0} rows */
+/* ell[sizes[15] * ell_width] (rows for the elements of generic tiles only, see T8gpuPlainPlan), geo_idx[n_faces],
+ * geo_table[n_geo*12] = {n, area, t1, 0, t2, 0} rows */
 void t8gpu_plan_plain_compressed(const void* plan, uint16_t* ell, uint16_t* geo_idx, double* geo_table);
 /* tile_desc[ntiles][8] of T8gpuPlainPlan (one record per tile in tile_order order) */
 void t8gpu_plan_plain_tile_desc(const void* plan, int32_t* tile_desc);

@@ -135,7 +135,9 @@ T8_DEV void plain_tile_body(const T8gpuPlainPlan& P, int pos, const FVars<T>& pr
   fin[1] = load_face(1);
   const int e = e0 + (own ? tid : 0);
   T         pv[5] = {T(0), T(0), T(0), T(0), T(0)}, volume = T(1);   // fetched behind the last flux pass (register budget)
-  const uint4* __restrict__ ellrow = reinterpret_cast<const uint4*>(P.ell + (size_t)e * P.ell_width);
+  // (ELL rows exist for the elements of generic tiles only: the tile's first row is word 6 of its descriptor)
+  const int ell_row = P.tile_desc[8 * static_cast<size_t>(pos) + 6] + (own ? tid : 0);
+  const uint4* __restrict__ ellrow = reinterpret_cast<const uint4*>(P.ell + (size_t)ell_row * P.ell_width);
   const uint4 ell0 = ellrow[0];
 
   // ---- phase 1 -----------------------------------------------------------------------------------

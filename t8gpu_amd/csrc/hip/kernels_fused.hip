@@ -146,7 +146,7 @@ int plain_generic_stage(int kind, int stage, const T8gpuPlainPlan* plan, int til
   hipStream_t s  = static_cast<hipStream_t>(stream);
   const dim3  grid(tile_count), block(256);
   const int   slots = plan->max_slots > 0 ? plan->max_slots : plan->max_elems + plan->max_halo;
-  const bool  pipelined = plan->ell && plan->ell_width >= 8 && plan->ell_width % 8 == 0 && plan->max_elems <= 256 &&
+  const bool  pipelined = plan->ell && plan->tile_desc && plan->ell_width >= 8 && plan->ell_width % 8 == 0 && plan->max_elems <= 256 &&
                          slots <= 512 && plan->max_faces <= 1024;
   const bool  four = plan->max_faces > 512;
   static const bool scatter = std::getenv("T8GPU_LDS_SCATTER") && std::getenv("T8GPU_LDS_SCATTER")[0] == '1';   // measured alternative

@@ -276,7 +276,7 @@ int plain_patch_stage(int kind, int stage, const T8gpuPlainPlan* plan, int patch
     // what plain_tile_body<T, K, S, true, 2> takes (kernels_fused.hip: the pipelined kernel with a geometry dictionary, two
     // passes of 256 faces), and its LDS window
     const int  slots = plan->max_slots > 0 ? plan->max_slots : plan->max_elems + plan->max_halo;
-    const bool ok = plan->ell && plan->ell_width >= 8 && plan->ell_width % 8 == 0 && plan->max_elems <= 256 && slots <= 512 &&
+    const bool ok = plan->ell && plan->tile_desc && plan->ell_width >= 8 && plan->ell_width % 8 == 0 && plan->max_elems <= 256 && slots <= 512 &&
                     plan->max_faces <= 512 && plan->geo_idx && plan->geo_table && plan->n_geo > 0;
     static const bool off = std::getenv("T8GPU_PATCH_MIXED") && std::getenv("T8GPU_PATCH_MIXED")[0] == '0';   // (measurements)
     if (!ok || off) return -1;

@@ -50,7 +50,7 @@ T8_DEV void ell_gather(uint4 w, const T* __restrict__ ff, T acc[5]) {
 }
 
 struct TileDesc {
-  int e0, ne, h0, nh, f0, nf;
+  int e0, ne, h0, nh, f0, nf, el0;   // el0: the tile's first row in P.ell (rows exist for generic tiles' elements only)
 };
 
 // (second launch bound = waves per SIMD the register allocation must allow: 3 workgroups per CU in fp64, 5 in fp32)
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_persisten
     const int8v r = *reinterpret_cast<const __attribute__((address_space(4))) int8v*>(
         reinterpret_cast<const __attribute__((address_space(4))) char*>(reinterpret_cast<uintptr_t>(P.tile_desc)) + 32 * k);
     TileDesc d;
-    d.e0 = r[0]; d.ne = r[1]; d.h0 = r[2]; d.nh = r[3]; d.f0 = r[4]; d.nf = r[5];
+    d.e0 = r[0]; d.ne = r[1]; d.h0 = r[2]; d.nh = r[3]; d.f0 = r[4]; d.nf = r[5]; d.el0 = r[6];
     return d;
   };
   // slots of the lane's two elements: lane < ne owns element e0 + lane, the remaining own + halo slots are halo elements
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_persisten
     p.gi1   = P.geo_idx[j1];
     p.orig0 = speed ? P.face_orig[j0] : -1;
     p.orig1 = speed ? P.face_orig[j1] : -1;
-    p.ell   = *reinterpret_cast<const uint4*>(P.ell + static_cast<size_t>(d.e0 + (tid < d.ne ? tid : 0)) * P.ell_width);
+    p.ell   = *reinterpret_cast<const uint4*>(P.ell + static_cast<size_t>(d.el0 + (tid < d.ne ? tid : 0)) * P.ell_width);
     return p;
   };
 
@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_persisten
     const T volume = vol[e];
     // second chunk of this tile's face lists (3D AMR): requested with the previous state, needed just before it
     uint4 ell1 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-    if (ELLC > 1) ell1 = *reinterpret_cast<const uint4*>(P.ell + static_cast<size_t>(e) * P.ell_width + 8);
+    const size_t erow = static_cast<size_t>(d0.el0 + (own ? tid : 0)) * P.ell_width;
+    if (ELLC > 1) ell1 = *reinterpret_cast<const uint4*>(P.ell + erow + 8);
     // ---- phase 1: the tile's own + halo elements -> LDS records ---------------------------------------------
     if (a0) {
       T w[NW];
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_persisten
         ell_gather<T>(ell1, ff, acc);
         // a third chunk only where an element has more than 15 faces (rare: fetched here, other waves cover it)
         if (ELLC > 2 && P.ell_width > 16 && (ell1.w >> 16) != 0xFFFFu)
-          ell_gather<T>(*reinterpret_cast<const uint4*>(P.ell + static_cast<size_t>(e) * P.ell_width + 16), ff, acc);
+          ell_gather<T>(*reinterpret_cast<const uint4*>(P.ell + erow + 16), ff, acc);
       }
     }
 

@@ -74,7 +74,8 @@ struct TilePlan {
   // compressed forms used by the pipelined kernel
   int32_t lecap = 512;                                 // max own + halo elements per tile
   int32_t ell_width = 0;                               // padded per-element face-list width (multiple of 8)
-  std::vector<uint16_t> ell;                           // [N][ell_width], 0xFFFF = padding
+  std::vector<uint16_t> ell;                           // [ell rows][ell_width], 0xFFFF = padding (generic tiles' elements only)
+  std::vector<int32_t>  ell_row0;                      // [ntiles + 1] first ELL row of each tile
   std::vector<uint16_t> geo_idx;                       // per tile face: row of geo_table (13 bits) | direction code << 13
                                                        // (empty if more than 8191 distinct rows)
   std::vector<double>   geo_table;                     // [n_geo][12]: n, area, t1, 0, t2, 0
@@ -119,57 +120,64 @@ void find_patches(TilePlan& P, const int32_t* fn, const double* normals, const d
     if (n[0] == 0.0 && n[1] == 1.0) return 1;
     return -1;
   };
-  int32_t e0 = 0;
-  while (e0 + kPatchElems <= N) {
-    Patch pt;
-    bool  ok = true;
-    for (int t = 0; t < kPatchElems && ok; t++) {
-      const int32_t e = e0 + t;
-      ok = deg[e + 1] - deg[e] == 4;
-      if (!ok) break;
-      const int32_t* fl = &ef[deg[e]];
-      int32_t        own[2] = {-1, -1}, far[2] = {-1, -1};   // the element's +x / +y faces, its -x / -y faces
-      for (int q = 0; q < 4 && ok; q++) {
-        const int32_t f = fl[q];
-        const int     ax = f < F ? axis_of(f) : -1;
-        if (ax < 0) { ok = false; break; }
-        const int32_t l = fn[2 * static_cast<size_t>(f)], r = fn[2 * static_cast<size_t>(f) + 1];
-        if (l == r) ok = false;
-        else if (l == e && own[ax] < 0) own[ax] = f;
-        else if (r == e && far[ax] < 0) far[ax] = f;
-        else ok = false;
+  // Every element is tested as a patch START on its own, in parallel: two patches cannot overlap (the checks pin a start
+  // to the origin of an aligned block -- element e0 + 1 must be its +x neighbour, e0 + 2 the +y neighbour, and so on through
+  // the Morton pattern), so there is no scan order to respect. Almost every candidate fails at its first element.
+  const int32_t ncand = N >= kPatchElems ? N - kPatchElems + 1 : 0;
+  std::vector<std::vector<Patch>> found(static_cast<size_t>(host_threads()));
+#pragma omp parallel num_threads(host_threads())
+  {
+    std::vector<Patch>& mine = found[static_cast<size_t>(omp_get_thread_num())];
+#pragma omp for schedule(static)
+    for (int32_t e0 = 0; e0 < ncand; e0++) {
+      Patch pt;
+      bool  ok = true;
+      for (int t = 0; t < kPatchElems && ok; t++) {
+        const int32_t e = e0 + t;
+        ok = deg[e + 1] - deg[e] == 4;
+        if (!ok) break;
+        const int32_t* fl = &ef[deg[e]];
+        int32_t        own[2] = {-1, -1}, far[2] = {-1, -1};   // the element's +x / +y faces, its -x / -y faces
+        for (int q = 0; q < 4 && ok; q++) {
+          const int32_t f = fl[q];
+          const int     ax = f < F ? axis_of(f) : -1;
+          if (ax < 0) { ok = false; break; }
+          const int32_t l = fn[2 * static_cast<size_t>(f)], r = fn[2 * static_cast<size_t>(f) + 1];
+          if (l == r) ok = false;
+          else if (l == e && own[ax] < 0) own[ax] = f;
+          else if (r == e && far[ax] < 0) far[ax] = f;
+          else ok = false;
+        }
+        if (!ok || own[0] < 0 || own[1] < 0 || far[0] < 0 || far[1] < 0) { ok = false; break; }
+        if (t == 0) {
+          pt.e0    = e0;
+          pt.fbase = own[0];
+          pt.area  = areas[own[0]];
+        }
+        for (int q = 0; q < 4; q++) ok = ok && areas[fl[q]] == pt.area;
+        ok = ok && own[0] == pt.fbase + 2 * t && own[1] == pt.fbase + 2 * t + 1 && fl[2] == own[0] && fl[3] == own[1];
+        if (!ok) break;
+        const int  i = li[t], j = lj[t];
+        const bool yfirst = fl[0] == far[1];
+        if (t == 0) pt.flags = yfirst ? 1 : 0;
+        else ok = yfirst == patch_y_first(i, j);
+        const int32_t px = fn[2 * static_cast<size_t>(own[0]) + 1], py = fn[2 * static_cast<size_t>(own[1]) + 1];
+        const int32_t mx = fn[2 * static_cast<size_t>(far[0])], my = fn[2 * static_cast<size_t>(far[1])];
+        auto outside = [&](int32_t s) { return s < e0 || s >= e0 + kPatchElems; };
+        // (a - side face whose left element is a ghost is reported -- speed estimate -- by the tile of its right element,
+        // which a patch cannot do: such blocks stay generic tiles. Ghosts across the + sides are fine.)
+        auto owned_outside = [&](int32_t s) { return s < N && (s < e0 || s >= e0 + kPatchElems); };
+        if (i < kPatchSide - 1) ok = ok && px == e0 + morton2(i + 1, j); else { ok = ok && outside(px); pt.halo[16 + j] = px; }
+        if (i > 0)              ok = ok && mx == e0 + morton2(i - 1, j); else { ok = ok && owned_outside(mx); pt.halo[j] = mx; }
+        if (j < kPatchSide - 1) ok = ok && py == e0 + morton2(i, j + 1); else { ok = ok && outside(py); pt.halo[48 + i] = py; }
+        if (j > 0)              ok = ok && my == e0 + morton2(i, j - 1); else { ok = ok && owned_outside(my); pt.halo[32 + i] = my; }
       }
-      if (!ok || own[0] < 0 || own[1] < 0 || far[0] < 0 || far[1] < 0) { ok = false; break; }
-      if (t == 0) {
-        pt.e0    = e0;
-        pt.fbase = own[0];
-        pt.area  = areas[own[0]];
-      }
-      for (int q = 0; q < 4; q++) ok = ok && areas[fl[q]] == pt.area;
-      ok = ok && own[0] == pt.fbase + 2 * t && own[1] == pt.fbase + 2 * t + 1 && fl[2] == own[0] && fl[3] == own[1];
-      if (!ok) break;
-      const int  i = li[t], j = lj[t];
-      const bool yfirst = fl[0] == far[1];
-      if (t == 0) pt.flags = yfirst ? 1 : 0;
-      else ok = yfirst == patch_y_first(i, j);
-      const int32_t px = fn[2 * static_cast<size_t>(own[0]) + 1], py = fn[2 * static_cast<size_t>(own[1]) + 1];
-      const int32_t mx = fn[2 * static_cast<size_t>(far[0])], my = fn[2 * static_cast<size_t>(far[1])];
-      auto outside = [&](int32_t s) { return s < e0 || s >= e0 + kPatchElems; };
-      // (a - side face whose left element is a ghost is reported -- speed estimate -- by the tile of its right element,
-      // which a patch cannot do: such blocks stay generic tiles. Ghosts across the + sides are fine.)
-      auto owned_outside = [&](int32_t s) { return s < N && (s < e0 || s >= e0 + kPatchElems); };
-      if (i < kPatchSide - 1) ok = ok && px == e0 + morton2(i + 1, j); else { ok = ok && outside(px); pt.halo[16 + j] = px; }
-      if (i > 0)              ok = ok && mx == e0 + morton2(i - 1, j); else { ok = ok && owned_outside(mx); pt.halo[j] = mx; }
-      if (j < kPatchSide - 1) ok = ok && py == e0 + morton2(i, j + 1); else { ok = ok && outside(py); pt.halo[48 + i] = py; }
-      if (j > 0)              ok = ok && my == e0 + morton2(i, j - 1); else { ok = ok && owned_outside(my); pt.halo[32 + i] = my; }
-    }
-    if (ok) {
-      P.patches.push_back(pt);
-      e0 += kPatchElems;
-    } else {
-      e0++;
+      if (ok) mine.push_back(pt);
     }
   }
+  for (auto& v : found)   // (static schedule: ascending e0 overall; the guard is belt and braces -- see above)
+    for (const Patch& q : v)
+      if (P.patches.empty() || q.e0 >= P.patches.back().e0 + kPatchElems) P.patches.push_back(q);
 }
 
 inline int morton3(int i, int j, int k) {   // 8 x 8 x 4: x bits 0, 3, 6; y bits 1, 4, 7; z bits 2, 5
@@ -203,69 +211,76 @@ void find_patches3(TilePlan& P, const int32_t* fn, const double* normals, const 
       if (n[a] == 1.0) return a;
     return -1;
   };
-  int32_t e0 = 0;
-  while (e0 + kPatchElems <= N) {
-    Patch pt;
-    pt.dim = 3;
-    pt.nh  = kPatchHalo3;
-    bool ok = true;
-    for (int t = 0; t < kPatchElems && ok; t++) {
-      const int32_t e = e0 + t;
-      ok = deg[e + 1] - deg[e] == 6;
-      if (!ok) break;
-      const int32_t* fl = &ef[deg[e]];
-      int32_t        own[3] = {-1, -1, -1}, far[3] = {-1, -1, -1};
-      for (int q = 0; q < 6 && ok; q++) {
-        const int32_t f = fl[q];
-        const int     ax = f < F ? axis_of(f) : -1;
-        if (ax < 0) { ok = false; break; }
-        const int32_t l = fn[2 * static_cast<size_t>(f)], r = fn[2 * static_cast<size_t>(f) + 1];
-        if (l == r) ok = false;
-        else if (l == e && own[ax] < 0) own[ax] = f;
-        else if (r == e && far[ax] < 0) far[ax] = f;
-        else ok = false;
+  // Every element is tested as a patch START on its own, in parallel: two patches cannot overlap (the checks pin a start
+  // to the origin of an aligned block -- element e0 + 1 must be its +x neighbour, e0 + 2 the +y neighbour, and so on through
+  // the Morton pattern), so there is no scan order to respect. Almost every candidate fails at its first element.
+  const int32_t ncand = N >= kPatchElems ? N - kPatchElems + 1 : 0;
+  std::vector<std::vector<Patch>> found(static_cast<size_t>(host_threads()));
+#pragma omp parallel num_threads(host_threads())
+  {
+    std::vector<Patch>& mine = found[static_cast<size_t>(omp_get_thread_num())];
+#pragma omp for schedule(static)
+    for (int32_t e0 = 0; e0 < ncand; e0++) {
+      Patch pt;
+      pt.dim = 3;
+      pt.nh  = kPatchHalo3;
+      bool ok = true;
+      for (int t = 0; t < kPatchElems && ok; t++) {
+        const int32_t e = e0 + t;
+        ok = deg[e + 1] - deg[e] == 6;
+        if (!ok) break;
+        const int32_t* fl = &ef[deg[e]];
+        int32_t        own[3] = {-1, -1, -1}, far[3] = {-1, -1, -1};
+        for (int q = 0; q < 6 && ok; q++) {
+          const int32_t f = fl[q];
+          const int     ax = f < F ? axis_of(f) : -1;
+          if (ax < 0) { ok = false; break; }
+          const int32_t l = fn[2 * static_cast<size_t>(f)], r = fn[2 * static_cast<size_t>(f) + 1];
+          if (l == r) ok = false;
+          else if (l == e && own[ax] < 0) own[ax] = f;
+          else if (r == e && far[ax] < 0) far[ax] = f;
+          else ok = false;
+        }
+        for (int a = 0; a < 3; a++) ok = ok && own[a] >= 0 && far[a] >= 0;
+        if (!ok) break;
+        if (t == 0) {
+          pt.e0    = e0;
+          pt.fbase = own[0];
+          pt.area  = areas[own[0]];
+        }
+        for (int q = 0; q < 6; q++) ok = ok && areas[fl[q]] == pt.area;
+        for (int a = 0; a < 3; a++) ok = ok && own[a] == pt.fbase + 3 * t + a && fl[3 + a] == own[a];
+        if (!ok) break;
+        const int i = li[t], j = lj[t], k = lk[t];
+        // position of every - face among the three (ascending face id = ascending index of the owning neighbour)
+        int pos[3] = {0, 0, 0};
+        for (int a = 0; a < 3; a++)
+          for (int q = 0; q < 3; q++)
+            if (fl[q] == far[a]) pos[a] = q;
+        const bool yx = pos[1] < pos[0], zx = pos[2] < pos[0], zy = pos[2] < pos[1];
+        if (t == 0) pt.flags = (yx ? 1 : 0) | (zx ? 2 : 0) | (zy ? 4 : 0);
+        // the rule, with the patch's flags where both coordinates of a pair are 0 (their ctz is then the forest's business)
+        const bool ryx = (i == 0 && j == 0) ? (pt.flags & 1) != 0 : ctz_or(j, 8) >= ctz_or(i, 8);
+        const bool rzx = (i == 0 && k == 0) ? (pt.flags & 2) != 0 : ctz_or(k, 8) >= ctz_or(i, 8);
+        const bool rzy = (j == 0 && k == 0) ? (pt.flags & 4) != 0 : ctz_or(k, 8) >= ctz_or(j, 8);
+        ok = ok && yx == ryx && zx == rzx && zy == rzy;
+        const int32_t pl[3] = {fn[2 * static_cast<size_t>(own[0]) + 1], fn[2 * static_cast<size_t>(own[1]) + 1], fn[2 * static_cast<size_t>(own[2]) + 1]};
+        const int32_t mi[3] = {fn[2 * static_cast<size_t>(far[0])], fn[2 * static_cast<size_t>(far[1])], fn[2 * static_cast<size_t>(far[2])]};
+        auto outside       = [&](int32_t s) { return s < e0 || s >= e0 + kPatchElems; };
+        auto owned_outside = [&](int32_t s) { return s < N && (s < e0 || s >= e0 + kPatchElems); };   // (see find_patches)
+        if (i < 7) ok = ok && pl[0] == e0 + morton3(i + 1, j, k); else { ok = ok && outside(pl[0]); pt.halo[32 + j + 8 * k] = pl[0]; }
+        if (i > 0) ok = ok && mi[0] == e0 + morton3(i - 1, j, k); else { ok = ok && owned_outside(mi[0]); pt.halo[j + 8 * k] = mi[0]; }
+        if (j < 7) ok = ok && pl[1] == e0 + morton3(i, j + 1, k); else { ok = ok && outside(pl[1]); pt.halo[96 + i + 8 * k] = pl[1]; }
+        if (j > 0) ok = ok && mi[1] == e0 + morton3(i, j - 1, k); else { ok = ok && owned_outside(mi[1]); pt.halo[64 + i + 8 * k] = mi[1]; }
+        if (k < 3) ok = ok && pl[2] == e0 + morton3(i, j, k + 1); else { ok = ok && outside(pl[2]); pt.halo[192 + i + 8 * j] = pl[2]; }
+        if (k > 0) ok = ok && mi[2] == e0 + morton3(i, j, k - 1); else { ok = ok && owned_outside(mi[2]); pt.halo[128 + i + 8 * j] = mi[2]; }
       }
-      for (int a = 0; a < 3; a++) ok = ok && own[a] >= 0 && far[a] >= 0;
-      if (!ok) break;
-      if (t == 0) {
-        pt.e0    = e0;
-        pt.fbase = own[0];
-        pt.area  = areas[own[0]];
-      }
-      for (int q = 0; q < 6; q++) ok = ok && areas[fl[q]] == pt.area;
-      for (int a = 0; a < 3; a++) ok = ok && own[a] == pt.fbase + 3 * t + a && fl[3 + a] == own[a];
-      if (!ok) break;
-      const int i = li[t], j = lj[t], k = lk[t];
-      // position of every - face among the three (ascending face id = ascending index of the owning neighbour)
-      int pos[3] = {0, 0, 0};
-      for (int a = 0; a < 3; a++)
-        for (int q = 0; q < 3; q++)
-          if (fl[q] == far[a]) pos[a] = q;
-      const bool yx = pos[1] < pos[0], zx = pos[2] < pos[0], zy = pos[2] < pos[1];
-      if (t == 0) pt.flags = (yx ? 1 : 0) | (zx ? 2 : 0) | (zy ? 4 : 0);
-      // the rule, with the patch's flags where both coordinates of a pair are 0 (their ctz is then the forest's business)
-      const bool ryx = (i == 0 && j == 0) ? (pt.flags & 1) != 0 : ctz_or(j, 8) >= ctz_or(i, 8);
-      const bool rzx = (i == 0 && k == 0) ? (pt.flags & 2) != 0 : ctz_or(k, 8) >= ctz_or(i, 8);
-      const bool rzy = (j == 0 && k == 0) ? (pt.flags & 4) != 0 : ctz_or(k, 8) >= ctz_or(j, 8);
-      ok = ok && yx == ryx && zx == rzx && zy == rzy;
-      const int32_t pl[3] = {fn[2 * static_cast<size_t>(own[0]) + 1], fn[2 * static_cast<size_t>(own[1]) + 1], fn[2 * static_cast<size_t>(own[2]) + 1]};
-      const int32_t mi[3] = {fn[2 * static_cast<size_t>(far[0])], fn[2 * static_cast<size_t>(far[1])], fn[2 * static_cast<size_t>(far[2])]};
-      auto outside       = [&](int32_t s) { return s < e0 || s >= e0 + kPatchElems; };
-      auto owned_outside = [&](int32_t s) { return s < N && (s < e0 || s >= e0 + kPatchElems); };   // (see find_patches)
-      if (i < 7) ok = ok && pl[0] == e0 + morton3(i + 1, j, k); else { ok = ok && outside(pl[0]); pt.halo[32 + j + 8 * k] = pl[0]; }
-      if (i > 0) ok = ok && mi[0] == e0 + morton3(i - 1, j, k); else { ok = ok && owned_outside(mi[0]); pt.halo[j + 8 * k] = mi[0]; }
-      if (j < 7) ok = ok && pl[1] == e0 + morton3(i, j + 1, k); else { ok = ok && outside(pl[1]); pt.halo[96 + i + 8 * k] = pl[1]; }
-      if (j > 0) ok = ok && mi[1] == e0 + morton3(i, j - 1, k); else { ok = ok && owned_outside(mi[1]); pt.halo[64 + i + 8 * k] = mi[1]; }
-      if (k < 3) ok = ok && pl[2] == e0 + morton3(i, j, k + 1); else { ok = ok && outside(pl[2]); pt.halo[192 + i + 8 * j] = pl[2]; }
-      if (k > 0) ok = ok && mi[2] == e0 + morton3(i, j, k - 1); else { ok = ok && owned_outside(mi[2]); pt.halo[128 + i + 8 * j] = mi[2]; }
-    }
-    if (ok) {
-      P.patches.push_back(pt);
-      e0 += kPatchElems;
-    } else {
-      e0++;
+      if (ok) mine.push_back(pt);
     }
   }
+  for (auto& v : found)   // (static schedule: ascending e0 overall; the guard is belt and braces -- see above)
+    for (const Patch& q : v)
+      if (P.patches.empty() || q.e0 >= P.patches.back().e0 + kPatchElems) P.patches.push_back(q);
 }
 
 void build(TilePlan& P, const int32_t* fn, const double* normals, const double* areas) {
@@ -278,24 +293,29 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
     std::fprintf(stderr, "[tile_plan] %-28s %.2f s\n", what, std::chrono::duration<double>(now - tprev).count());
     tprev = now;
   };
-  // faces of each owned element, in original face order (interior faces first, then walls)
+  // faces of each owned element, in original face order (interior faces first, then walls): counted and placed in
+  // parallel over the faces (atomic cursors), then every element's short list is sorted back into ascending face id
   std::vector<int32_t> deg(static_cast<size_t>(N) + 1, 0);
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
   for (int32_t f = 0; f < F; f++) {
     const int32_t l = fn[2 * static_cast<size_t>(f)], r = fn[2 * static_cast<size_t>(f) + 1];
-    if (l < N) deg[l + 1]++;
-    if (r < N && r != l) deg[r + 1]++;
+    if (l < N) __atomic_fetch_add(&deg[l + 1], 1, __ATOMIC_RELAXED);
+    if (r < N && r != l) __atomic_fetch_add(&deg[r + 1], 1, __ATOMIC_RELAXED);
   }
   for (int32_t b = 0; b < B; b++) deg[fn[2 * static_cast<size_t>(F) + b] + 1]++;
   for (int32_t e = 0; e < N; e++) deg[e + 1] += deg[e];
   std::vector<int32_t> ef(deg[N]);
   {
     std::vector<int32_t> cur(deg.begin(), deg.end() - 1);
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
     for (int32_t f = 0; f < F; f++) {
       const int32_t l = fn[2 * static_cast<size_t>(f)], r = fn[2 * static_cast<size_t>(f) + 1];
-      if (l < N) ef[cur[l]++] = f;
-      if (r < N && r != l) ef[cur[r]++] = f;
+      if (l < N) ef[__atomic_fetch_add(&cur[l], 1, __ATOMIC_RELAXED)] = f;
+      if (r < N && r != l) ef[__atomic_fetch_add(&cur[r], 1, __ATOMIC_RELAXED)] = f;
     }
     for (int32_t b = 0; b < B; b++) ef[cur[fn[2 * static_cast<size_t>(F) + b]]++] = F + b;
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
+    for (int32_t e = 0; e < N; e++) std::sort(ef.begin() + deg[e], ef.begin() + deg[e + 1]);
   }
   auto side = [&](int32_t f, int which) -> int32_t {
     if (f >= F) return which == 0 ? fn[2 * static_cast<size_t>(F) + (f - F)] : -1;
@@ -543,16 +563,24 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
   P.n_patch_class[2] -= P.n_interior;
 
   lap("tile classes");
-  // fixed-width (ELL) copy of the element face lists: one aligned 16-byte load per 8 entries
+  // fixed-width (ELL) copy of the element face lists: one aligned 16-byte load per 8 entries. Rows exist for the elements of
+  // GENERIC tiles only (patch tiles read no face lists: 97 % of the benchmark mesh), in tile-index order; tile t's rows
+  // start at ell_row0[t] (tile_desc word 6), element e of the tile is row ell_row0[t] + (e - elem_off[t]).
   int32_t maxdeg = 0;
   for (int32_t e = 0; e < N; e++) maxdeg = std::max(maxdeg, P.csr_off[e + 1] - P.csr_off[e]);
   P.ell_width = std::max(8, (maxdeg + 7) / 8 * 8);
-  P.ell.resize(static_cast<size_t>(N) * P.ell_width);
+  P.ell_row0.assign(static_cast<size_t>(ntiles) + 1, 0);
+  for (int32_t t = 0; t < ntiles; t++)
+    P.ell_row0[t + 1] = P.ell_row0[t] + (P.tile_patch[t] >= 0 ? 0 : P.elem_off[t + 1] - P.elem_off[t]);
+  P.ell.resize(static_cast<size_t>(P.ell_row0[ntiles]) * P.ell_width);
 #pragma omp parallel for num_threads(host_threads()) schedule(static)
-  for (int32_t e = 0; e < N; e++) {
-    uint16_t*     row = &P.ell[static_cast<size_t>(e) * P.ell_width];
-    const int32_t n   = P.csr_off[e + 1] - P.csr_off[e];
-    for (int32_t c = 0; c < P.ell_width; c++) row[c] = c < n ? P.csr_ent[P.csr_off[e] + c] : static_cast<uint16_t>(0xFFFFu);
+  for (int32_t t = 0; t < ntiles; t++) {
+    if (P.tile_patch[t] >= 0) continue;
+    for (int32_t e = P.elem_off[t]; e < P.elem_off[t + 1]; e++) {
+      uint16_t*     row = &P.ell[static_cast<size_t>(P.ell_row0[t] + (e - P.elem_off[t])) * P.ell_width];
+      const int32_t n   = P.csr_off[e + 1] - P.csr_off[e];
+      for (int32_t c = 0; c < P.ell_width; c++) row[c] = c < n ? P.csr_ent[P.csr_off[e] + c] : static_cast<uint16_t>(0xFFFFu);
+    }
   }
 
   lap("ELL rows");
@@ -673,7 +701,7 @@ int32_t t8gpu_plan_plain_patch_dim(const void* h) {
 }
 
 // sizes[16] = {ntiles, n_halo, n_faces, n_csr, max_elems, max_halo, max_faces, n_interior_tiles, N, F,
-//              ell_width, n_geo (0: no dictionary), max_slots, n_deep_tiles, n_patches, 0}; the maxima are over the
+//              ell_width, n_geo (0: no dictionary), max_slots, n_deep_tiles, n_patches, n_ell_rows}; the maxima are over the
 //              generic tiles only
 void t8gpu_plan_plain_sizes(const void* h, int64_t* sizes) {
   const TilePlan* P = static_cast<const TilePlan*>(h);
@@ -692,7 +720,7 @@ void t8gpu_plan_plain_sizes(const void* h, int64_t* sizes) {
   sizes[12] = P->max_slots;
   sizes[13] = P->n_deep;
   sizes[14] = static_cast<int64_t>(P->patches.size());
-  sizes[15] = 0;
+  sizes[15] = P->ell_width > 0 ? static_cast<int64_t>(P->ell.size() / static_cast<size_t>(P->ell_width)) : 0;   // ELL rows
 }
 
 void t8gpu_plan_plain_compressed(const void* h, uint16_t* ell, uint16_t* geo_idx, double* geo_table) {
@@ -710,7 +738,8 @@ void t8gpu_plan_plain_tile_desc(const void* h, int32_t* tile_desc) {
     d[0] = P->elem_off[t]; d[1] = P->elem_off[t + 1] - P->elem_off[t];
     d[2] = P->halo_off[t]; d[3] = P->halo_off[t + 1] - P->halo_off[t];
     d[4] = P->face_off[t]; d[5] = P->face_off[t + 1] - P->face_off[t];
-    d[6] = d[7] = 0;
+    d[6] = P->ell_row0.empty() ? 0 : P->ell_row0[t];   // generic tiles: first row of the tile in `ell`
+    d[7] = 0;
     if (!P->tile_patch.empty() && P->tile_patch[t] >= 0) {   // patch tile: {e0, 256, first halo entry, 64 | 256, fbase, 0x100 | 0x200 (3D) | flags, area}
       const Patch& pt = P->patches[P->tile_patch[t]];
       d[4] = pt.fbase;

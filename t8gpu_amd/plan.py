@@ -72,7 +72,8 @@ class HostPlainPlan:
             self.tile_order = np.zeros(self.ntiles, np.int32)
             lib.t8gpu_plan_plain_arrays(h, *(p(getattr(self, f)) if getattr(self, f).size else None for f in self.FIELDS))
             self.ell_width, n_geo, self.max_slots, self.n_deep = int(sz[10]), int(sz[11]), int(sz[12]), int(sz[13])
-            self.ell = np.zeros((N, self.ell_width), np.uint16)
+            self.n_ell_rows = int(sz[15])                  # rows exist for the elements of generic tiles only (tile_desc word 6)
+            self.ell = np.zeros((max(1, self.n_ell_rows), self.ell_width), np.uint16)
             self.geo_idx = np.zeros(n_faces if n_geo else 0, np.uint16)
             self.geo_table = np.zeros((n_geo, 12), np.float64)
             lib.t8gpu_plan_plain_compressed(h, p(self.ell), p(self.geo_idx) if n_geo else None,
