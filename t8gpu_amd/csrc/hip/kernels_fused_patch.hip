@@ -294,6 +294,15 @@ int plain_patch_stage(int kind, int stage, const T8gpuPlainPlan* plan, int patch
     per_cu_env      = env ? std::atoi(env) : 0;
     if (per_cu_env < 0 || per_cu_env > 8) per_cu_env = 0;
   }
+  // persistent = true: the launch covers the whole plan -- as many patch workgroups as stay resident (3 per CU in fp64).
+  // persistent = false: a class of a multi-rank stage, launched beside the pack / RCCL / unpack kernels of the exchange: one
+  // patch per workgroup, so that slots free up continuously. That costs the patch kernel its software pipeline (13 % at c2
+  // size, 19 % at c4 size: T8GPU_PATCH_PERSISTENT=0 on one rank), but a "polite" persistent grid of two workgroups per CU
+  // for the class launches -- measured in round 3 -- is worse where it matters: rank 3 of the 8-way c4 split with an RCCL
+  // self-exchange 0.173 -> 0.205 ms/step (profiles/r03_halo_overhead.md); the exchange kernels wait behind resident
+  // workgroups that never leave.
+  static const bool never_persistent = std::getenv("T8GPU_PATCH_PERSISTENT") && std::getenv("T8GPU_PATCH_PERSISTENT")[0] == '0';   // (measurements)
+  if (never_persistent) persistent = false;
   const int  per_cu    = per_cu_env > 0 ? per_cu_env : (sizeof(T) == 8 ? 3 : 5);
   const int  resident  = cus * per_cu;
   const int  patch_wgs = (!persistent || patch_count < resident) ? patch_count : resident;
