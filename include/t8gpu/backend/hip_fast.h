@@ -180,7 +180,8 @@ namespace t8gpu::hip {
       m_plan.max_elems = static_cast<int32_t>(sz[4]); m_plan.max_halo = static_cast<int32_t>(sz[5]);
       m_plan.max_faces = static_cast<int32_t>(sz[6]); m_plan.ell_width = static_cast<int32_t>(w);
       m_plan.n_geo = static_cast<int32_t>(ngeo); m_plan.max_slots = static_cast<int32_t>(sz[12]);
-      m_plan.n_deep_tiles = static_cast<int32_t>(sz[13]); m_plan.reserved = 0;
+      m_plan.n_deep_tiles = static_cast<int32_t>(sz[13]);
+      m_plan.n_slots_addressed = m.num_local_elements + m.num_ghost_elements;
       for (int c = 0; c < 3; c++) m_plan.n_patch_tiles[c] = patch_counts[c];
       m_plan.patch_dim = patch_dim;
       T8gpuHalo  hl{};

@@ -156,7 +156,9 @@ typedef struct T8gpuPlainPlan {
   int32_t n_geo;
   int32_t max_slots;          /* max over tiles of own + halo elements (0: unknown, max_elems + max_halo is used) */
   int32_t n_deep_tiles;       /* leading tiles of tile_order that read nothing a ghost-reading tile owns (0: unknown) */
-  int32_t reserved;
+  int32_t n_slots_addressed;  /* owned + ghost elements of the planes the plan indexes (ABI 5; was reserved). The patch kernels
+                               * address a plane by a 32-bit byte offset and refuse plans whose planes reach 4 GiB (or that
+                               * leave this 0): build the plan without patches for such meshes */
   const int32_t* tile_desc;   /* [ntiles][8], in tile_order order: {first element, elements, first halo entry, halo entries,
                                * first face, faces, first ELL row, 0} of tile_order[k] -- one 32-byte record per tile for the persistent
                                * kernel, which reads it several tiles ahead (NULL: that kernel is not used) */

@@ -107,10 +107,10 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
   auto prefetch = [&](const Desc& d, int hslot) {
     Pre p;
 #pragma unroll
-    for (int k = 0; k < 5; k++) p.s0[k] = src.p[k][d.e0 + tid];
+    for (int k = 0; k < 5; k++) p.s0[k] = at32<T>(src.p[k], static_cast<unsigned>(d.e0 + tid));
     if (halo_wave) {
 #pragma unroll
-      for (int k = 0; k < 5; k++) p.sh[k] = src.p[k][hslot];
+      for (int k = 0; k < 5; k++) p.sh[k] = at32<T>(src.p[k], static_cast<unsigned>(hslot));
     } else {
 #pragma unroll
       for (int k = 0; k < 5; k++) p.sh[k] = T(0);
@@ -135,10 +135,10 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
     T         pv[5] = {T(0), T(0), T(0), T(0), T(0)};
     if (STAGE > 1) {
 #pragma unroll
-      for (int k = 0; k < 5; k++) pv[k] = prev.p[k][e];
+      for (int k = 0; k < 5; k++) pv[k] = at32<T>(prev.p[k], static_cast<unsigned>(e));
     }
     // (patches of uniform volume carry it in their descriptor: 8 of ~130 bytes per element and stage less to load)
-    const T volume = (d0.flags & 0x400) ? static_cast<T>(d0.vol) : vol[e];
+    const T volume = (d0.flags & 0x400) ? static_cast<T>(d0.vol) : at32<T>(vol, static_cast<unsigned>(e));
     const T area   = static_cast<T>(d0.area);
 
     // ---- phase 1: records of the own cell and (wave 3) of the cells across the sides ----------------------------------
@@ -162,7 +162,7 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
     }
     if (res_e >= 0) {   // results of the previous patch: behind this iteration's first wait (vmcnt retires in order)
 #pragma unroll
-      for (int k = 0; k < 5; k++) out.p[k][res_e] = res[k];
+      for (int k = 0; k < 5; k++) at32<T>(out.p[k], static_cast<unsigned>(res_e)) = res[k];
     }
     __syncthreads();
 
@@ -225,7 +225,7 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
   }
   if (res_e >= 0) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) out.p[k][res_e] = res[k];
+    for (int k = 0; k < 5; k++) at32<T>(out.p[k], static_cast<unsigned>(res_e)) = res[k];
   }
 }
 
@@ -268,6 +268,9 @@ int plain_patch_stage(int kind, int stage, const T8gpuPlainPlan* plan, int patch
                       FVars<T> prev, FVars<T> mid, FVars<T> out, const T* volume, T dt, T* speed, bool persistent, hipStream_t stream) {
   if (patch_count <= 0) return tile_count > 0 ? -1 : 0;
   if (!plan->tile_desc) return static_cast<int>(hipErrorInvalidValue);
+  // (the kernel addresses a plane by a 32-bit byte offset, patch_common.hpp: at32)
+  if (plan->n_slots_addressed <= 0 || static_cast<unsigned long long>(plan->n_slots_addressed) * sizeof(T) >= (1ull << 32))
+    return static_cast<int>(hipErrorInvalidValue);
   const int    nw  = kind == 0 ? kPrimWords : 5;
   const int    rec = sizeof(T) == 8 ? (nw > 5 ? 10 : 6) : 12;
   const size_t tab = (sizeof(T) == 8 && kind == 0) ? 2 * kLogTabEntries * sizeof(double) : 0;

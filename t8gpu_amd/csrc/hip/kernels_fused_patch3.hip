@@ -118,7 +118,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
   auto fetch = [&](const Desc& d, int hslot, T s[5]) {   // the state of the lane's cell: its own, or the cell across a side
     const int slot = side ? hslot : d.e0 + tid;
 #pragma unroll
-    for (int k = 0; k < 5; k++) s[k] = src.p[k][slot];
+    for (int k = 0; k < 5; k++) s[k] = at32<T>(src.p[k], static_cast<unsigned>(slot));
   };
 
   const int stride = nx;
@@ -138,9 +138,9 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
     if (!side) {
       if (STAGE > 1) {
 #pragma unroll
-        for (int k = 0; k < 5; k++) pv[k] = prev.p[k][e];
+        for (int k = 0; k < 5; k++) pv[k] = at32<T>(prev.p[k], static_cast<unsigned>(e));
       }
-      volume = (d0.flags & 0x400) ? static_cast<T>(d0.vol) : vol[e];   // (uniform patch volume from the descriptor)
+      volume = (d0.flags & 0x400) ? static_cast<T>(d0.vol) : at32<T>(vol, static_cast<unsigned>(e));   // (uniform patch volume from the descriptor)
     }
     const T area = static_cast<T>(d0.area);
 
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
       }
       const T scale = dt / volume;
 #pragma unroll
-      for (int k = 0; k < 5; k++) out.p[k][e] = rk_stage_update<T, STAGE>(pv[k], cur[k], scale, acc[k]);
+      for (int k = 0; k < 5; k++) at32<T>(out.p[k], static_cast<unsigned>(e)) = rk_stage_update<T, STAGE>(pv[k], cur[k], scale, acc[k]);
     }
 #pragma unroll
     for (int k = 0; k < 5; k++) cur[k] = nxt[k];
@@ -233,6 +233,9 @@ int plain_patch3_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile
                        FVars<T> out, const T* volume, T dt, T* speed, bool persistent, hipStream_t stream) {
   if (tile_count <= 0) return 0;
   if (!plan->tile_desc) return static_cast<int>(hipErrorInvalidValue);
+  // (the kernel addresses a plane by a 32-bit byte offset, patch_common.hpp: at32)
+  if (plan->n_slots_addressed <= 0 || static_cast<unsigned long long>(plan->n_slots_addressed) * sizeof(T) >= (1ull << 32))
+    return static_cast<int>(hipErrorInvalidValue);
   const int    nw  = kind == 0 ? kPrimWords : 5;
   const int    rec = sizeof(T) == 8 ? (nw > 5 ? 10 : 6) : 12;
   const size_t lds = sizeof(T) * (static_cast<size_t>(5) * kP3FF + static_cast<size_t>(rec) * 512) +

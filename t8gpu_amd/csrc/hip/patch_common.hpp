@@ -7,6 +7,20 @@
 
 namespace t8gpu_hip {
 
+// Element `i` of a state plane through a 32-bit BYTE offset from the plane's (wave-uniform) base pointer: the compiler then
+// uses the scalar-base addressing form of global_load / global_store (one VALU shift for five planes instead of a sign
+// extension, a 64-bit shift and five 64-bit adds per group of loads: ~30 VALU instructions per patch). Valid while a plane is
+// shorter than 4 GiB -- the plan says so (n_slots_addressed, checked by the launchers; t8gpu_amd/fused.py builds plans of
+// larger meshes without patches).
+template <class T>
+T8_DEV const T& at32(const T* base, unsigned i) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + i * static_cast<unsigned>(sizeof(T)));
+}
+template <class T>
+T8_DEV T& at32(T* base, unsigned i) {
+  return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + i * static_cast<unsigned>(sizeof(T)));
+}
+
 constexpr int kPatchFF = 544;   // flux slots per variable: 256 +x faces, 256 +y faces, 16 -x side, 16 -y side
 
 T8_DEV int patch_morton(int i, int j) {

@@ -13,7 +13,7 @@ class T8gpuPlainPlan(C.Structure):
         ("ntiles", C.c_int32), ("n_interior_tiles", C.c_int32), ("max_elems", C.c_int32), ("max_halo", C.c_int32),
         ("max_faces", C.c_int32), ("ell_width", C.c_int32), ("ell", C.c_void_p), ("geo_idx", C.c_void_p),
         ("geo_table", C.c_void_p), ("n_geo", C.c_int32), ("max_slots", C.c_int32), ("n_deep_tiles", C.c_int32),
-        ("reserved", C.c_int32), ("tile_desc", C.c_void_p), ("n_patch_tiles", C.c_int32 * 3), ("patch_dim", C.c_int32)]
+        ("n_slots_addressed", C.c_int32), ("tile_desc", C.c_void_p), ("n_patch_tiles", C.c_int32 * 3), ("patch_dim", C.c_int32)]
 
 
 class PlainPlan:
@@ -26,6 +26,9 @@ class PlainPlan:
         if patches is None:
             patches = compressed and os.environ.get("T8GPU_PATCH", "1") != "0"
         self.patches = patches if compressed else False          # True / False, or 2 / 3 for one kind only
+        # the patch kernels address a plane by a 32-bit byte offset: meshes whose planes reach 4 GiB keep the tile kernels
+        if (part.N + part.G) * (4 if dtype == torch.float32 else 8) >= 2 ** 32:
+            self.patches = False
         # tuning knobs of the tiling. A mesh that would give fewer than 512 tiles (two per CU) gets half-size tiles:
         # c1 (65 536 elements) runs 16 % faster on 512 tiles of 128 than on 256 tiles of 256.
         given_fcap = fcap
@@ -110,6 +113,7 @@ class PlainPlan:
         for k in range(3):
             c.n_patch_tiles[k] = self.host.n_patch_class[k]
         c.patch_dim = self.host.patch_dim
+        c.n_slots_addressed = part.N + part.G
         self.c = c
 
     @staticmethod
