@@ -362,10 +362,12 @@ def bench_adaptive(args, w, dts, tdtype, kindf, mode, rank, world, dist, rehears
     (MeshManager::adapt + partition + compute_connectivity_information, mesh_manager.inl:196-330,626-723,333-481, and this
     backend's tile plan). One JSON line: value = cell-updates/s of the whole loop; config carries the step and the
     cycle time separately (the device kernels are the small part of a cycle, as in the reference: DESIGN.md section 7)."""
-    from t8gpu_amd import amr
+    from t8gpu_amd import amr, hostmem
     from t8gpu_amd.halo import HaloExchange
     from t8gpu_amd.solver import PlainSolver
     from t8gpu_amd.synth import SynthMesh
+    if os.environ.get("T8GPU_KEEP_HEAP", "1") != "0":
+        hostmem.keep_heap()     # the cycle's host arrays are reused instead of page-faulted in again every adapt
     a = dict(w["adaptive"])
     if os.environ.get("T8GPU_C5A_LEVELS"):      # "min,max": a small version of the same loop (tests)
         a["min_level"], a["max_level"] = (int(x) for x in os.environ["T8GPU_C5A_LEVELS"].split(","))

@@ -19,7 +19,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from t8gpu_amd import amr, vtk  # noqa: E402
+from t8gpu_amd import amr, hostmem, vtk  # noqa: E402
 from t8gpu_amd.halo import HaloExchange  # noqa: E402
 from t8gpu_amd.solver import PlainSolver  # noqa: E402
 from t8gpu_amd.synth import SynthMesh  # noqa: E402
@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--vtk", default=None, help="prefix of the .vtu / .pvtu files written at the end (density, energy, momentum)")
     args = ap.parse_args()
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
+    hostmem.keep_heap()      # host arrays of an adapt cycle are reused by the next one (t8gpu_amd/hostmem.py)
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     rehearsal = os.environ.get("T8GPU_REHEARSAL", "0") == "1"
     dist = None

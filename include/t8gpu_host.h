@@ -52,6 +52,9 @@ void  t8gpu_synth_mesh_marks(const void* mesh, const double* criteria, double th
 /* clears the -1 marks of families cut by a partition offset (a family is only coarsened on one process) */
 void  t8gpu_synth_mesh_unmark_split_families(const void* mesh, int8_t* marks, const int64_t* offsets, int n_offsets);
 void* t8gpu_synth_mesh_adapt(const void* mesh, const int8_t* marks);
+/* the same forest by the general procedure (leaf list and lookup grid rebuilt per balance round): the fallback of the
+ * call above, exported for the tests that compare the two */
+void* t8gpu_synth_mesh_adapt_by_rounds(const void* mesh, const int8_t* marks);
 int   t8gpu_synth_mesh_adapt_data(const void* old_mesh, const void* new_mesh, int32_t* adapt_data);
 
 /* ---- tile plan of the fused plain-element kernels --------------------------------------------- */
@@ -61,7 +64,9 @@ void* t8gpu_plan_plain_create(int32_t N, int32_t G, int32_t F, int32_t B, int32_
  * elements in Morton order with the canonical face listing (csrc/host/tile_plan.cpp: find_patches). A patch is a tile
  * without face records: tile_desc holds {first element, 256, first halo entry, 64, id of its first own face,
  * 0x100 | flags, area (double)}, halo_ids the 64 elements across its sides ([-x | +x | -y | +y] x 16). Inside every
- * class of tile_order the patch tiles come first (t8gpu_plan_plain_patch_counts). */
+ * class of tile_order the patch tiles come first (t8gpu_plan_plain_patch_counts).
+ * flags bit 2: the caller does not read `face_geo` when the plan has a geometry dictionary (sizes[11] > 0): the array is
+ * then left empty (32 bytes per tile face less to build and copy). */
 void* t8gpu_plan_plain_create_ex(int32_t N, int32_t G, int32_t F, int32_t B, int32_t ndim, const int32_t* face_neighbors,
                                  const double* normals, const double* areas, int32_t tmax, int32_t fcap, int32_t flags);
 void  t8gpu_plan_plain_destroy(void* plan);

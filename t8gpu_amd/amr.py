@@ -51,7 +51,7 @@ def adapt(solver, threshold=10.0, min_level=1, max_level=4, family_members_avera
     t2 = time.perf_counter()
     dim = mesh.dim if volume_dim is None else volume_dim
     new = PlainSolver(new_part, solver.dtype, flux_kind=solver.kind, mode=solver.mode,
-                      state=np.zeros((5, new_part.N + new_part.G)), plan_options=_inherited_plan_options(solver))
+                      state="zeros", plan_options=_inherited_plan_options(solver))
     t3 = time.perf_counter()
     new.next, new.prev = solver.next, solver.prev
     ad = torch.from_numpy(adapt_data).cuda()
@@ -114,7 +114,7 @@ class PartitionedAdapt:
         # 2. the new partition and an empty solver for it
         self.new_part = self.new_mesh.partition(self.rank, self.world, subgrid=False, normal_dim=part.normal_dim)
         self.new_solver = PlainSolver(self.new_part, dtype, flux_kind=solver.kind, mode=solver.mode,
-                                      state=np.zeros((5, self.new_part.N + self.new_part.G)),
+                                      state="zeros",
                                       plan_options=_inherited_plan_options(solver))
         self.new_solver.next, self.new_solver.prev = solver.next, solver.prev
         # 3. message plan: intersections of what I have with what every rank will own (and vice versa)

@@ -10,7 +10,11 @@
 
 #include <omp.h>
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
+#include <memory>
+#include <vector>
 
 inline int host_threads() {
   static const int n = [] {
@@ -23,5 +27,42 @@ inline int host_threads() {
   }();
   return n;
 }
+
+// std::vector whose resize() leaves new elements of a trivial type uninitialised: for the large output arrays that a parallel
+// loop overwrites completely right away (a value-initialising resize is a serial pass over hundreds of MB).
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    using other = NoInitAlloc<U>;
+  };
+  NoInitAlloc() = default;
+  template <class U>
+  NoInitAlloc(const NoInitAlloc<U>&) {}
+  template <class U>
+  void construct(U* p) {
+    ::new (static_cast<void*>(p)) U;   // default-initialisation: nothing for trivial types
+  }
+  template <class U, class... A>
+  void construct(U* p, A&&... a) {
+    ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
+  }
+};
+template <class T>
+using uvector = std::vector<T, NoInitAlloc<T>>;
+
+// T8GPU_PLAN_VERBOSE=1: the planners print how long each of their phases took (scripts/host_cycle_time.py)
+struct PhaseTimer {
+  const char*                           who;
+  bool                                  on;
+  std::chrono::steady_clock::time_point prev;
+  explicit PhaseTimer(const char* w) : who(w), on(std::getenv("T8GPU_PLAN_VERBOSE") != nullptr), prev(std::chrono::steady_clock::now()) {}
+  void lap(const char* what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[%s] %-28s %.3f s\n", who, what, std::chrono::duration<double>(now - prev).count());
+    prev = now;
+  }
+};
 
 #endif  // T8GPU_HOST_THREADS_HPP

@@ -160,9 +160,9 @@ struct Part {
   int         rank = 0, nranks = 1, subgrid = 0, ndim = 3;
   int64_t     first = 0;
   int32_t     N = 0, G = 0, F = 0, B = 0;
-  std::vector<int32_t> fn;       // 2F + B
-  std::vector<double>  normals;  // ndim * (F + B)
-  std::vector<double>  areas;    // F + B
+  uvector<int32_t> fn;       // 2F + B      (uvector: sized, then written completely by parallel loops)
+  uvector<double>  normals;  // ndim * (F + B)
+  uvector<double>  areas;    // F + B
   std::vector<int32_t> level_diff, nb_offset;
   std::vector<int64_t> ghost_global;
   std::vector<int32_t> ghost_owner;
@@ -184,12 +184,13 @@ void build_part(Part& P) {
   const int64_t lo = (n * P.rank) / P.nranks, hi = (n * (P.rank + 1)) / P.nranks;
   P.first = lo;
   P.N     = static_cast<int32_t>(hi - lo);
+  PhaseTimer timer("synth part");
 
   struct RawFace {
     int64_t l, r;
     int     f;
   };
-  std::vector<RawFace> faces, walls;
+  uvector<RawFace> faces, walls;   // (sized by the counting pass, written by the second)
   // the faces a rank lists, in element order then face order (the single-rank listing rule). Two passes over the
   // elements that can touch the rank's range -- count, prefix sum, fill -- both parallel over elements.
   auto visit = [&](int64_t e, RawFace* fo, RawFace* wo, int32_t& nf, int32_t& nw) {
@@ -232,11 +233,14 @@ void build_part(Part& P) {
       visit(e, faces.data() + of[e], walls.data() + ow[e], a, b);
     }
   }
+  timer.lap("face listing");
   // ghosts: referenced elements outside [lo, hi), sorted by global index
   std::vector<int64_t> gh;
-  for (const RawFace& rf : faces) {
-    if (rf.l < lo || rf.l >= hi) gh.push_back(rf.l);
-    if (rf.r < lo || rf.r >= hi) gh.push_back(rf.r);
+  if (P.nranks > 1) {   // (one rank owns every element: nothing to look for)
+    for (const RawFace& rf : faces) {
+      if (rf.l < lo || rf.l >= hi) gh.push_back(rf.l);
+      if (rf.r < lo || rf.r >= hi) gh.push_back(rf.r);
+    }
   }
   std::sort(gh.begin(), gh.end());
   gh.erase(std::unique(gh.begin(), gh.end()), gh.end());
@@ -249,10 +253,11 @@ void build_part(Part& P) {
     return P.N + static_cast<int32_t>(std::lower_bound(gh.begin(), gh.end(), g) - gh.begin());
   };
 
+  timer.lap("ghost list");
   P.F = static_cast<int32_t>(faces.size());
   P.B = static_cast<int32_t>(walls.size());
   P.fn.resize(2 * static_cast<size_t>(P.F) + P.B);
-  P.normals.assign(static_cast<size_t>(P.ndim) * (P.F + P.B), 0.0);
+  P.normals.resize(static_cast<size_t>(P.ndim) * (P.F + P.B));
   P.areas.resize(static_cast<size_t>(P.F) + P.B);
   if (P.subgrid) {
     P.level_diff.resize(P.F);
@@ -260,7 +265,7 @@ void build_part(Part& P) {
   }
   auto geom = [&](size_t slot, int64_t e, int f) {
     const double h = std::ldexp(1.0, -M.leaves[e].level);
-    P.normals[P.ndim * slot + f / 2] = (f & 1) ? 1.0 : -1.0;
+    for (int d = 0; d < P.ndim; d++) P.normals[P.ndim * slot + d] = d == f / 2 ? ((f & 1) ? 1.0 : -1.0) : 0.0;
     P.areas[slot]                    = dim == 3 ? h * h : h;
   };
 #pragma omp parallel for num_threads(host_threads()) schedule(static)
@@ -285,11 +290,13 @@ void build_part(Part& P) {
       }
     }
   }
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
   for (int32_t i = 0; i < P.B; i++) {
     P.fn[2 * static_cast<size_t>(P.F) + i] = local(walls[i].l);
     geom(static_cast<size_t>(P.F) + i, walls[i].l, walls[i].f);
   }
 
+  timer.lap("face arrays");
   // peers + recv ranges (ghost slots are grouped by owner because sorted by global id)
   P.peers.clear();
   P.recv_off.assign(1, 0);
@@ -303,10 +310,12 @@ void build_part(Part& P) {
   // send lists: my elements that share a listed face with an element of peer p
   std::vector<std::vector<int32_t>> send(P.peers.size());
   auto peer_slot = [&](int r) { return static_cast<size_t>(std::lower_bound(P.peers.begin(), P.peers.end(), r) - P.peers.begin()); };
-  for (int32_t i = 0; i < P.F; i++) {
-    const int32_t l = P.fn[2 * static_cast<size_t>(i)], r = P.fn[2 * static_cast<size_t>(i) + 1];
-    if (l >= P.N && r < P.N) send[peer_slot(P.ghost_owner[l - P.N])].push_back(r);
-    if (r >= P.N && l < P.N) send[peer_slot(P.ghost_owner[r - P.N])].push_back(l);
+  if (!P.peers.empty()) {
+    for (int32_t i = 0; i < P.F; i++) {
+      const int32_t l = P.fn[2 * static_cast<size_t>(i)], r = P.fn[2 * static_cast<size_t>(i) + 1];
+      if (l >= P.N && r < P.N) send[peer_slot(P.ghost_owner[l - P.N])].push_back(r);
+      if (r >= P.N && l < P.N) send[peer_slot(P.ghost_owner[r - P.N])].push_back(l);
+    }
   }
   P.send_off.assign(1, 0);
   P.send_idx.clear();
@@ -316,6 +325,7 @@ void build_part(Part& P) {
     P.send_idx.insert(P.send_idx.end(), s.begin(), s.end());
     P.send_off.push_back(static_cast<int32_t>(P.send_idx.size()));
   }
+  timer.lap("peers + send lists");
 }
 
 // Kelvin-Helmholtz initial state at a point, SURVEY 8d (restating the values of
@@ -379,9 +389,9 @@ void t8gpu_synth_part_destroy(void* h) { delete static_cast<Part*>(h); }
 // (first element, ghost list): the initial condition of a partition can then be evaluated when -- and if -- it is asked for
 void t8gpu_synth_part_release_arrays(void* h) {
   Part* p = static_cast<Part*>(h);
-  std::vector<int32_t>().swap(p->fn);
-  std::vector<double>().swap(p->normals);
-  std::vector<double>().swap(p->areas);
+  uvector<int32_t>().swap(p->fn);
+  uvector<double>().swap(p->normals);
+  uvector<double>().swap(p->areas);
   std::vector<int32_t>().swap(p->level_diff);
   std::vector<int32_t>().swap(p->nb_offset);
 }
@@ -547,7 +557,9 @@ void t8gpu_synth_mesh_unmark_split_families(const void* mesh, int8_t* marks, con
   }
 }
 
-void* t8gpu_synth_mesh_adapt(const void* mesh, const int8_t* marks) {
+// The general procedure: rebuild the leaf list and the lookup grid after every balance round. Kept as the fallback of
+// t8gpu_synth_mesh_adapt below (which needs the old forest to be 2:1 balanced).
+static void* adapt_by_rounds(const void* mesh, const int8_t* marks) {
   const Mesh& O    = *static_cast<const Mesh*>(mesh);
   const int   nsub = 1 << O.dim;
   Mesh*       M    = new Mesh;
@@ -561,6 +573,7 @@ void* t8gpu_synth_mesh_adapt(const void* mesh, const int8_t* marks) {
     return nullptr;
   }
   M->lmax = newmax;
+  PhaseTimer timer("synth adapt (rounds)");
   // 1. refinements and tentative coarsenings; `origin` remembers how each new leaf was made:
   //    0 kept, 1 refined child, 2 coarsened parent (can be undone by the balance step)
   std::vector<uint8_t> origin;
@@ -588,7 +601,9 @@ void* t8gpu_synth_mesh_adapt(const void* mesh, const int8_t* marks) {
     }
     e++;
   }
+  timer.lap("refine / coarsen");
   M->fill_owner();
+  timer.lap("lookup grid");
   // 2. balance: a leaf two or more levels coarser than a face neighbour is split. A leaf made by
   //    coarsening goes back to its children (net change 0); a kept leaf is refined once (net +1).
   for (;;) {
@@ -619,9 +634,112 @@ void* t8gpu_synth_mesh_adapt(const void* mesh, const int8_t* marks) {
     M->leaves.swap(next);
     origin.swap(norigin);
     M->fill_owner();
+    timer.lap("balance round");
   }
+  timer.lap("balance check");
   return M;
 }
+
+// One pass over the OLD forest instead of a rebuilt forest per balance round. The old forest is 2:1 balanced, so the new
+// one (the coarsest balanced refinement of "old forest with the marks applied") never differs from it by more than one
+// level anywhere: the result is a level change d[e] in {-1, 0, +1} per old leaf (-1 for all members of a family or for
+// none), and balance is the least fixed point of "raise the coarser side of a face whose levels differ by two" -- iterated
+// on d with the OLD lookup grid, every face looked at from its finer-or-equal old leaf (whose coarser neighbour is unique).
+// The new leaves are then written in one parallel expansion and the lookup grid of the new forest is filled once
+// (it used to be rebuilt after every round: 512 MB per round at level 9).
+void* t8gpu_synth_mesh_adapt(const void* mesh, const int8_t* marks) {
+  const Mesh&   O    = *static_cast<const Mesh*>(mesh);
+  const int     nsub = 1 << O.dim;
+  const int64_t n    = static_cast<int64_t>(O.leaves.size());
+  PhaseTimer    timer("synth adapt");
+  int           newmax = O.lmax;
+#pragma omp parallel for num_threads(host_threads()) schedule(static) reduction(max : newmax)
+  for (int64_t e = 0; e < n; e++)
+    if (marks[e] > 0 && O.leaves[e].level + 1 > newmax) newmax = O.leaves[e].level + 1;
+  if (O.dim * newmax > 28) return nullptr;
+  std::vector<int8_t> d(static_cast<size_t>(n), 0);
+  auto get = [&](int64_t e) { return __atomic_load_n(&d[e], __ATOMIC_RELAXED); };
+  auto put = [&](int64_t e, int8_t v) { __atomic_store_n(&d[e], v, __ATOMIC_RELAXED); };
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
+  for (int64_t e = 0; e < n; e++) {
+    if (marks[e] > 0) {
+      d[e] = 1;
+    } else if (marks[e] < 0 && is_family_start(O, static_cast<size_t>(e))) {   // (families are disjoint: child 0 opens one)
+      bool all = true;
+      for (int ch = 0; ch < nsub; ch++) all = all && marks[e + ch] < 0;
+      if (all)
+        for (int ch = 0; ch < nsub; ch++) put(e + ch, -1);
+    }
+  }
+  timer.lap("marks -> level changes");
+  int broken = 0;
+  for (;;) {
+    int any = 0;
+#pragma omp parallel for num_threads(host_threads()) schedule(static) reduction(| : any, broken)
+    for (int64_t e = 0; e < n; e++) {
+      const Leaf& le = O.leaves[e];
+      for (int f = 0; f < 2 * O.dim; f++) {
+        const int32_t nb = O.across(static_cast<size_t>(e), f);
+        if (nb < 0) continue;
+        const Leaf& ln = O.leaves[nb];
+        if (ln.level > le.level) continue;   // that pair is looked at from the finer side
+        const int8_t dn = get(nb);
+        if (ln.level + dn >= le.level + get(e) - 1) continue;
+        any |= 1;
+        if (dn < 0) {   // the neighbour's family is not coarsened after all
+          int ch = 0;
+          for (int k = 0; k < O.dim; k++) ch |= static_cast<int>(ln.c[k] & 1u) << k;
+          for (int k = 0; k < nsub; k++) put(nb - ch + k, 0);
+        } else if (dn == 0) {
+          put(nb, 1);
+        } else {
+          broken |= 1;   // a second refinement: the old forest was not balanced
+        }
+      }
+    }
+    timer.lap("balance round");
+    if (!any || broken) break;
+  }
+  if (broken) return adapt_by_rounds(mesh, marks);
+  // the new leaves: every old leaf becomes itself, its children, or (the first member of a coarsened family) its parent
+  std::vector<int64_t> at(static_cast<size_t>(n) + 1, 0);
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
+  for (int64_t e = 0; e < n; e++) {
+    bool first = true;
+    if (d[e] < 0)
+      for (int k = 0; k < O.dim; k++) first = first && !(O.leaves[e].c[k] & 1u);
+    at[e + 1] = d[e] > 0 ? nsub : (d[e] < 0 ? (first ? 1 : 0) : 1);
+  }
+  for (int64_t e = 0; e < n; e++) at[e + 1] += at[e];
+  Mesh* M = new Mesh;
+  M->dim = O.dim; M->base = O.base; M->band = O.band; M->shrink = O.shrink; M->periodic = O.periodic;
+  M->lmax = newmax;
+  M->leaves.resize(static_cast<size_t>(at[n]));
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
+  for (int64_t e = 0; e < n; e++) {
+    const Leaf& l = O.leaves[e];
+    Leaf*       o = M->leaves.data() + at[e];
+    if (at[e + 1] == at[e]) continue;
+    if (d[e] > 0) {
+      for (int ch = 0; ch < nsub; ch++) {
+        o[ch].level = l.level + 1;
+        for (int k = 0; k < 3; k++) o[ch].c[k] = k < O.dim ? 2 * l.c[k] + ((ch >> k) & 1) : 0;
+      }
+    } else if (d[e] < 0) {
+      o->level = l.level - 1;
+      for (int k = 0; k < 3; k++) o->c[k] = l.c[k] >> 1;
+    } else {
+      *o = l;
+    }
+  }
+  timer.lap("new leaves");
+  M->fill_owner();
+  timer.lap("lookup grid");
+  return M;
+}
+
+// the general procedure by itself (tests compare the two)
+void* t8gpu_synth_mesh_adapt_by_rounds(const void* mesh, const int8_t* marks) { return adapt_by_rounds(mesh, marks); }
 
 int t8gpu_synth_mesh_adapt_data(const void* old_mesh, const void* new_mesh, int32_t* adapt_data) {
   const Mesh&  O = *static_cast<const Mesh*>(old_mesh);

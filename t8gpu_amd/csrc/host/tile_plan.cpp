@@ -64,23 +64,25 @@ struct TilePlan {
   int32_t N = 0, G = 0, F = 0, B = 0, ndim = 3, tmax = 256, fcap = 512;
   int32_t max_halo = 0, max_faces = 0, max_elems = 0, n_interior = 0, max_slots = 0, n_deep = 0;
   std::vector<int32_t>  elem_off, halo_off, face_off;  // [ntiles + 1]
-  std::vector<int32_t>  halo_ids;                      // slots
-  std::vector<uint32_t> face_lr;                       // l | r << 16 (tile-local; r = 0xFFFF: wall mirror)
-  std::vector<double>   face_geo;                      // [nfaces][4] = nx, ny, nz, area
-  std::vector<int32_t>  face_orig;                     // original face id if this tile reports its speed, else -1
+  // (uvector: sized once, then written completely by the parallel per-tile loops -- no value-initialising pass)
+  uvector<int32_t>      halo_ids;                      // slots
+  uvector<uint32_t>     face_lr;                       // l | r << 16 (tile-local; r = 0xFFFF: wall mirror)
+  uvector<double>       face_geo;                      // [nfaces][4] = nx, ny, nz, area
+  uvector<int32_t>      face_orig;                     // original face id if this tile reports its speed, else -1
   std::vector<int32_t>  csr_off;                       // [N + 1]
-  std::vector<uint16_t> csr_ent;                       // tile-local face | 0x8000 if the element is the RIGHT side
+  uvector<uint16_t>     csr_ent;                       // tile-local face | 0x8000 if the element is the RIGHT side
   std::vector<int32_t>  tile_order;                    // interior tiles first, then tiles that read ghost slots
   // compressed forms used by the pipelined kernel
   int32_t lecap = 512;                                 // max own + halo elements per tile
   int32_t ell_width = 0;                               // padded per-element face-list width (multiple of 8)
-  std::vector<uint16_t> ell;                           // [ell rows][ell_width], 0xFFFF = padding (generic tiles' elements only)
+  uvector<uint16_t>     ell;                           // [ell rows][ell_width], 0xFFFF = padding (generic tiles' elements only)
   std::vector<int32_t>  ell_row0;                      // [ntiles + 1] first ELL row of each tile
-  std::vector<uint16_t> geo_idx;                       // per tile face: row of geo_table (13 bits) | direction code << 13
+  uvector<uint16_t>     geo_idx;                       // per tile face: row of geo_table (13 bits) | direction code << 13
                                                        // (empty if more than 8191 distinct rows)
   std::vector<double>   geo_table;                     // [n_geo][12]: n, area, t1, 0, t2, 0
   // structured patches (see find_patches): tiles the patch kernel evaluates without face records
   int32_t want_patches = 0;
+  bool    skip_face_geo = false;                       // leave face_geo empty when the plan has a geometry dictionary
   std::vector<Patch>   patches;                        // in element order
   std::vector<int32_t> tile_patch;                     // [ntiles] index into patches, or -1 (generic tile)
   int32_t n_patch_class[3] = {0, 0, 0};                // leading patch tiles of the deep / near / ghost-reading class
@@ -285,14 +287,8 @@ void find_patches3(TilePlan& P, const int32_t* fn, const double* normals, const 
 
 void build(TilePlan& P, const int32_t* fn, const double* normals, const double* areas) {
   const int32_t N = P.N, F = P.F, B = P.B;
-  const bool verbose = std::getenv("T8GPU_PLAN_VERBOSE") != nullptr;
-  auto       tprev   = std::chrono::steady_clock::now();
-  auto lap = [&](const char* what) {
-    if (!verbose) return;
-    const auto now = std::chrono::steady_clock::now();
-    std::fprintf(stderr, "[tile_plan] %-28s %.2f s\n", what, std::chrono::duration<double>(now - tprev).count());
-    tprev = now;
-  };
+  PhaseTimer timer("tile_plan");
+  auto       lap = [&](const char* what) { timer.lap(what); };
   // faces of each owned element, in original face order (interior faces first, then walls): counted and placed in
   // parallel over the faces (atomic cursors), then every element's short list is sorted back into ascending face id
   std::vector<int32_t> deg(static_cast<size_t>(N) + 1, 0);
@@ -331,39 +327,88 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
   // greedy tiling: grow the element range while elements <= tmax, distinct faces <= fcap and own + halo
   // elements <= lecap (the kernel's LDS window). The halo count is tracked incrementally: an element that
   // joins the tile stops being halo, its neighbours outside the range become halo.
-  P.elem_off.assign(1, 0);
-  std::vector<int32_t> seen(static_cast<size_t>(F) + B, -1);
+  // A patch is a tile of its own, so the stretches of other elements between patches are tiled independently of each other:
+  // in parallel, one run at a time. Long stretches are cut every kRunCut elements as well (a fixed rule: the tiling does not
+  // depend on the number of threads); the faces / halo elements of the tile under construction sit in two small hash sets.
   {
-    std::vector<int32_t> hstamp(static_cast<size_t>(N) + P.G, -1);
-    int32_t e = 0, tile = 0;
-    while (e < N) {
-      if (patch_at[e] >= 0) {   // a patch is a tile of its own
+    constexpr int32_t kRunCut = 1 << 16;
+    std::vector<std::pair<int32_t, int32_t>> runs;
+    for (int32_t e = 0; e < N;) {
+      if (patch_at[e] >= 0) {
         e += kPatchElems;
-        P.elem_off.push_back(e);
-        tile++;
         continue;
       }
-      int32_t nf = 0, nh = 0, start = e;
-      while (e < N && e - start < P.tmax && patch_at[e] < 0) {
-        int32_t add = 0, dh = hstamp[e] == tile ? -1 : 0;
-        for (int32_t j = deg[e]; j < deg[e + 1]; j++) {
-          if (seen[ef[j]] != tile) add++;
-          for (int w = 0; w < 2; w++) {
-            const int32_t o = side(ef[j], w);
-            if (o >= 0 && (o < start || o > e) && hstamp[o] != tile) {
-              hstamp[o] = tile;   // (stamped even if e is rejected below: the tile ends there, the stamp with it)
-              dh++;
-            }
-          }
-        }
-        if (e > start && (nf + add > P.fcap || (e - start + 1) + nh + dh > P.lecap)) break;
-        for (int32_t j = deg[e]; j < deg[e + 1]; j++) seen[ef[j]] = tile;
-        nf += add;
-        nh += dh;
-        e++;
+      const int32_t start = e;
+      while (e < N && patch_at[e] < 0 && e - start < kRunCut) e++;
+      runs.push_back({start, e});
+    }
+    struct StampSet {   // open addressing, emptied in O(1) by moving to the next generation
+      std::vector<int32_t> key, gen;
+      int32_t              cur = 0;
+      uint32_t             mask;
+      int                  shift;
+      explicit StampSet(int log2cap) : key(size_t(1) << log2cap), gen(size_t(1) << log2cap, -1), mask((1u << log2cap) - 1u), shift(32 - log2cap) {}
+      void clear() { cur++; }
+      bool contains(int32_t k) const {
+        for (uint32_t h = (static_cast<uint32_t>(k) * 2654435761u) >> shift; gen[h] == cur; h = (h + 1) & mask)
+          if (key[h] == k) return true;
+        return false;
       }
-      P.elem_off.push_back(e);
-      tile++;
+      bool insert(int32_t k) {   // true: was not there
+        uint32_t h = (static_cast<uint32_t>(k) * 2654435761u) >> shift;
+        for (; gen[h] == cur; h = (h + 1) & mask)
+          if (key[h] == k) return false;
+        gen[h] = cur;
+        key[h] = k;
+        return true;
+      }
+    };
+    int32_t most = 0;   // faces of one element
+#pragma omp parallel for num_threads(host_threads()) schedule(static) reduction(max : most)
+    for (int32_t e = 0; e < N; e++) most = std::max(most, deg[e + 1] - deg[e]);
+    int log2cap = 12;   // >= 4 x the entries a tile can hold (a tile ends at fcap faces / lecap slots, plus one element's worth)
+    while (log2cap < 30 && (int64_t(1) << log2cap) < 4 * (int64_t(std::max(P.fcap, P.lecap)) + 2 * int64_t(most) + 64)) log2cap++;
+    std::vector<std::vector<int32_t>> ends(runs.size());
+#pragma omp parallel num_threads(host_threads())
+    {
+      StampSet faces(log2cap), halo(log2cap);
+#pragma omp for schedule(dynamic, 1)
+      for (int64_t r = 0; r < static_cast<int64_t>(runs.size()); r++) {
+        int32_t       e = runs[r].first;
+        const int32_t stop = runs[r].second;
+        while (e < stop) {
+          faces.clear();
+          halo.clear();
+          int32_t nf = 0, nh = 0;
+          const int32_t start = e;
+          while (e < stop && e - start < P.tmax) {
+            int32_t add = 0, dh = halo.contains(e) ? -1 : 0;
+            for (int32_t j = deg[e]; j < deg[e + 1]; j++) {
+              if (faces.insert(ef[j])) add++;   // (inserted even if e is rejected below: the tile ends there, the sets with it)
+              for (int w = 0; w < 2; w++) {
+                const int32_t o = side(ef[j], w);
+                if (o >= 0 && (o < start || o > e) && halo.insert(o)) dh++;
+              }
+            }
+            if (e > start && (nf + add > P.fcap || (e - start + 1) + nh + dh > P.lecap)) break;
+            nf += add;
+            nh += dh;
+            e++;
+          }
+          ends[r].push_back(e);
+        }
+      }
+    }
+    P.elem_off.assign(1, 0);
+    size_t r = 0;
+    for (int32_t e = 0; e < N;) {   // patches and runs alternate in element order
+      if (patch_at[e] >= 0) {
+        e += kPatchElems;
+        P.elem_off.push_back(e);
+      } else {
+        P.elem_off.insert(P.elem_off.end(), ends[r].begin(), ends[r].end());
+        e = runs[r++].second;
+      }
     }
   }
   lap("greedy tiling");
@@ -375,7 +420,7 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
     {
       std::vector<int32_t>                     out;
       std::vector<std::pair<int32_t, int32_t>> work;
-#pragma omp for schedule(static)
+#pragma omp for schedule(dynamic, 64)
       for (int32_t t = 0; t < nt0; t++) {
         if (patch_at[P.elem_off[t]] >= 0) continue;
         work.assign(1, {P.elem_off[t], P.elem_off[t + 1]});
@@ -444,7 +489,7 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
   std::vector<std::vector<int32_t>> tfs(ntiles), halos(ntiles);
 #pragma omp parallel num_threads(host_threads())
   {
-#pragma omp for schedule(static)
+#pragma omp for schedule(dynamic, 64)
     for (int32_t t = 0; t < ntiles; t++) {
       std::vector<int32_t>&tf = tfs[t], &halo = halos[t];
       tile_lists(t, tf, halo);
@@ -464,17 +509,122 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
     P.halo_off[t + 1] += P.halo_off[t];
     P.face_off[t + 1] += P.face_off[t];
   }
+  lap("per-tile lists (sizes)");
+  // Dictionary of the distinct {nx, ny, nz, area} tuples (exact bit patterns) of the mesh's faces: Cartesian AMR meshes
+  // have a few dozen, so a tile face carries a 2-byte index instead of 4 float_type values. Built over the ORIGINAL faces
+  // (every thread collects the distinct tuples of its share; on a curved mesh each gives up after 8192), then every
+  // original face gets its row | direction code << 13, which pass 2 below copies to the tile faces.
+  uvector<uint16_t> orig_gidx;
+  {
+    struct Key {
+      uint64_t w[4];
+      bool     operator<(const Key& o) const { return std::lexicographical_compare(w, w + 4, o.w, o.w + 4); }
+      bool     operator==(const Key& o) const { return std::equal(w, w + 4, o.w); }
+    };
+    struct KeyHash {
+      size_t operator()(const Key& k) const {
+        uint64_t h = 0x9E3779B97F4A7C15ull;
+        for (int i = 0; i < 4; i++) h = (h ^ k.w[i]) * 0xff51afd7ed558ccdull + (h >> 29);
+        return static_cast<size_t>(h);
+      }
+    };
+    const int64_t nof = static_cast<int64_t>(F) + B;
+    auto key_of = [&](int64_t f, double* g) {
+      for (int k = 0; k < 3; k++) g[k] = k < P.ndim ? normals[static_cast<size_t>(P.ndim) * f + k] : 0.0;
+      g[3] = areas[f];
+      Key key;
+      std::memcpy(key.w, g, 32);
+      return key;
+    };
+    constexpr size_t kMaxRows = 8191;   // 13 bits of row index: the upper 3 bits of geo_idx carry the direction code
+    std::vector<Key> uniq;
+    bool             too_many = false;
+    // (a few dozen tuples repeat millions of times: a small direct-mapped cache of recent keys answers nearly every face)
+    constexpr int kCache = 256;
+    auto slot_of = [](const Key& k) {
+      const uint64_t h = (k.w[0] ^ (k.w[1] * 3) ^ (k.w[2] * 7) ^ (k.w[3] * 13)) * 0x9E3779B97F4A7C15ull;
+      return static_cast<int>(h >> 56);
+    };
+#pragma omp parallel num_threads(host_threads())
+    {
+      std::unordered_set<Key, KeyHash> set;
+      std::vector<Key>                 cache(kCache);
+      std::vector<uint8_t>             full(kCache, 0);
+#pragma omp for schedule(static) nowait
+      for (int64_t f = 0; f < nof; f++) {
+        if (set.size() > kMaxRows) continue;
+        double    g[4];
+        const Key key = key_of(f, g);
+        const int c   = slot_of(key);
+        if (full[c] && key == cache[c]) continue;
+        cache[c] = key;
+        full[c]  = 1;
+        set.insert(key);
+      }
+#pragma omp critical
+      {
+        if (set.size() > kMaxRows) too_many = true;
+        if (!too_many) uniq.insert(uniq.end(), set.begin(), set.end());
+      }
+    }
+    if (!too_many) {
+      std::sort(uniq.begin(), uniq.end());   // (sorted: the table does not depend on the order of discovery)
+      uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+      too_many = uniq.size() > kMaxRows;
+    }
+    if (!too_many && nof > 0) {
+      // table row = {nx, ny, nz, area, t1x, t1y, t1z, 0, t2x, t2y, t2z, 0}: the face frame (the reference
+      // rebuilds it per face and stage, kernels.cu:174-193) is computed once per distinct normal
+      P.geo_table.assign(uniq.size() * 12, 0.0);
+      for (size_t i = 0; i < uniq.size(); i++) {
+        double* row = &P.geo_table[12 * i];
+        std::memcpy(row, uniq[i].w, 32);
+        const double* n = row;
+        double t1[3] = {n[1], n[2], -n[0]};
+        const double dp = n[0] * t1[0] + n[1] * t1[1] + n[2] * t1[2];
+        for (int k = 0; k < 3; k++) t1[k] -= dp * n[k];
+        const double nrm = std::sqrt(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]);
+        for (int k = 0; k < 3; k++) row[4 + k] = t1[k] / nrm;
+        row[8]  = n[1] * row[6] - n[2] * row[5];
+        row[9]  = n[2] * row[4] - n[0] * row[6];
+        row[10] = n[0] * row[5] - n[1] * row[4];
+      }
+      orig_gidx.resize(static_cast<size_t>(nof));
+#pragma omp parallel num_threads(host_threads())
+      {
+        std::vector<Key>      cache(kCache);
+        std::vector<uint32_t> value(kCache, 0xFFFFFFFFu);   // row | code << 13 of the cached key
+#pragma omp for schedule(static)
+        for (int64_t f = 0; f < nof; f++) {
+          double    g[4];
+          const Key key = key_of(f, g);
+          const int c   = slot_of(key);
+          if (value[c] == 0xFFFFFFFFu || !(key == cache[c])) {
+            const unsigned row  = static_cast<unsigned>(std::lower_bound(uniq.begin(), uniq.end(), key) - uniq.begin());
+            const unsigned code = static_cast<unsigned>(direction_code(g, 3));
+            cache[c] = key;
+            value[c] = row | (code << 13);
+          }
+          orig_gidx[f] = static_cast<uint16_t>(value[c]);
+        }
+      }
+    }
+  }
+  const bool have_dict = !orig_gidx.empty();
+  const bool fill_geo  = !(have_dict && P.skip_face_geo);
+  lap("geometry dictionary");
   for (int32_t e = 0; e < N; e++) P.csr_off[e + 1] = deg[e + 1];   // one entry per (element, face) incidence
   P.halo_ids.resize(P.halo_off[ntiles]);
   P.face_lr.resize(P.face_off[ntiles]);
-  P.face_geo.resize(4 * static_cast<size_t>(P.face_off[ntiles]));
+  if (fill_geo) P.face_geo.resize(4 * static_cast<size_t>(P.face_off[ntiles]));
+  if (have_dict) P.geo_idx.resize(P.face_off[ntiles]);
   P.face_orig.resize(P.face_off[ntiles]);
   P.csr_ent.resize(deg[N]);
 #pragma omp parallel num_threads(host_threads())
   {
     std::vector<int32_t> order, where;
     std::vector<uint8_t> codes;
-#pragma omp for schedule(static)
+#pragma omp for schedule(dynamic, 64)
     for (int32_t t = 0; t < ntiles; t++) {
       const int32_t e0 = P.elem_off[t], e1 = P.elem_off[t + 1], ne = e1 - e0;
       const std::vector<int32_t>&tf = tfs[t], &halo = halos[t];
@@ -509,8 +659,11 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
         const int32_t l = side(f, 0), r = side(f, 1);
         const uint32_t ll = loc(l), rr = r < 0 ? 0xFFFFu : loc(r);
         P.face_lr[q] = ll | (rr << 16);
-        for (int k = 0; k < 3; k++) P.face_geo[4 * q + k] = k < P.ndim ? normals[static_cast<size_t>(P.ndim) * f + k] : 0.0;
-        P.face_geo[4 * q + 3] = areas[f];
+        if (fill_geo) {
+          for (int k = 0; k < 3; k++) P.face_geo[4 * q + k] = k < P.ndim ? normals[static_cast<size_t>(P.ndim) * f + k] : 0.0;
+          P.face_geo[4 * q + 3] = areas[f];
+        }
+        if (have_dict) P.geo_idx[q] = orig_gidx[f];
         // the tile owning the left element reports the speed estimate (left is always owned or, for a
         // face whose left side is a ghost, the tile of the right element does)
         const int32_t reporter = (l < N) ? l : r;
@@ -573,7 +726,7 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
   for (int32_t t = 0; t < ntiles; t++)
     P.ell_row0[t + 1] = P.ell_row0[t] + (P.tile_patch[t] >= 0 ? 0 : P.elem_off[t + 1] - P.elem_off[t]);
   P.ell.resize(static_cast<size_t>(P.ell_row0[ntiles]) * P.ell_width);
-#pragma omp parallel for num_threads(host_threads()) schedule(static)
+#pragma omp parallel for num_threads(host_threads()) schedule(dynamic, 64)
   for (int32_t t = 0; t < ntiles; t++) {
     if (P.tile_patch[t] >= 0) continue;
     for (int32_t e = P.elem_off[t]; e < P.elem_off[t + 1]; e++) {
@@ -584,65 +737,6 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
   }
 
   lap("ELL rows");
-  // dictionary of distinct {nx, ny, nz, area} tuples (exact bit patterns): Cartesian AMR meshes have a
-  // few dozen, so a face needs a 2-byte index instead of 4 float_type values
-  {
-    struct Key {
-      uint64_t w[4];
-      bool     operator<(const Key& o) const { return std::lexicographical_compare(w, w + 4, o.w, o.w + 4); }
-      bool     operator==(const Key& o) const { return std::equal(w, w + 4, o.w); }
-    };
-    const size_t     nfaces = P.face_lr.size();
-    // distinct rows through a hash set (a sort of all n_faces 32-byte keys was a third of the planning time);
-    // the few survivors are sorted so that the table does not depend on the order of discovery
-    struct KeyHash {
-      size_t operator()(const Key& k) const {
-        uint64_t h = 0x9E3779B97F4A7C15ull;
-        for (int i = 0; i < 4; i++) h = (h ^ k.w[i]) * 0xff51afd7ed558ccdull + (h >> 29);
-        return static_cast<size_t>(h);
-      }
-    };
-    std::unordered_set<Key, KeyHash> set;
-    bool                             too_many = false;
-    for (size_t f = 0; f < nfaces && !too_many; f++) {
-      Key k;
-      std::memcpy(k.w, &P.face_geo[4 * f], 32);
-      set.insert(k);
-      too_many = set.size() > 8191;   // 13 bits of row index: the upper 3 bits of geo_idx carry the direction code
-    }
-    std::vector<Key> uniq;
-    if (!too_many) uniq.assign(set.begin(), set.end());
-    std::sort(uniq.begin(), uniq.end());
-    if (too_many) uniq.resize(8192);   // (only its size is looked at below)
-    if (uniq.size() <= 8191) {
-      // table row = {nx, ny, nz, area, t1x, t1y, t1z, 0, t2x, t2y, t2z, 0}: the face frame (the reference
-      // rebuilds it per face and stage, kernels.cu:174-193) is computed once per distinct normal
-      P.geo_table.assign(uniq.size() * 12, 0.0);
-      for (size_t i = 0; i < uniq.size(); i++) {
-        double* row = &P.geo_table[12 * i];
-        std::memcpy(row, uniq[i].w, 32);
-        const double* n = row;
-        double t1[3] = {n[1], n[2], -n[0]};
-        const double dp = n[0] * t1[0] + n[1] * t1[1] + n[2] * t1[2];
-        for (int k = 0; k < 3; k++) t1[k] -= dp * n[k];
-        const double nrm = std::sqrt(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]);
-        for (int k = 0; k < 3; k++) row[4 + k] = t1[k] / nrm;
-        row[8]  = n[1] * row[6] - n[2] * row[5];
-        row[9]  = n[2] * row[4] - n[0] * row[6];
-        row[10] = n[0] * row[5] - n[1] * row[4];
-      }
-      P.geo_idx.resize(nfaces);
-#pragma omp parallel for num_threads(host_threads()) schedule(static)
-      for (int64_t f = 0; f < static_cast<int64_t>(nfaces); f++) {
-        Key k;
-        std::memcpy(k.w, &P.face_geo[4 * static_cast<size_t>(f)], 32);
-        const unsigned row  = static_cast<unsigned>(std::lower_bound(uniq.begin(), uniq.end(), k) - uniq.begin());
-        const unsigned code = static_cast<unsigned>(direction_code(&P.face_geo[4 * static_cast<size_t>(f)], 3));
-        P.geo_idx[f]        = static_cast<uint16_t>(row | (code << 13));
-      }
-    }
-  }
-  lap("geometry dictionary");
 }
 
 }  // namespace
@@ -651,13 +745,15 @@ extern "C" {
 
 // fn = [2F + B] reference face_neighbors (local slots), normals = [ndim * (F + B)], areas = [F + B].
 // Returns null if a limit of the packed format is exceeded (tile-local index >= 0xFFFF, > 32767 faces).
-// flags bit 0: cut structured patches (find_patches) out of the tiling
+// flags bit 0 / 1: cut structured 2D / 3D patches (find_patches, find_patches3) out of the tiling; bit 2: the caller does not
+// read `face_geo` when the plan has a geometry dictionary (sizes[11] > 0): it is left empty then
 void* t8gpu_plan_plain_create_ex(int32_t N, int32_t G, int32_t F, int32_t B, int32_t ndim, const int32_t* fn,
                                  const double* normals, const double* areas, int32_t tmax, int32_t fcap, int32_t flags) {
   if (N < 0 || F < 0 || B < 0 || ndim < 2 || ndim > 3 || tmax < 1 || tmax > 1024 || fcap < 1) return nullptr;
   TilePlan* P = new TilePlan;
   P->N = N; P->G = G; P->F = F; P->B = B; P->ndim = ndim; P->tmax = tmax; P->fcap = fcap;
-  P->want_patches = flags & 3;   // bit 0: 2D patches (16 x 16), bit 1: 3D patches (8 x 8 x 4)
+  P->want_patches  = flags & 3;   // bit 0: 2D patches (16 x 16), bit 1: 3D patches (8 x 8 x 4)
+  P->skip_face_geo = (flags & 4) != 0;   // bit 2: no face_geo rows if the plan has a geometry dictionary
   build(*P, fn, normals, areas);
   if (P->max_elems + P->max_halo >= 0xFFFF || P->max_faces > 0x7FFE) {
     delete P;

@@ -49,7 +49,7 @@ class HostPlainPlan:
         assert fn.size == 2 * F + B and nr.size == ndim * (F + B) and ar.size == F + B
         p = _synth._p
         # patches: True = both kinds (16 x 16 quadrilateral blocks, 8 x 8 x 4 hexahedral blocks), 2 / 3 = that kind only
-        pflags = {False: 0, True: 3, 2: 1, 3: 2}[patches]
+        pflags = {False: 0, True: 3, 2: 1, 3: 2}[patches] | (0 if want_face_geo else 4)
         h = lib.t8gpu_plan_plain_create_ex(N, G, F, B, ndim, p(fn), p(nr), p(ar), tmax, fcap, pflags)
         if not h:
             raise ValueError("tile plan exceeds the packed index format (use smaller tmax / fcap)")
@@ -59,22 +59,23 @@ class HostPlainPlan:
             (self.ntiles, n_halo, n_faces, n_csr, self.max_elems, self.max_halo, self.max_faces,
              self.n_interior) = (int(x) for x in sz[:8])
             self.N, self.F, self.B, self.tmax, self.fcap = N, F, B, tmax, fcap
+            # (np.empty: t8gpu_plan_plain_arrays / _compressed overwrite every entry)
             self.elem_off = np.zeros(self.ntiles + 1, np.int32)
             self.halo_off = np.zeros(self.ntiles + 1, np.int32)
             self.face_off = np.zeros(self.ntiles + 1, np.int32)
-            self.halo_ids = np.zeros(n_halo, np.int32)
-            self.face_lr = np.zeros(n_faces, np.uint32)
+            self.halo_ids = np.empty(n_halo, np.int32)
+            self.face_lr = np.empty(n_faces, np.uint32)
             n_geo_rows = int(sz[11])
-            self.face_geo = np.zeros((0 if (n_geo_rows and not want_face_geo) else n_faces, 4), np.float64)
-            self.face_orig = np.zeros(n_faces, np.int32)
-            self.csr_off = np.zeros(N + 1, np.int32)
-            self.csr_ent = np.zeros(n_csr, np.uint16)
+            self.face_geo = np.empty((0 if (n_geo_rows and not want_face_geo) else n_faces, 4), np.float64)
+            self.face_orig = np.empty(n_faces, np.int32)
+            self.csr_off = np.empty(N + 1, np.int32)
+            self.csr_ent = np.empty(n_csr, np.uint16)
             self.tile_order = np.zeros(self.ntiles, np.int32)
             lib.t8gpu_plan_plain_arrays(h, *(p(getattr(self, f)) if getattr(self, f).size else None for f in self.FIELDS))
             self.ell_width, n_geo, self.max_slots, self.n_deep = int(sz[10]), int(sz[11]), int(sz[12]), int(sz[13])
             self.n_ell_rows = int(sz[15])                  # rows exist for the elements of generic tiles only (tile_desc word 6)
-            self.ell = np.zeros((max(1, self.n_ell_rows), self.ell_width), np.uint16)
-            self.geo_idx = np.zeros(n_faces if n_geo else 0, np.uint16)
+            self.ell = (np.empty if self.n_ell_rows else np.zeros)((max(1, self.n_ell_rows), self.ell_width), np.uint16)
+            self.geo_idx = np.empty(n_faces if n_geo else 0, np.uint16)
             self.geo_table = np.zeros((n_geo, 12), np.float64)
             lib.t8gpu_plan_plain_compressed(h, p(self.ell), p(self.geo_idx) if n_geo else None,
                                             p(self.geo_table) if n_geo else None)

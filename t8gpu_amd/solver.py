@@ -55,13 +55,13 @@ class PlainSolver:
         self.N, self.G, self.F, self.B, self.ndim = part.N, part.G, part.F, part.B, part.normal_dim
         self.stride = capacity or tot
         self.planes = torch.zeros((26, self.stride), dtype=dtype, device="cuda")
-        ic = part.kh_initial_state() if state is None else state
-        self.planes[0:5, :tot] = _dev(ic, dtype)
+        if not (isinstance(state, str) and state == "zeros"):     # "zeros": the caller fills the planes on the device (amr.adapt)
+            ic = part.kh_initial_state() if state is None else state
+            self.planes[0:5, :tot] = _dev(ic, dtype)
         self.planes[25, :tot] = _dev(part.volumes, dtype)
         self.fn = _dev(part.face_neighbors)
         self.indices = None  # ghosts already resolve to local slots
-        self.normals = _dev(part.normals, dtype)
-        self.areas = _dev(part.areas, dtype)
+        self._normals = self._areas = None     # per-face geometry of the compat kernels: uploaded when first asked for
         self.speed = torch.zeros(max(1, part.F + part.B), dtype=dtype, device="cuda")
         self.next, self.prev = STEP0, STEP3  # solver.h:100-101
         self.plan = None
@@ -73,6 +73,20 @@ class PlainSolver:
             self.plan_build_s = time.perf_counter() - t0          # host tile plan + its upload (amr.adapt reports it)
         elif mode != "compat":
             raise ValueError(mode)
+
+    @property
+    def normals(self):
+        """device copy of face_normals (the fused kernels read the tile plan's geometry instead: an adaptive fused run never
+        uploads these 24 bytes per face)"""
+        if self._normals is None:
+            self._normals = _dev(self.part.normals, self.dtype)
+        return self._normals
+
+    @property
+    def areas(self):
+        if self._areas is None:
+            self._areas = _dev(self.part.areas, self.dtype)
+        return self._areas
 
     # -- accessors named after the reference API ------------------------------------------------
     def get_own_variables(self, step):

@@ -32,6 +32,8 @@ def lib():
         _lib.t8gpu_synth_mesh_unmark_split_families.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib.t8gpu_synth_mesh_adapt.restype = C.c_void_p
         _lib.t8gpu_synth_mesh_adapt.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.t8gpu_synth_mesh_adapt_by_rounds.restype = C.c_void_p
+        _lib.t8gpu_synth_mesh_adapt_by_rounds.argtypes = [C.c_void_p, C.c_void_p]
         _lib.t8gpu_synth_mesh_adapt_data.restype = C.c_int
         _lib.t8gpu_synth_mesh_adapt_data.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     return _lib
@@ -81,11 +83,12 @@ class SynthMesh:
         lib().t8gpu_synth_mesh_unmark_split_families(self._h, _p(marks), _p(off), int(off.size))
         return marks
 
-    def adapt(self, marks):
-        """Returns (new mesh, adapt_data[n_new + 1]); every element changes by at most one level."""
+    def adapt(self, marks, by_rounds=False):
+        """Returns (new mesh, adapt_data[n_new + 1]); every element changes by at most one level.
+        by_rounds=True: the provider's general procedure (tests compare it with the one-pass default)."""
         marks = np.ascontiguousarray(marks, np.int8)
         assert marks.size == self.num_elements
-        h = lib().t8gpu_synth_mesh_adapt(self._h, _p(marks))
+        h = (lib().t8gpu_synth_mesh_adapt_by_rounds if by_rounds else lib().t8gpu_synth_mesh_adapt)(self._h, _p(marks))
         if not h:
             raise ValueError("adaptation exceeds the finest representable level")
         new = object.__new__(SynthMesh)
@@ -94,7 +97,7 @@ class SynthMesh:
         new.num_elements = lib().t8gpu_synth_mesh_num_elements(h)
         new.finest_level = lib().t8gpu_synth_mesh_finest_level(h)
         new.max_level = max(self.max_level, new.finest_level)
-        adapt_data = np.zeros(new.num_elements + 1, np.int32)
+        adapt_data = np.empty(new.num_elements + 1, np.int32)
         if lib().t8gpu_synth_mesh_adapt_data(self._h, h, _p(adapt_data)) != 0:
             raise RuntimeError("old and new forests are not one refinement / coarsening step apart")
         return new, adapt_data
@@ -114,21 +117,22 @@ class Partition:
         if not h:
             raise ValueError("invalid partition parameters")
         try:
+            # (np.empty below: the provider overwrites every entry of these arrays)
             cnt = np.zeros(8, np.int64)
             lib().t8gpu_synth_part_counts(h, _p(cnt))
             self.N, self.G, self.F, self.B, npeer, nsend = (int(x) for x in cnt[:6])
             self.first_global, self.num_global = int(cnt[6]), int(cnt[7])
-            self.face_neighbors = np.zeros(2 * self.F + self.B, np.int32)
-            self.normals = np.zeros(normal_dim * (self.F + self.B), np.float64)
-            self.areas = np.zeros(self.F + self.B, np.float64)
-            self.level_diff = np.zeros(self.F, np.int32) if subgrid else None
-            self.nb_offset = np.zeros(dim * self.F, np.int32) if subgrid else None
+            self.face_neighbors = np.empty(2 * self.F + self.B, np.int32)
+            self.normals = np.empty(normal_dim * (self.F + self.B), np.float64)
+            self.areas = np.empty(self.F + self.B, np.float64)
+            self.level_diff = np.empty(self.F, np.int32) if subgrid else None
+            self.nb_offset = np.empty(dim * self.F, np.int32) if subgrid else None
             lib().t8gpu_synth_part_connectivity(h, _p(self.face_neighbors), _p(self.normals), _p(self.areas),
                                                 _p(self.level_diff), _p(self.nb_offset))
             tot = self.N + self.G
-            self.levels = np.zeros(tot, np.int32)
-            self.volumes = np.zeros(tot, np.float64)
-            self.centres = np.zeros((tot, 3), np.float64)
+            self.levels = np.empty(tot, np.int32)
+            self.volumes = np.empty(tot, np.float64)
+            self.centres = np.empty((tot, 3), np.float64)
             lib().t8gpu_synth_part_elements(h, _p(self.levels), _p(self.volumes), _p(self.centres))
             self.ghost_global = np.zeros(self.G, np.int64)
             self.ghost_owner = np.zeros(self.G, np.int32)

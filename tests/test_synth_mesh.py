@@ -127,3 +127,26 @@ def test_adapt_refine_coarsen_balance_and_correspondence(dim):
     fam = np.zeros(up.num_elements)
     fam[np.arange(up.num_elements) % nsub >= 4] = 1000.0
     assert (up.marks_from_criteria(fam, 10.0, 0, 9, family_members_averaged=4)[np.arange(up.num_elements) % nsub < 4] == -1).all() or dim == 2
+
+
+@pytest.mark.parametrize("dim,base,lmax,periodic", [(2, 2, 6, True), (2, 3, 6, False), (3, 2, 5, True), (3, 2, 4, False)])
+def test_one_pass_adapt_equals_adapt_by_rounds(dim, base, lmax, periodic):
+    """The provider's one-pass adapt (level changes on the old forest, one lookup-grid fill) gives the forest of the general
+    procedure (leaf list + lookup grid rebuilt after every balance round), over a chain of random adapts: refinement ripples,
+    families whose coarsening the balance takes back, walls and periodic wraps."""
+    rng = np.random.default_rng(11 * dim + lmax)
+    m = SynthMesh(dim, base, lmax, band=0.08, periodic=periodic)
+    for step in range(6):
+        lv = m.partition().levels[:m.num_elements]
+        r = rng.random(m.num_elements)
+        marks = np.zeros(m.num_elements, np.int8)
+        marks[(r < (0.02, 0.3, 0.05)[step % 3]) & (lv < lmax + 1)] = 1
+        marks[r > (0.5, 0.9, 0.2)[step % 3]] = -1
+        a, ad_a = m.adapt(marks)
+        b, ad_b = m.adapt(marks, by_rounds=True)
+        pa, pb = a.partition(), b.partition()
+        assert a.num_elements == b.num_elements and np.array_equal(ad_a, ad_b)
+        assert np.array_equal(pa.levels, pb.levels) and np.array_equal(pa.centres, pb.centres)
+        assert np.array_equal(pa.face_neighbors, pb.face_neighbors) and np.array_equal(pa.areas, pb.areas)
+        assert a.num_elements != m.num_elements or step > 0
+        m = a
