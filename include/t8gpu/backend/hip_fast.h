@@ -140,10 +140,10 @@ namespace t8gpu::hip {
     /// them) and the communicator; iterate_fused then exchanges the ghost layer per stage (csrc/hip/stepper.hip).
     explicit PlainFusedPlan(HostMeshArrays const& m, int ndim = 3, int tmax = 256, int fcap = 512, HostHaloArrays const* halo = nullptr,
                             Communicator const* comm = nullptr) {
-      // (flags 3: structured patches -- 16 x 16 quadrilateral / 8 x 8 x 4 hexahedral blocks -- are cut out of the tiling and run through the patch kernels)
+      // (flags 3 | 8: structured patches -- 16 x 16 quadrilateral / 8 x 8 x 4 hexahedral blocks, the irregular 3D ones included -- are cut out of the tiling and run through the patch kernels)
       void* h = t8gpu_plan_plain_create_ex(m.num_local_elements, m.num_ghost_elements, m.num_local_faces,
                                            m.num_local_boundary_faces, ndim, m.face_neighbors.data(), m.face_normals.data(),
-                                           m.face_surfaces.data(), tmax, fcap, 3);
+                                           m.face_surfaces.data(), tmax, fcap, 3 | 8);
       if (!h) T8GPU_ABORT("t8gpu_plan_plain_create_ex failed");
       int64_t sz[16];
       t8gpu_plan_plain_sizes(h, sz);
@@ -160,6 +160,8 @@ namespace t8gpu::hip {
       t8gpu_plan_plain_tile_desc(h, tile_desc.data());
       int32_t patch_counts[4];
       t8gpu_plan_plain_patch_counts(h, patch_counts);
+      int32_t irregular_counts[3];
+      t8gpu_plan_plain_irregular_counts(h, irregular_counts);
       const int32_t patch_dim = t8gpu_plan_plain_patch_dim(h);
       t8gpu_plan_plain_destroy(h);
       m_plan.elem_off   = up(elem_off);
@@ -183,6 +185,7 @@ namespace t8gpu::hip {
       m_plan.n_deep_tiles = static_cast<int32_t>(sz[13]);
       m_plan.n_slots_addressed = m.num_local_elements + m.num_ghost_elements;
       for (int c = 0; c < 3; c++) m_plan.n_patch_tiles[c] = patch_counts[c];
+      for (int c = 0; c < 3; c++) m_plan.n_irregular_tiles[c] = irregular_counts[c];
       m_plan.patch_dim = patch_dim;
       T8gpuHalo  hl{};
       const bool multi = halo && comm && !halo->peers.empty();

@@ -175,6 +175,10 @@ typedef struct T8gpuPlainPlan {
   int32_t patch_dim;          /* 2: the 16 x 16 patches above; 3: 8 x 8 x 4 blocks of same-size hexahedra (256 halo entries:
                                * -x 32 | +x 32 | -y 32 | +y 32 | -z 64 | +z 64; own faces fbase + 3 t + {0, 1, 2}; flags bits 0-2:
                                * -y before -x, -z before -x, -z before -y where both coordinates of the pair are 0); 0: no patches */
+  int32_t n_irregular_tiles[3]; /* ABI 6: the LAST so many of the n_patch_tiles[c] patch tiles of class c are IRREGULAR 3D patches
+                               * (t8gpu_host.h: t8gpu_plan_plain_create_ex flag 8): descriptor word 5 has 0x800, word 4 is the
+                               * first of 512 face_lr / face_orig entries with the per-cell words. They run through the
+                               * irregular instantiation of k_plain_patch3 in a launch of their own */
 } T8gpuPlainPlan;
 
 /* tile_begin/tile_count select a range of tile_order (0, ntiles = everything; [0, n_interior) can run

@@ -72,6 +72,13 @@ void* t8gpu_plan_plain_create_ex(int32_t N, int32_t G, int32_t F, int32_t B, int
 void  t8gpu_plan_plain_destroy(void* plan);
 /* counts[4] = leading patch tiles of the deep / near-boundary / ghost-reading class of tile_order, total */
 void  t8gpu_plan_plain_patch_counts(const void* plan, int32_t* counts);
+/* flags bit 3 of t8gpu_plan_plain_create_ex (with bit 1): IRREGULAR 3D patches too -- the same blocks next to a periodic
+ * wrap, a wall or a coarser neighbour across a - side, where who lists a side face (and so the order of a cell's six face
+ * ids) differs from cell to cell. tile_desc word 5 has 0x800, word 4 = first of 512 entries of face_lr / face_orig holding,
+ * for cell c: face_lr[w + c] = sides the cell lists (bit per t8code face) | walls << 6 | the six sides in ascending face id
+ * << 12 (3 bits each); face_orig[w + c] / face_orig[w + 256 + c] = id of the cell's first own interior / wall face (-1:
+ * none). They are the LAST patch tiles of every class: counts[3] = how many (t8gpu_plan_plain_irregular_counts). */
+void  t8gpu_plan_plain_irregular_counts(const void* plan, int32_t* counts);
 /* flags bit 1 of t8gpu_plan_plain_create_ex: 3D patches -- 8 x 8 x 4 same-size hexahedra that are 256 consecutive elements
  * in Morton order (find_patches3); tile_desc = {first element, 256, first halo entry, 256, id of the first own face,
  * 0x300 | flags, area}, halo = [-x 32 | +x 32 | -y 32 | +y 32 | -z 64 | +z 64]. A plan holds one kind of patch.

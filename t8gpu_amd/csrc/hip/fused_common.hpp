@@ -128,10 +128,11 @@ template <class T>
 int plain_patch_stage(int kind, int stage, const T8gpuPlainPlan* plan, int patch_begin, int patch_count, int tile_begin, int tile_count,
                       FVars<T> prev, FVars<T> mid, FVars<T> out, const T* volume, T dt, T* speed, bool persistent, hipStream_t stream);
 
-// 3D structured patches (kernels_fused_patch3.hip): [tile_begin, +tile_count) of tile_order are 8 x 8 x 4 patch tiles
+// 3D structured patches (kernels_fused_patch3.hip): [tile_begin, +tile_count) of tile_order are 8 x 8 x 4 patch tiles, all
+// regular or (irregular = true) all irregular ones
 template <class T>
 int plain_patch3_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count, FVars<T> prev, FVars<T> mid,
-                       FVars<T> out, const T* volume, T dt, T* speed, bool persistent, hipStream_t stream);
+                       FVars<T> out, const T* volume, T dt, T* speed, bool persistent, bool irregular, hipStream_t stream);
 
 }  // namespace t8gpu_hip
 

@@ -259,9 +259,19 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
       // (Measured and dropped: the generic tiles on a side stream forked from / joined to the caller's stream by events, so
       //  that they run BESIDE the patches -- c5 5 235 -> 5 078, c5u 5 070 -> 4 716 M/s: the fork / join events cost more than
       //  the overlap returns, as with the Subgrid leftover blocks of round 2.)
-      const int rc = plain_patch3_stage<T>(kind, stage, plan, pb, pe - pb, fmk<T>(prev), fmk<T>(mid), fmk<T>(out), volume, dt, speed,
-                                           whole || persistent_always, static_cast<hipStream_t>(stream));
-      if (rc != 0) return rc;
+      // (the class's patch tiles are [regular | irregular]: one launch each)
+      const int ni = plan->n_irregular_tiles[c];
+      if (ni < 0 || ni > plan->n_patch_tiles[c]) return static_cast<int>(hipErrorInvalidValue);
+      const int i0 = p1 - ni;   // first irregular patch of the class
+      const int rb = pb, re = pe < i0 ? pe : i0, ib = pb > i0 ? pb : i0, ie = pe;
+      if (re > rb)
+        if (int rc = plain_patch3_stage<T>(kind, stage, plan, rb, re - rb, fmk<T>(prev), fmk<T>(mid), fmk<T>(out), volume, dt, speed,
+                                           whole || persistent_always, false, static_cast<hipStream_t>(stream)))
+          return rc;
+      if (ie > ib)
+        if (int rc = plain_patch3_stage<T>(kind, stage, plan, ib, ie - ib, fmk<T>(prev), fmk<T>(mid), fmk<T>(out), volume, dt, speed,
+                                           whole || persistent_always, true, static_cast<hipStream_t>(stream)))
+          return rc;
     } else if (pe > pb) {
       if (int rc = flush()) return rc;
       // patches and generic tiles of the class in ONE launch where the patches carry most of it (the generic tiles then

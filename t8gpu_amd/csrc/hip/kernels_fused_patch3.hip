@@ -41,7 +41,10 @@ T8_DEV int patch3_ctz(int v) { return v == 0 ? 8 : __builtin_ctz(static_cast<uns
 
 // (second launch bound = wavefronts per SIMD the register allocation must allow: two 8-wave workgroups per CU in fp64 --
 //  77 KB of LDS each --, three in fp32)
-template <class T, int KIND, int STAGE>
+// IRR: the launch covers IRREGULAR patches (descriptor flag 0x800, csrc/host/tile_plan.cpp) -- the same block, with every side
+// face evaluated in the orientation its per-cell words give and the six fluxes of a cell added in the listed order. A separate
+// instantiation: the regular one keeps its register budget.
+template <class T, int KIND, int STAGE, bool IRR>
 __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8gpuPlainPlan P, int tile_begin, int tile_count, FVars<T> prev,
                                                                                  FVars<T> src, FVars<T> out, const T* __restrict__ vol, T dt,
                                                                                  T* __restrict__ speed) {
@@ -131,6 +134,22 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
   for (; t < tend; t += stride) {
     const Desc d2   = load_desc(t + 2 * stride);
     const int  hs_c = side ? P.halo_ids[d2.h0 + hl] : 0;
+    // irregular patch (0x800): the per-cell words of the lane's cell -- and, on the - side lanes, of the boundary cell whose -
+    // face they take. Requested BEFORE the next tile's states: vmcnt retires in order, their wait must not include those.
+    constexpr bool irr = IRR;
+    unsigned   ia = 0, ib = 0;
+    int        id_a = -1, idw_a = -1, id_b = -1, idw_b = -1;
+    if (irr) {
+      const unsigned q0 = static_cast<unsigned>(d0.fbase);   // (descriptor word 4 of an irregular patch: where its words start)
+      ia    = P.face_lr[q0 + c];
+      id_a  = P.face_orig[q0 + c];
+      idw_a = P.face_orig[q0 + 256 + c];
+      if (minus) {
+        ib    = P.face_lr[q0 + m_r];
+        id_b  = P.face_orig[q0 + m_r];
+        idw_b = P.face_orig[q0 + 256 + m_r];
+      }
+    }
     T          nxt[5];
     if (t + stride < tend) fetch(d1, hs_b, nxt);
     const int e = d0.e0 + c;
@@ -156,7 +175,34 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
     __syncthreads();
 
     // ---- phase 2 -----------------------------------------------------------------------------------------------------------
-    if (!side) {
+    if (irr) {   // every side face in its listed orientation (patch_common.hpp: patch_face3g); interior faces come out the same
+      T g[5], sp;
+      if (!side) {
+#pragma unroll 1
+        for (int a = 0; a < 2; a++) {   // the +x and the +y face of the lane's cell
+          const int  sd  = 2 * a + 1;
+          const bool own = (ia >> sd) & 1u;
+          patch_face3g<T, KIND, NW>(a, true, own, (ia >> (6 + sd)) & 1u, pe + c * REC, pe + (a == 0 ? rx : ry) * REC, area, g, sp);
+#pragma unroll
+          for (int k = 0; k < 5; k++) ff[k * kP3FF + 256 * a + c] = g[k];
+          if (speed && own) speed[patch3_own_id(ia, id_a, idw_a, sd)] = sp;
+        }
+      } else {
+        const bool own = (ia >> 5) & 1u;
+        patch_face3g<T, KIND, NW>(2, true, own, (ia >> 11) & 1u, pe + c * REC, pe + rz * REC, area, g, sp);
+#pragma unroll
+        for (int k = 0; k < 5; k++) ff[k * kP3FF + 512 + c] = g[k];
+        if (speed && own) speed[patch3_own_id(ia, id_a, idw_a, 5)] = sp;
+        if (minus) {
+          const int  ax   = m < 32 ? 0 : (m < 64 ? 1 : 2);
+          const bool mown = (ib >> (2 * ax)) & 1u;
+          patch_face3g<T, KIND, NW>(ax, false, mown, (ib >> (6 + 2 * ax)) & 1u, pe + m_r * REC, pe + m_l * REC, area, g, sp);
+#pragma unroll
+          for (int k = 0; k < 5; k++) ff[k * kP3FF + 768 + m] = g[k];
+          if (speed && mown) speed[patch3_own_id(ib, id_b, idw_b, 2 * ax)] = sp;
+        }
+      }
+    } else if (!side) {
       T wr[NW], g[5], sx, sy;
       rec_load<T, NW>(pe + rx * REC, wr);
       patch_face3<T, KIND, NW>(0, mine, wr, area, g, sx);
@@ -196,7 +242,21 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
     __syncthreads();
 
     // ---- phase 3: six fluxes in ascending face id, RK stage ------------------------------------------------------------------
-    if (!side) {
+    if (!side && irr) {   // the six sides in the listed order (ascending face id), - for the faces the cell lists itself
+      const unsigned ord = ia >> 12;
+      T              acc[5] = {T(0), T(0), T(0), T(0), T(0)};
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        const int sd  = (ord >> (3 * q)) & 7u;
+        const int pos = sd == 0 ? a_mx : (sd == 1 ? c : (sd == 2 ? a_my : (sd == 3 ? 256 + c : (sd == 4 ? a_mz : 512 + c))));
+        const T   sg  = (ia >> sd) & 1u ? T(-1) : T(1);
+#pragma unroll
+        for (int k = 0; k < 5; k++) acc[k] = __builtin_fma(sg, ff[k * kP3FF + pos], acc[k]);
+      }
+      const T scale = dt / volume;
+#pragma unroll
+      for (int k = 0; k < 5; k++) at32<T>(out.p[k], static_cast<unsigned>(e)) = rk_stage_update<T, STAGE>(pv[k], cur[k], scale, acc[k]);
+    } else if (!side) {
       const bool yx = f_yx ? (d0.flags & 1) != 0 : r_yx;   // -y before -x
       const bool zx = f_zx ? (d0.flags & 2) != 0 : r_zx;   // -z before -x
       const bool zy = f_zy ? (d0.flags & 4) != 0 : r_zy;   // -z before -y
@@ -230,8 +290,9 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
 // workgroup (class-split multi-rank launches).
 template <class T>
 int plain_patch3_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count, FVars<T> prev, FVars<T> mid,
-                       FVars<T> out, const T* volume, T dt, T* speed, bool persistent, hipStream_t stream) {
+                       FVars<T> out, const T* volume, T dt, T* speed, bool persistent, bool irregular, hipStream_t stream) {
   if (tile_count <= 0) return 0;
+  if (irregular && (!plan->face_lr || !plan->face_orig)) return static_cast<int>(hipErrorInvalidValue);
   if (!plan->tile_desc) return static_cast<int>(hipErrorInvalidValue);
   // (the kernel addresses a plane by a 32-bit byte offset, patch_common.hpp: at32)
   if (plan->n_slots_addressed <= 0 || static_cast<unsigned long long>(plan->n_slots_addressed) * sizeof(T) >= (1ull << 32))
@@ -254,16 +315,24 @@ int plain_patch3_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile
   const int  resident  = cus * per_cu;
   const int  grid_size = (!persistent || tile_count < resident) ? tile_count : resident;
   const dim3 grid(grid_size), block(512);
-  note_stage_kernel(tile_count, "k_plain_patch3<T, K, S>", static_cast<int>(sizeof(T)), kind, stage);
-#define T8_P3(K, S)                                                                                                          \
+  note_stage_kernel(tile_count, irregular ? "k_plain_patch3<T, K, S, true>" : "k_plain_patch3<T, K, S, false>", static_cast<int>(sizeof(T)), kind,
+                    stage);
+#define T8_P3I(K, S, I)                                                                                                      \
   do {                                                                                                                       \
     if (lds > 64 * 1024) {                                                                                                   \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_plain_patch3<T, K, S>),                            \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_plain_patch3<T, K, S, I>),                         \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                 \
       if (e != hipSuccess) return static_cast<int>(e);                                                                       \
     }                                                                                                                        \
-    hipLaunchKernelGGL((k_plain_patch3<T, K, S>), grid, block, lds, stream, *plan, tile_begin, tile_count, prev, mid, out, volume, dt, \
-                       speed);                                                                                               \
+    hipLaunchKernelGGL((k_plain_patch3<T, K, S, I>), grid, block, lds, stream, *plan, tile_begin, tile_count, prev, mid, out, volume, \
+                       dt, speed);                                                                                           \
+  } while (0)
+#define T8_P3(K, S)          \
+  do {                       \
+    if (irregular)           \
+      T8_P3I(K, S, true);    \
+    else                     \
+      T8_P3I(K, S, false);   \
   } while (0)
 #define T8_P3S(K)          \
   do {                     \
@@ -282,12 +351,13 @@ int plain_patch3_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile
     T8_P3S(2);
 #undef T8_P3S
 #undef T8_P3
+#undef T8_P3I
   return static_cast<int>(hipGetLastError());
 }
 
 template int plain_patch3_stage<float>(int, int, const T8gpuPlainPlan*, int, int, FVars<float>, FVars<float>, FVars<float>, const float*,
-                                       float, float*, bool, hipStream_t);
+                                       float, float*, bool, bool, hipStream_t);
 template int plain_patch3_stage<double>(int, int, const T8gpuPlainPlan*, int, int, FVars<double>, FVars<double>, FVars<double>,
-                                        const double*, double, double*, bool, hipStream_t);
+                                        const double*, double, double*, bool, bool, hipStream_t);
 
 }  // namespace t8gpu_hip

@@ -41,13 +41,23 @@ namespace {
 // added in the order of the owning neighbours' indices: pairwise "-y before -x" iff ctz(j) >= ctz(i), "-z before -x" iff
 // ctz(k) >= ctz(i), "-z before -y" iff ctz(k) >= ctz(j); where BOTH coordinates of a pair are 0 the patch's position in
 // the forest decides -- three flag bits per patch (bit 0: y before x, bit 1: z before x, bit 2: z before y).
-constexpr int kPatchSide = 16, kPatchElems = 256, kPatchHalo = 64, kPatchHalo3 = 256;
+// IRREGULAR 3D patches (flag 0x800): the same 8 x 8 x 4 block with sides that are not listed that way -- a periodic wrap
+// (the cell across has the lower index on a + side, the higher one on a - side), a coarser neighbour across a - side (the
+// finer cell lists a hanging face), a wall. Every cell still has exactly one face per side, of the patch's area, with one
+// element (or a wall) behind it; what varies per cell is WHO lists each side face and the order of the six ids. The
+// planner writes that down per cell (Patch::info: own-side mask, wall mask, the six sides in ascending face id, the ids of
+// the first own interior / wall face) and the kernel evaluates each side face in its listed orientation; the interior of
+// the block is as in a regular patch. Blocks next to the domain boundary (13 % of the c5 benchmark mesh) become patches.
+constexpr int kPatchSide = 16, kPatchElems = 256, kPatchHalo = 64, kPatchHalo3 = 256, kPatchInfoWords = 512;
 struct Patch {
   int32_t e0 = 0, fbase = 0, flags = 0;   // 2D: flags bit 0: element 0 adds its -y face before its -x face; 3D: see above
   int32_t dim = 2, nh = kPatchHalo;
   double  area = 0;
   double  volume = 0;        // > 0: every element of the patch has exactly this volume (t8gpu_plan_plain_patch_volumes)
   int32_t halo[kPatchHalo3];
+  // IRREGULAR 3D patches (flags 0x800, see find_patches3): per cell {sides | walls << 6 | summation order << 12, id of its first
+  // own interior face or -1, id of its first wall face or -1}; empty for regular patches
+  std::vector<int32_t> info;
 };
 
 inline int morton2(int i, int j) {
@@ -86,6 +96,7 @@ struct TilePlan {
   std::vector<Patch>   patches;                        // in element order
   std::vector<int32_t> tile_patch;                     // [ntiles] index into patches, or -1 (generic tile)
   int32_t n_patch_class[3] = {0, 0, 0};                // leading patch tiles of the deep / near / ghost-reading class
+  int32_t n_irregular_class[3] = {0, 0, 0};            // ... the last so many of which are irregular patches
 };
 
 // Direction code of a unit normal: 2 * axis + (1 if it points along +axis) for an EXACT axis normal (one component
@@ -213,6 +224,86 @@ void find_patches3(TilePlan& P, const int32_t* fn, const double* normals, const 
       if (n[a] == 1.0) return a;
     return -1;
   };
+  // The irregular form (see the top of the file): tried where the regular checks fail. Sides are numbered like t8code
+  // faces (0 -x, 1 +x, 2 -y, 3 +y, 4 -z, 5 +z), which is also the order in which an element lists its own faces.
+  auto irregular = [&](int32_t e0, Patch& pt) -> bool {
+    pt       = Patch();
+    pt.dim   = 3;
+    pt.nh    = kPatchHalo3;
+    pt.e0    = e0;
+    pt.flags = 0x800;
+    pt.info.assign(3 * kPatchElems, -1);
+    const int ext[3] = {8, 8, 4};
+    for (int t = 0; t < kPatchElems; t++) {
+      const int32_t e = e0 + t;
+      if (deg[e + 1] - deg[e] != 6) return false;
+      const int32_t* fl      = &ef[deg[e]];
+      const int      ijk[3]  = {li[t], lj[t], lk[t]};
+      uint32_t       own = 0, wall = 0, order = 0, seen = 0;
+      int32_t        first_id = -1, wall_first = -1, id_of[6] = {-1, -1, -1, -1, -1, -1};
+      for (int q = 0; q < 6; q++) {
+        const int32_t f       = fl[q];
+        const bool    is_wall = f >= F;
+        const int32_t l = is_wall ? fn[2 * static_cast<size_t>(F) + (f - F)] : fn[2 * static_cast<size_t>(f)];
+        const int32_t r = is_wall ? -1 : fn[2 * static_cast<size_t>(f) + 1];
+        const double* n = normals + static_cast<size_t>(3) * f;
+        int           axis = -1;
+        for (int a = 0; a < 3; a++) {
+          if (n[a] == 0.0) continue;
+          if ((n[a] != 1.0 && n[a] != -1.0) || axis >= 0) return false;
+          axis = a;
+        }
+        if (axis < 0) return false;
+        if (t == 0 && q == 0) pt.area = areas[f];
+        if (areas[f] != pt.area) return false;
+        bool mine_;
+        if (l == e && r != e) mine_ = true;
+        else if (r == e && l != e) mine_ = false;
+        else return false;
+        const bool plus = mine_ ? n[axis] > 0.0 : n[axis] < 0.0;   // (the normal points away from the listing element)
+        const int  sd   = 2 * axis + (plus ? 1 : 0);
+        if (seen & (1u << sd)) return false;
+        seen |= 1u << sd;
+        order |= static_cast<uint32_t>(sd) << (3 * q);
+        id_of[sd] = f;
+        if (mine_) {
+          own |= 1u << sd;
+          if (is_wall) {
+            wall |= 1u << sd;
+            if (wall_first < 0) wall_first = f;
+          } else if (first_id < 0) {
+            first_id = f;
+          }
+        }
+        const int32_t nb     = is_wall ? e : (mine_ ? r : l);
+        const bool    inside = plus ? ijk[axis] < ext[axis] - 1 : ijk[axis] > 0;
+        if (inside) {   // the interior of the block is as in a regular patch
+          int nijk[3] = {ijk[0], ijk[1], ijk[2]};
+          nijk[axis] += plus ? 1 : -1;
+          if (is_wall || mine_ != plus || nb != e0 + morton3(nijk[0], nijk[1], nijk[2])) return false;
+        } else {
+          if (!is_wall && nb >= e0 && nb < e0 + kPatchElems) return false;
+          if (!mine_ && nb >= N) return false;   // (a face listed by a ghost is reported by its right element's tile: not a patch)
+          const int u = axis == 0 ? ijk[1] : ijk[0], v = axis == 2 ? ijk[1] : ijk[2];
+          const int base = axis == 0 ? (plus ? 32 : 0) : (axis == 1 ? (plus ? 96 : 64) : (plus ? 192 : 128));
+          pt.halo[base + u + 8 * v] = nb;
+        }
+      }
+      // an element lists its own faces in side order, interior faces and walls each with consecutive ids
+      const uint32_t own_int = own & ~wall;
+      for (int sd = 0; sd < 6; sd++) {
+        if (own_int & (1u << sd)) {
+          if (id_of[sd] != first_id + __builtin_popcount(own_int & ((1u << sd) - 1u))) return false;
+        } else if (wall & (1u << sd)) {
+          if (id_of[sd] != wall_first + __builtin_popcount(wall & ((1u << sd) - 1u))) return false;
+        }
+      }
+      pt.info[3 * t]     = static_cast<int32_t>(own | (wall << 6) | (order << 12));
+      pt.info[3 * t + 1] = first_id;
+      pt.info[3 * t + 2] = wall_first;
+    }
+    return true;
+  };
   // Every element is tested as a patch START on its own, in parallel: two patches cannot overlap (the checks pin a start
   // to the origin of an aligned block -- element e0 + 1 must be its +x neighbour, e0 + 2 the +y neighbour, and so on through
   // the Morton pattern), so there is no scan order to respect. Almost every candidate fails at its first element.
@@ -277,6 +368,7 @@ void find_patches3(TilePlan& P, const int32_t* fn, const double* normals, const 
         if (k < 3) ok = ok && pl[2] == e0 + morton3(i, j, k + 1); else { ok = ok && outside(pl[2]); pt.halo[192 + i + 8 * j] = pl[2]; }
         if (k > 0) ok = ok && mi[2] == e0 + morton3(i, j, k - 1); else { ok = ok && owned_outside(mi[2]); pt.halo[128 + i + 8 * j] = mi[2]; }
       }
+      if (!ok && (P.want_patches & 8)) ok = irregular(e0, pt);
       if (ok) mine.push_back(pt);
     }
   }
@@ -493,7 +585,9 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
     for (int32_t t = 0; t < ntiles; t++) {
       std::vector<int32_t>&tf = tfs[t], &halo = halos[t];
       tile_lists(t, tf, halo);
-      P.face_off[t + 1] = static_cast<int32_t>(tf.size());
+      // (an irregular patch keeps its per-cell words where a generic tile keeps face records: 512 entries of face_lr / face_orig)
+      const bool irregular = P.tile_patch[t] >= 0 && !P.patches[P.tile_patch[t]].info.empty();
+      P.face_off[t + 1] = irregular ? kPatchInfoWords : static_cast<int32_t>(tf.size());
       P.halo_off[t + 1] = static_cast<int32_t>(halo.size());
       reads_ghost[t]    = !halo.empty() && *std::max_element(halo.begin(), halo.end()) >= N;
     }
@@ -631,6 +725,21 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
       if (P.tile_patch[t] >= 0) {
         for (int32_t j = deg[e0]; j < deg[e1]; j++) P.csr_ent[j] = static_cast<uint16_t>(0xFFFFu);   // (never read)
         std::copy(halo.begin(), halo.end(), P.halo_ids.begin() + P.halo_off[t]);
+        const std::vector<int32_t>& info = P.patches[P.tile_patch[t]].info;
+        if (!info.empty()) {   // face_lr[q0 + c] = sides | walls | order, face_orig[q0 + c] / [q0 + 256 + c] = first own interior / wall id
+          const size_t q0 = P.face_off[t];
+          for (int c = 0; c < kPatchElems; c++) {
+            P.face_lr[q0 + c]                 = static_cast<uint32_t>(info[3 * c]);
+            P.face_lr[q0 + kPatchElems + c]   = 0u;
+            P.face_orig[q0 + c]               = info[3 * c + 1];
+            P.face_orig[q0 + kPatchElems + c] = info[3 * c + 2];
+          }
+          for (size_t q = q0; q < q0 + kPatchInfoWords; q++) {
+            if (fill_geo)
+              for (int k = 0; k < 4; k++) P.face_geo[4 * q + k] = 0.0;
+            if (have_dict) P.geo_idx[q] = 0;
+          }
+        }
         continue;
       }
       auto loc = [&](int32_t s) -> uint32_t {
@@ -698,13 +807,18 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
   // (inside every class the patch tiles come first: a launch over a range of tile_order is a patch-kernel launch over
   // the patch tiles in it and a generic launch over the rest)
   P.tile_order.clear();
-  auto append_class = [&](int cls) {
-    for (int pass = 0; pass < 2; pass++) {
+  auto append_class = [&](int cls) {   // regular patches, irregular patches, generic tiles
+    for (int pass = 0; pass < 3; pass++) {
+      const int32_t before = static_cast<int32_t>(P.tile_order.size());
       for (int32_t t = 0; t < ntiles; t++) {
-        const int c = reads_ghost[t] ? 2 : (near_boundary[t] ? 1 : 0);
-        if (c == cls && (P.tile_patch[t] >= 0) == (pass == 0)) P.tile_order.push_back(t);
+        const int c    = reads_ghost[t] ? 2 : (near_boundary[t] ? 1 : 0);
+        const int kind = P.tile_patch[t] < 0 ? 2 : (P.patches[P.tile_patch[t]].info.empty() ? 0 : 1);
+        if (c == cls && kind == pass) P.tile_order.push_back(t);
       }
-      if (pass == 0) P.n_patch_class[cls] = static_cast<int32_t>(P.tile_order.size());
+      if (pass == 1) {
+        P.n_irregular_class[cls] = static_cast<int32_t>(P.tile_order.size()) - before;
+        P.n_patch_class[cls]     = static_cast<int32_t>(P.tile_order.size());
+      }
     }
   };
   append_class(0);
@@ -752,7 +866,7 @@ void* t8gpu_plan_plain_create_ex(int32_t N, int32_t G, int32_t F, int32_t B, int
   if (N < 0 || F < 0 || B < 0 || ndim < 2 || ndim > 3 || tmax < 1 || tmax > 1024 || fcap < 1) return nullptr;
   TilePlan* P = new TilePlan;
   P->N = N; P->G = G; P->F = F; P->B = B; P->ndim = ndim; P->tmax = tmax; P->fcap = fcap;
-  P->want_patches  = flags & 3;   // bit 0: 2D patches (16 x 16), bit 1: 3D patches (8 x 8 x 4)
+  P->want_patches  = flags & 11;   // bit 0: 2D patches (16 x 16), bit 1: 3D patches (8 x 8 x 4), bit 3: irregular 3D patches too
   P->skip_face_geo = (flags & 4) != 0;   // bit 2: no face_geo rows if the plan has a geometry dictionary
   build(*P, fn, normals, areas);
   if (P->max_elems + P->max_halo >= 0xFFFF || P->max_faces > 0x7FFE) {
@@ -772,6 +886,11 @@ void t8gpu_plan_plain_patch_counts(const void* h, int32_t* counts) {
   const TilePlan* P = static_cast<const TilePlan*>(h);
   for (int c = 0; c < 3; c++) counts[c] = P->n_patch_class[c];
   counts[3] = static_cast<int32_t>(P->patches.size());
+}
+// counts[3] = how many of the patch tiles of each class are IRREGULAR patches (flag 0x800; the last ones among the class's patches)
+void t8gpu_plan_plain_irregular_counts(const void* h, int32_t* counts) {
+  const TilePlan* P = static_cast<const TilePlan*>(h);
+  for (int c = 0; c < 3; c++) counts[c] = P->n_irregular_class[c];
 }
 // Optional, after create and before t8gpu_plan_plain_tile_desc: volumes[N] of the owned elements. A patch whose 256 elements
 // all have bit for bit the same volume gets it into its descriptor (flag 0x400, words 1 and 3), and the kernels then skip
@@ -838,7 +957,7 @@ void t8gpu_plan_plain_tile_desc(const void* h, int32_t* tile_desc) {
     d[7] = 0;
     if (!P->tile_patch.empty() && P->tile_patch[t] >= 0) {   // patch tile: {e0, 256, first halo entry, 64 | 256, fbase, 0x100 | 0x200 (3D) | flags, area}
       const Patch& pt = P->patches[P->tile_patch[t]];
-      d[4] = pt.fbase;
+      d[4] = pt.info.empty() ? pt.fbase : P->face_off[t];   // (irregular patch: where its per-cell words start in face_lr / face_orig)
       d[5] = 0x100 | (pt.dim == 3 ? 0x200 : 0) | pt.flags;
       std::memcpy(d + 6, &pt.area, 8);
       if (pt.volume > 0.0) {   // uniform volume: flag 0x400, the double in words 1 and 3 (element / halo counts are implied)

@@ -13,11 +13,13 @@ class T8gpuPlainPlan(C.Structure):
         ("ntiles", C.c_int32), ("n_interior_tiles", C.c_int32), ("max_elems", C.c_int32), ("max_halo", C.c_int32),
         ("max_faces", C.c_int32), ("ell_width", C.c_int32), ("ell", C.c_void_p), ("geo_idx", C.c_void_p),
         ("geo_table", C.c_void_p), ("n_geo", C.c_int32), ("max_slots", C.c_int32), ("n_deep_tiles", C.c_int32),
-        ("n_slots_addressed", C.c_int32), ("tile_desc", C.c_void_p), ("n_patch_tiles", C.c_int32 * 3), ("patch_dim", C.c_int32)]
+        ("n_slots_addressed", C.c_int32), ("tile_desc", C.c_void_p), ("n_patch_tiles", C.c_int32 * 3), ("patch_dim", C.c_int32),
+                ("n_irregular_tiles", C.c_int32 * 3)]
 
 
 class PlainPlan:
-    def __init__(self, part, dtype, tmax=None, fcap=None, compressed=True, dictionary=True, patches=None, flux_kind=None):
+    def __init__(self, part, dtype, tmax=None, fcap=None, compressed=True, dictionary=True, patches=None, flux_kind=None,
+                 irregular=None):
         """compressed=False: generic kernel (CSR lists, full geometry). dictionary=False: pipelined kernel
         with per-face geometry rows even where the mesh has few distinct ones (what curved meshes get anyway).
         patches: cut structured 16 x 16 patches out of the tiling for the patch kernel (default: yes for the compressed
@@ -26,6 +28,8 @@ class PlainPlan:
         if patches is None:
             patches = compressed and os.environ.get("T8GPU_PATCH", "1") != "0"
         self.patches = patches if compressed else False          # True / False, or 2 / 3 for one kind only
+        # 3D: blocks next to periodic wraps / walls / coarser - side neighbours become (irregular) patches too
+        self.irregular = os.environ.get("T8GPU_PATCH_IRREGULAR", "1") != "0" if irregular is None else bool(irregular)
         # the patch kernels address a plane by a 32-bit byte offset: meshes whose planes reach 4 GiB keep the tile kernels
         if (part.N + part.G) * (4 if dtype == torch.float32 else 8) >= 2 ** 32:
             self.patches = False
@@ -64,7 +68,7 @@ class PlainPlan:
                     self.auto_fcap = 480
         fcap = int(os.environ.get("T8GPU_FCAP", 512)) if fcap is None else fcap
         # the per-face geometry rows are only read by the kernels without a dictionary (generic kernel, dictionary=False)
-        self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary), patches=self.patches)
+        self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary), patches=self.patches, irregular=self.irregular)
         if retry_768:
             # 480-face tiles only pay if the persistent kernel takes the plan: the LAUNCHER'S OWN test is asked (C-ABI query;
             # it covers the LDS margin, the tile-count gate for mid-size meshes, the flux kind and T8GPU_PERSISTENT=0 --
@@ -72,7 +76,7 @@ class PlainPlan:
             # better on 768-face tiles.
             if not (compressed and dictionary and self._persistent_accepts(self.host, dtype, flux_kind)):
                 fcap = self.auto_fcap = 768
-                self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary), patches=self.patches)
+                self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary), patches=self.patches, irregular=self.irregular)
         self.dtype = dtype
         self._keep = {}
         c = T8gpuPlainPlan()
@@ -81,7 +85,7 @@ class PlainPlan:
         skip_geo = (compressed and dictionary and h.geo_table.shape[0] > 0 and h.max_elems <= 256 and h.max_slots <= 512
                     and h.max_faces <= 1024)
         if not skip_geo and h.face_geo.shape[0] == 0 and h.face_lr.size:     # the kernels this plan gets do read the rows
-            self.host = h = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=True, patches=self.patches)
+            self.host = h = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=True, patches=self.patches, irregular=self.irregular)
         for name in HostPlainPlan.FIELDS:
             a = getattr(self.host, name)
             if name == "face_geo":
@@ -112,6 +116,7 @@ class PlainPlan:
         c.max_slots, c.n_deep_tiles = self.host.max_slots, self.host.n_deep
         for k in range(3):
             c.n_patch_tiles[k] = self.host.n_patch_class[k]
+            c.n_irregular_tiles[k] = self.host.n_irregular_class[k]
         c.patch_dim = self.host.patch_dim
         c.n_slots_addressed = part.N + part.G
         self.c = c

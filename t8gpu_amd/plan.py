@@ -17,6 +17,7 @@ def _lib():
         lib.t8gpu_plan_plain_create_ex.restype = C.c_void_p
         lib.t8gpu_plan_plain_create_ex.argtypes = [C.c_int32] * 5 + [C.c_void_p] * 3 + [C.c_int32] * 3
         lib.t8gpu_plan_plain_patch_counts.argtypes = [C.c_void_p] * 2
+        lib.t8gpu_plan_plain_irregular_counts.argtypes = [C.c_void_p] * 2
         lib.t8gpu_plan_plain_patch_dim.argtypes = [C.c_void_p]
         lib.t8gpu_plan_plain_patch_dim.restype = C.c_int32
         lib.t8gpu_plan_plain_patch_volumes.argtypes = [C.c_void_p, C.c_void_p]
@@ -37,7 +38,7 @@ class HostPlainPlan:
               "csr_ent", "tile_order")
 
     def __init__(self, N, G, F, B, ndim, face_neighbors, normals, areas, tmax=256, fcap=512, want_face_geo=True,
-                 patches=False, volumes=None):
+                 patches=False, volumes=None, irregular=True):
         """patches=True: structured 16 x 16 patches are cut out of the tiling (tile_plan.cpp: find_patches); they are
         tiles without face records (`tile_patch[t]` = 1), first inside every class of `tile_order` (`n_patch_class`).
         want_face_geo=False: leave `face_geo` (32 bytes per tile face, only read by the kernels that have no geometry
@@ -50,6 +51,8 @@ class HostPlainPlan:
         p = _synth._p
         # patches: True = both kinds (16 x 16 quadrilateral blocks, 8 x 8 x 4 hexahedral blocks), 2 / 3 = that kind only
         pflags = {False: 0, True: 3, 2: 1, 3: 2}[patches] | (0 if want_face_geo else 4)
+        if irregular and (pflags & 2):
+            pflags |= 8       # 3D blocks next to a periodic wrap / wall / coarser - side neighbour become (irregular) patches too
         h = lib.t8gpu_plan_plain_create_ex(N, G, F, B, ndim, p(fn), p(nr), p(ar), tmax, fcap, pflags)
         if not h:
             raise ValueError("tile plan exceeds the packed index format (use smaller tmax / fcap)")
@@ -90,11 +93,16 @@ class HostPlainPlan:
             cnt = np.zeros(4, np.int32)
             lib.t8gpu_plan_plain_patch_counts(h, p(cnt))
             self.n_patch_class, self.n_patches = tuple(int(x) for x in cnt[:3]), int(cnt[3])
+            lib.t8gpu_plan_plain_irregular_counts(h, p(cnt))
+            self.n_irregular_class = tuple(int(x) for x in cnt[:3])      # the last patch tiles of every class (flag 0x800)
             self.patch_dim = int(lib.t8gpu_plan_plain_patch_dim(h))            # 2 | 3 | 0 (no patch tiles)
             # per tile (index, not position): is it a patch tile? (tile_desc is in tile_order order)
+            # (word 5 of a GENERIC tile's descriptor is its face count: the flag bits mean something in patch descriptors only,
+            #  so the patch tiles are taken from their positions -- the first n_patch_class[c] of every class)
             self.tile_patch = np.zeros(self.ntiles, bool)
-            if self.ntiles:
-                self.tile_patch[self.tile_order] = (self.tile_desc[:self.ntiles, 5] & 0x100) != 0
+            n_deep, n_int = int(sz[13]), int(sz[7])
+            for c, a in enumerate((0, n_deep, n_int)):
+                self.tile_patch[self.tile_order[a:a + self.n_patch_class[c]]] = True
         finally:
             lib.t8gpu_plan_plain_destroy(h)
 

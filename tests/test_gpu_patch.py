@@ -71,6 +71,9 @@ def test_patch3_kernel_vs_oracle_and_bitwise_vs_tile_kernels(dtype, kind, mesh_a
     st = perturbed_state(part, 41)
     a, b = _pair(part, dtype, kind, st)
     assert a.plan.host.patch_dim == 3
+    # every one of these meshes has blocks next to a periodic wrap, a coarser neighbour or a wall: IRREGULAR patches (the
+    # irregular instantiation of k_plain_patch3) beside the regular ones
+    assert sum(a.plan.host.n_irregular_class) > 0 and (mesh_args["base_level"] < 5 or sum(a.plan.host.n_irregular_class) < a.plan.host.n_patches)
     o = O.PlainCase(part, NP[dtype], state=st)
     dt = 0.1 * 2.0 ** -mesh.finest_level
     a.iterate(dt)
@@ -86,6 +89,43 @@ def test_patch3_kernel_vs_oracle_and_bitwise_vs_tile_kernels(dtype, kind, mesh_a
         o.iterate(dt, kind=kind)
     assert rel_err(a.state().cpu().numpy(), o.current()[:, :part.N]) < TOL10[dtype]
     assert torch.equal(a.state(), b.state()) and torch.equal(a.speed, b.speed)
+
+
+@pytest.mark.parametrize("mesh_args", [dict(dim=3, base_level=4, max_level=4), dict(dim=3, base_level=4, max_level=6, band=0.1, periodic=False)])
+def test_irregular_patches_alone_and_switched_off(mesh_args):
+    """A 16^3 periodic cube is irregular patches only (every block touches a wrap); with irregular=False (T8GPU_PATCH_IRREGULAR=0)
+    those blocks stay generic tiles. Same bits either way, and through partial launches that cut the irregular range."""
+    mesh = SynthMesh(**mesh_args)
+    part = mesh.partition()
+    st = perturbed_state(part, 43)
+    a = PlainSolver(part, torch.float64, mode="fused", state=st, plan_options=dict(patches=True, irregular=True))
+    b = PlainSolver(part, torch.float64, mode="fused", state=st, plan_options=dict(patches=True, irregular=False))
+    c = PlainSolver(part, torch.float64, mode="fused", state=st, plan_options=dict(patches=True, irregular=True))
+    ha, hb = a.plan.host, b.plan.host
+    assert sum(ha.n_irregular_class) > 0 and sum(hb.n_irregular_class) == 0 and ha.n_patches > hb.n_patches
+    if mesh_args["max_level"] == 4:
+        assert sum(ha.n_irregular_class) == ha.n_patches == ha.ntiles and hb.n_patches == 0
+    o = O.PlainCase(part, np.float64, state=st)
+    dt = 0.1 * 2.0 ** -mesh.finest_level
+    for _ in range(3):
+        a.iterate(dt)
+        b.iterate(dt)
+        o.iterate(dt)
+    torch.cuda.synchronize()
+    assert rel_err(a.state().cpu().numpy(), o.current()[:, :part.N]) < TOL10[torch.float64]
+    assert torch.equal(a.state(), b.state()) and torch.equal(a.speed, b.speed)
+    # one stage in pieces that cut through the regular patches, the irregular patches and the generic tiles
+    d = PlainSolver(part, torch.float64, mode="fused", state=st, plan_options=dict(patches=True, irregular=True))
+    nt, npatch, nirr = ha.ntiles, ha.n_patches, sum(ha.n_irregular_class)
+    cuts = sorted({0, (npatch - nirr) // 2, npatch - nirr + nirr // 3, npatch - 1, npatch + (nt - npatch) // 2, nt})
+    s = hip.stream_ptr()
+    c.begin_step()
+    d.begin_step()
+    c.plan.stage(c, 1, c.prev, 1, dt, s)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        d.plan.stage(d, 1, d.prev, 1, dt, s, tile_begin=lo, tile_count=hi - lo)
+    torch.cuda.synchronize()
+    assert not torch.isnan(c.planes).any() and torch.equal(c.planes, d.planes)
 
 
 def test_patch_kernel_through_the_native_stepper_and_one_patch_per_workgroup():

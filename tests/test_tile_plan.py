@@ -77,6 +77,38 @@ def interpret_patch3(plan, t, state, net, reporters):
     area = float(d[6:8].copy().view(np.float64)[0])
     halo = plan.halo_ids[h0:h0 + 256]
     ax = [np.array([[1.0, 0.0, 0.0]]), np.array([[0.0, 1.0, 0.0]]), np.array([[0.0, 0.0, 1.0]])]
+    if flags & 0x800:
+        # IRREGULAR patch: word 4 is where its per-cell words start in face_lr / face_orig; every side face in the orientation
+        # the words give (the lister is the left operand, the normal points away from it), the six added in the listed order
+        w = fbase
+        assert plan.face_off[t] == w and plan.face_off[t + 1] - w == 512
+        info, first, wfirst = plan.face_lr[w:w + 256], plan.face_orig[w:w + 256], plan.face_orig[w + 256:w + 512]
+        for i in range(8):
+            for j in range(8):
+                for k in range(4):
+                    c = _morton3(i, j, k)
+                    e = e0 + c
+                    nb = [e0 + _morton3(i - 1, j, k) if i > 0 else halo[j + 8 * k], e0 + _morton3(i + 1, j, k) if i < 7 else halo[32 + j + 8 * k],
+                          e0 + _morton3(i, j - 1, k) if j > 0 else halo[64 + i + 8 * k], e0 + _morton3(i, j + 1, k) if j < 7 else halo[96 + i + 8 * k],
+                          e0 + _morton3(i, j, k - 1) if k > 0 else halo[128 + i + 8 * j], e0 + _morton3(i, j, k + 1) if k < 3 else halo[192 + i + 8 * j]]
+                    own, wall, order = int(info[c]) & 63, (int(info[c]) >> 6) & 63, int(info[c]) >> 12
+                    assert wall & ~own == 0 and sorted((order >> (3 * q)) & 7 for q in range(6)) == list(range(6))
+                    acc = np.zeros(5)
+                    for q in range(6):
+                        sd = (order >> (3 * q)) & 7
+                        mine, is_wall, below = bool((own >> sd) & 1), bool((wall >> sd) & 1), (1 << sd) - 1
+                        s = 1.0 if mine == bool(sd & 1) else -1.0
+                        L, R = (e, nb[sd]) if mine else (nb[sd], e)
+                        if is_wall:
+                            f = area * O.xyz_face_flux(0, s * ax[sd // 2], state[:, [L]].T.copy(), state[:, [L]].T.copy(), mirror=True)[0]
+                        else:
+                            f = area * O.xyz_face_flux(0, s * ax[sd // 2], state[:, [L]].T.copy(), state[:, [R]].T.copy())[0]
+                        acc = acc - f if mine else acc + f
+                        if mine:
+                            reporters.append(int(wfirst[c]) + bin(wall & below).count("1") if is_wall
+                                             else int(first[c]) + bin(own & ~wall & below).count("1"))
+                    net[:, e] = acc
+        return
 
     def flux(a, l, r):
         return area * O.xyz_face_flux(0, ax[a], state[:, [l]].T.copy(), state[:, [r]].T.copy())[0]
@@ -143,6 +175,10 @@ def interpret(plan, part, state, reporters=None):
     return net
 
 
+def order_of(plan):
+    return plan.tile_order
+
+
 @pytest.mark.parametrize("mesh_args,ranks,patches", [(dict(dim=2, base_level=3, max_level=6, band=0.06), 1, False),
                                                      (dict(dim=2, base_level=3, max_level=5, band=0.06, periodic=False), 1, False),
                                                      (dict(dim=3, base_level=2, max_level=3, band=0.2), 1, False),
@@ -151,9 +187,13 @@ def interpret(plan, part, state, reporters=None):
                                                      (dict(dim=2, base_level=6, max_level=6, periodic=False), 1, True),
                                                      (dict(dim=2, base_level=4, max_level=7, band=0.12), 3, True),
                                                      (dict(dim=3, base_level=3, max_level=5, band=0.12), 1, True),
-                                                     (dict(dim=3, base_level=5, max_level=5, periodic=False), 2, True)])
+                                                     (dict(dim=3, base_level=5, max_level=5, periodic=False), 2, True),
+                                                     # every block next to a periodic wrap; walls, coarser neighbours and a partition cut
+                                                     (dict(dim=3, base_level=4, max_level=4), 1, True),
+                                                     (dict(dim=3, base_level=3, max_level=5, band=0.12, periodic=False), 2, True)])
 def test_plan_reproduces_the_face_loop(mesh_args, ranks, patches):
     mesh = SynthMesh(**mesh_args)
+    irregular_expected = True if (mesh_args["dim"] == 3 and patches) else (False if patches else None)
     n_patches = 0
     for rk in range(ranks):
         part = mesh.partition(rk, ranks)
@@ -180,8 +220,16 @@ def test_plan_reproduces_the_face_loop(mesh_args, ranks, patches):
         # invariants of the packed format
         assert plan.elem_off[0] == 0 and plan.elem_off[-1] == part.N and (np.diff(plan.elem_off) > 0).all()
         generic = ~plan.tile_patch
-        assert np.diff(plan.elem_off)[generic].max() <= 64 and plan.max_faces <= max(150, np.diff(plan.csr_off).max())
-        assert (np.diff(plan.elem_off)[plan.tile_patch] == 256).all() and (np.diff(plan.face_off)[plan.tile_patch] == 0).all()
+        assert not generic.any() or np.diff(plan.elem_off)[generic].max() <= 64
+        assert plan.max_faces <= max(150, np.diff(plan.csr_off).max())
+        irregular = np.zeros(plan.ntiles, bool)
+        irregular[order_of(plan)] = (plan.tile_desc[:plan.ntiles, 5] & 0x800) != 0
+        irregular &= plan.tile_patch             # (word 5 of a generic tile is its face count)
+        assert (np.diff(plan.elem_off)[plan.tile_patch] == 256).all()
+        assert (np.diff(plan.face_off)[plan.tile_patch & ~irregular] == 0).all() and (np.diff(plan.face_off)[irregular] == 512).all()
+        assert irregular.sum() == sum(plan.n_irregular_class) and (irregular.sum() > 0) == (irregular_expected is True or irregular.sum() > 0)
+        if irregular_expected is not None:
+            assert (irregular.sum() > 0) == irregular_expected
         assert np.array_equal(np.sort(rep), np.arange(part.F + part.B))      # every face has exactly one reporter
         order = plan.tile_order
         assert np.array_equal(np.sort(order), np.arange(plan.ntiles))
@@ -189,10 +237,12 @@ def test_plan_reproduces_the_face_loop(mesh_args, ranks, patches):
         assert not reads_ghost[order[:plan.n_interior]].any() and reads_ghost[order[plan.n_interior:]].all()
         if ranks == 1:
             assert plan.n_interior == plan.ntiles
-        # inside every class of tile_order the patch tiles come first
+        # inside every class of tile_order the patch tiles come first, the irregular ones last among them
         for c, (a, b) in enumerate(((0, plan.n_deep), (plan.n_deep, plan.n_interior), (plan.n_interior, plan.ntiles))):
             flags = plan.tile_patch[order[a:b]]
             assert flags[:plan.n_patch_class[c]].all() and not flags[plan.n_patch_class[c]:].any()
+            irr = irregular[order[a:b]][:plan.n_patch_class[c]]
+            assert not irr[:plan.n_patch_class[c] - plan.n_irregular_class[c]].any() and irr[plan.n_patch_class[c] - plan.n_irregular_class[c]:].all()
     assert (n_patches > 0) == patches
 
 
