@@ -33,6 +33,12 @@ def main():
         s = amr.adapt(s, 10.0, lo, hi)[0]
         torch.cuda.synchronize()
     pr.disable()
+    h = s.plan.host
+    gen = ~h.tile_patch
+    import numpy as np
+    print(f"plan: {h.n_patches} patches ({sum(h.n_irregular_class)} irregular) = {h.n_patches * 256 / s.N:.1%} of the elements; "
+          f"{int(gen.sum())} generic tiles, {np.diff(h.elem_off)[gen].mean():.0f} elements / {np.diff(h.face_off)[gen].mean():.0f} faces / "
+          f"{np.diff(h.halo_off)[gen].mean():.0f} halo entries each; levels {np.bincount(s.part.levels[:s.N])}")
     print("N =", s.N, "split (s):", {k: round(v, 4) for k, v in s.last_adapt_split.items()})
     pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
 

@@ -15,3 +15,6 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
 timeout -k 10 240 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d "$OUT/mix" -- python3 "$ROOT/bench.py" "$@" --no-cpu-baseline > "$OUT/mix.log" 2>&1 || echo "instruction-mix pass failed (see mix.log)"
 python3 "$ROOT/scripts/summarize_profile.py" "$OUT" > "$OUT/summary.md" 2>&1
 cat "$OUT/summary.md"
+# the raw traces are tens of MB per pass (gpurun copies at most 64 MiB back): keep the summary, traffic.json, the stats tables
+find "$OUT" -type f \( -name "*_kernel_trace.csv" -o -name "*_counter_collection.csv" -o -name "*_marker_api_trace.csv" -o -name "*.db" \) -delete
+du -sh "$OUT" | cut -f1

@@ -57,16 +57,22 @@ def main(out):
         w = ws[0] / ws[1] if ws[1] else 0.0
         print(f"| {k} | {f:.0f} | {2 * f * 1024 / 1e6:.1f} | {w:.0f} | {w * 1024 / 1e6:.1f} | {(2 * f + w) * 1024 / 1e6:.1f} |")
     # machine-readable traffic per launch of the dominant kernel family (bench.py reports it as roofline.traffic)
-    # The stage kernels: every family (name up to '<') of this library's fused-stage kernels that appears in the trace. One
+    # The stage kernels: every family (name without the STAGE argument) of this library's fused-stage kernels that appears in the trace. One
     # RK stage launches one kernel of each family (e.g. k_plain_patch3 + k_plain_persistent on a 3D mesh), so the HBM
     # bytes of a STAGE -- what bench.py divides by its event-timed stage duration -- are the sum over the families of the
     # family's mean bytes per launch (mean over its three stage instances).
     stage_prefixes = ("k_plain_stage", "k_plain_patch", "k_plain_persistent", "k_plain_fused", "k_subgrid_family", "k_subgrid_fused",
                       "k_subgrid444_fused", "k_flux_faces", "k_subgrid_inner")
+    def family(k):   # the name without its STAGE template argument (the third): the three stage instances of one kernel
+        if "<" not in k:
+            return k
+        head, args = k.split("<", 1)
+        a = [x.strip() for x in args.rstrip(">").split(",")]
+        return head + "<" + ", ".join(a[:2] + a[3:]) + ">"
     fams = defaultdict(list)
     for k in sorted(set(fetch) | set(write)):
         if k.startswith(stage_prefixes):
-            fams[k.split("<")[0]].append(k)
+            fams[family(k)].append(k)
     dom = [k for ks in fams.values() for k in ks]
     if dom:
         tot = 0.0

@@ -15,12 +15,17 @@ from .solver import FLUXES, PlainSolver
 
 
 def _inherited_plan_options(solver):
-    """Tile caps of the adapted mesh's plan: those the previous plan settled on (fused.PlainPlan may build a plan twice to
-    find out which kernel a mesh class gets; an adaptive run should pay for that once, not at every adapt)."""
+    """Tile caps and patch forms of the adapted mesh's plan: those the previous plan settled on (fused.PlainPlan may build a
+    plan twice to find out which kernel a mesh class gets; an adaptive run should pay for that once, not at every adapt)."""
     plan = getattr(solver, "plan", None)
-    if plan is None or getattr(plan, "auto_fcap", None) is None:
+    if plan is None:
         return None
-    return {"fcap": plan.auto_fcap}
+    opts = {}
+    if getattr(plan, "auto_fcap", None) is not None:
+        opts["fcap"] = plan.auto_fcap
+    if getattr(plan, "auto_irregular", None) is not None:
+        opts["irregular"] = plan.auto_irregular
+    return opts or None
 
 
 def refinement_criteria(solver):

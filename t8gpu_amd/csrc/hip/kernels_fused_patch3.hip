@@ -38,6 +38,39 @@ T8_DEV int patch3_morton(int i, int j, int k) {   // x bits 0, 3, 6; y bits 1, 4
   return t;
 }
 T8_DEV int patch3_ctz(int v) { return v == 0 ? 8 : __builtin_ctz(static_cast<unsigned>(v)); }
+T8_DEV void patch3_ijk(int c, int& ci, int& cj, int& ck) {
+  ci = cj = ck = 0;
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    ci |= ((c >> (3 * b)) & 1) << b;
+    cj |= ((c >> (3 * b + 1)) & 1) << b;
+  }
+#pragma unroll
+  for (int b = 0; b < 2; b++) ck |= ((c >> (3 * b + 2)) & 1) << b;
+}
+// records of the right operands of cell c's + faces (inside the patch, or the slot of the cell across the side)
+T8_DEV void patch3_plus_slots(int c, int& rx, int& ry, int& rz) {
+  int ci, cj, ck;
+  patch3_ijk(c, ci, cj, ck);
+  rx = ci < 7 ? patch3_morton(ci + 1, cj, ck) : 256 + 32 + cj + 8 * ck;
+  ry = cj < 7 ? patch3_morton(ci, cj + 1, ck) : 256 + 96 + ci + 8 * ck;
+  rz = ck < 3 ? patch3_morton(ci, cj, ck + 1) : 256 + 192 + ci + 8 * cj;
+}
+// flux slots of cell c's - faces (the + faces of the cells before it, or the slots of the - sides)
+T8_DEV void patch3_minus_slots(int c, int& a_mx, int& a_my, int& a_mz) {
+  int ci, cj, ck;
+  patch3_ijk(c, ci, cj, ck);
+  a_mx = ci > 0 ? patch3_morton(ci - 1, cj, ck) : 768 + cj + 8 * ck;
+  a_my = cj > 0 ? 256 + patch3_morton(ci, cj - 1, ck) : 768 + 32 + ci + 8 * ck;
+  a_mz = ck > 0 ? 512 + patch3_morton(ci, cj, ck - 1) : 768 + 64 + ci + 8 * cj;
+}
+// An opaque copy of a lane constant: what the IRREGULAR instantiation derives from it inside the loop is computed there
+// (some 100 integer instructions per patch), not held in registers across the whole loop -- it has none to spare, and a
+// spill reload waits for the in-flight prefetch.
+T8_DEV int patch3_fresh(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 
 // (second launch bound = wavefronts per SIMD the register allocation must allow: two 8-wave workgroups per CU in fp64 --
 //  77 KB of LDS each --, three in fp32)
@@ -72,21 +105,11 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
   // ---- lane constants: c = the cell the lane works for (cell lanes: their own; side lanes: the cell whose +z face they take)
   const bool side = tid >= 256;
   const int  c    = tid & 255, hl = tid - 256;
-  int        ci = 0, cj = 0, ck = 0;
-#pragma unroll
-  for (int b = 0; b < 3; b++) {
-    ci |= ((c >> (3 * b)) & 1) << b;
-    cj |= ((c >> (3 * b + 1)) & 1) << b;
-  }
-#pragma unroll
-  for (int b = 0; b < 2; b++) ck |= ((c >> (3 * b + 2)) & 1) << b;
+  int        ci, cj, ck, rx, ry, rz, a_mx, a_my, a_mz;
+  patch3_ijk(c, ci, cj, ck);
   // records of the right operands of the cell's + faces; flux slots of its - faces (the + faces of the cells across)
-  const int rx   = ci < 7 ? patch3_morton(ci + 1, cj, ck) : 256 + 32 + cj + 8 * ck;
-  const int ry   = cj < 7 ? patch3_morton(ci, cj + 1, ck) : 256 + 96 + ci + 8 * ck;
-  const int rz   = ck < 3 ? patch3_morton(ci, cj, ck + 1) : 256 + 192 + ci + 8 * cj;
-  const int a_mx = ci > 0 ? patch3_morton(ci - 1, cj, ck) : 768 + cj + 8 * ck;
-  const int a_my = cj > 0 ? 256 + patch3_morton(ci, cj - 1, ck) : 768 + 32 + ci + 8 * ck;
-  const int a_mz = ck > 0 ? 512 + patch3_morton(ci, cj, ck - 1) : 768 + 64 + ci + 8 * cj;
+  patch3_plus_slots(c, rx, ry, rz);
+  patch3_minus_slots(c, a_mx, a_my, a_mz);
   // pairwise order of the - faces (true: the second-named axis' face has the smaller id); where both coordinates of the pair
   // are 0 the patch's flags decide (bits 0 / 1 / 2)
   const bool r_yx = patch3_ctz(cj) >= patch3_ctz(ci), r_zx = patch3_ctz(ck) >= patch3_ctz(ci), r_zy = patch3_ctz(ck) >= patch3_ctz(cj);
@@ -129,29 +152,29 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
   int       hs_b = side ? P.halo_ids[d1.h0 + hl] : 0;
   T         cur[5];
   fetch(d0, side ? P.halo_ids[d0.h0 + hl] : 0, cur);
+  // IRREGULAR patches: the per-cell words travel like the states -- requested one patch ahead (lane tid: face_lr[w + c] and
+  // face_orig[w + tid], i.e. the first own interior id of cell tid or, on the side lanes, the first wall id of cell tid - 256),
+  // parked in the PADDING of the lane's LDS record in phase 1 and read from there by whoever needs another cell's words. (A
+  // load consumed in the iteration that issues it waits for the whole prefetch: vmcnt retires in order.)
+  auto info_words = [&](const Desc& d, unsigned& lr, int& id) {
+    const unsigned w = static_cast<unsigned>(d.fbase);   // (descriptor word 4 of an irregular patch: where its words start)
+    lr = P.face_lr[w + c];
+    id = P.face_orig[w + tid];
+  };
+  unsigned lr_cur = 0, lr_nxt = 0;
+  int      id_cur = -1, id_nxt = -1;
+  if (IRR) info_words(d0, lr_cur, id_cur);
   __builtin_amdgcn_s_waitcnt(0);   // (the prologue's loads must not become a wait inside the loop)
 
   for (; t < tend; t += stride) {
     const Desc d2   = load_desc(t + 2 * stride);
     const int  hs_c = side ? P.halo_ids[d2.h0 + hl] : 0;
-    // irregular patch (0x800): the per-cell words of the lane's cell -- and, on the - side lanes, of the boundary cell whose -
-    // face they take. Requested BEFORE the next tile's states: vmcnt retires in order, their wait must not include those.
     constexpr bool irr = IRR;
-    unsigned   ia = 0, ib = 0;
-    int        id_a = -1, idw_a = -1, id_b = -1, idw_b = -1;
-    if (irr) {
-      const unsigned q0 = static_cast<unsigned>(d0.fbase);   // (descriptor word 4 of an irregular patch: where its words start)
-      ia    = P.face_lr[q0 + c];
-      id_a  = P.face_orig[q0 + c];
-      idw_a = P.face_orig[q0 + 256 + c];
-      if (minus) {
-        ib    = P.face_lr[q0 + m_r];
-        id_b  = P.face_orig[q0 + m_r];
-        idw_b = P.face_orig[q0 + 256 + m_r];
-      }
-    }
     T          nxt[5];
-    if (t + stride < tend) fetch(d1, hs_b, nxt);
+    if (t + stride < tend) {
+      fetch(d1, hs_b, nxt);
+      if (irr) info_words(d1, lr_nxt, id_nxt);
+    }
     const int e = d0.e0 + c;
     T         pv[5] = {T(0), T(0), T(0), T(0), T(0)}, volume = T(1);
     if (!side) {
@@ -172,31 +195,53 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
       for (int k = 0; k < 5; k++) mine[k] = cur[k];
     }
     rec_store<T, NW>(pe + tid * REC, mine);
+    if (irr) {   // (the record's padding: word NW of REC -- 8 bytes in fp64, 12 in fp32 -- never touched by rec_store / rec_load)
+      int* const spare = reinterpret_cast<int*>(pe + tid * REC + NW);
+      spare[0] = static_cast<int>(lr_cur);
+      spare[1] = id_cur;
+    }
     __syncthreads();
 
     // ---- phase 2 -----------------------------------------------------------------------------------------------------------
     if (irr) {   // every side face in its listed orientation (patch_common.hpp: patch_face3g); interior faces come out the same
       T g[5], sp;
-      if (!side) {
-#pragma unroll 1
-        for (int a = 0; a < 2; a++) {   // the +x and the +y face of the lane's cell
-          const int  sd  = 2 * a + 1;
-          const bool own = (ia >> sd) & 1u;
-          patch_face3g<T, KIND, NW>(a, true, own, (ia >> (6 + sd)) & 1u, pe + c * REC, pe + (a == 0 ? rx : ry) * REC, area, g, sp);
+      auto spare_of = [&](int slot, int j) { return reinterpret_cast<const int*>(pe + slot * REC + NW)[j]; };
+      // words of cell c (the lane's own cell, or the one whose +z face a side lane takes): sides | walls | order, first ids
+      const unsigned ia    = side ? static_cast<unsigned>(spare_of(c, 0)) : lr_cur;
+      const int      id_a  = side ? spare_of(c, 1) : id_cur;
+      const int      idw_a = side ? id_cur : spare_of(256 + c, 1);
+      int            qx, qy, qz;
+      patch3_plus_slots(patch3_fresh(c), qx, qy, qz);
+      if (!side) {   // the +x and the +y face of the lane's cell (compile-time axes: a run-time axis costs ~50 selects per face)
+        {
+          const bool own = (ia >> 1) & 1u;
+          patch_face3g<T, KIND, NW>(0, true, own, (ia >> 7) & 1u, pe + c * REC, pe + qx * REC, area, g, sp);
 #pragma unroll
-          for (int k = 0; k < 5; k++) ff[k * kP3FF + 256 * a + c] = g[k];
-          if (speed && own) speed[patch3_own_id(ia, id_a, idw_a, sd)] = sp;
+          for (int k = 0; k < 5; k++) ff[k * kP3FF + c] = g[k];
+          if (speed && own) speed[patch3_own_id(ia, id_a, idw_a, 1)] = sp;
+        }
+        {
+          const bool own = (ia >> 3) & 1u;
+          patch_face3g<T, KIND, NW>(1, true, own, (ia >> 9) & 1u, pe + c * REC, pe + qy * REC, area, g, sp);
+#pragma unroll
+          for (int k = 0; k < 5; k++) ff[k * kP3FF + 256 + c] = g[k];
+          if (speed && own) speed[patch3_own_id(ia, id_a, idw_a, 3)] = sp;
         }
       } else {
         const bool own = (ia >> 5) & 1u;
-        patch_face3g<T, KIND, NW>(2, true, own, (ia >> 11) & 1u, pe + c * REC, pe + rz * REC, area, g, sp);
+        patch_face3g<T, KIND, NW>(2, true, own, (ia >> 11) & 1u, pe + c * REC, pe + qz * REC, area, g, sp);
 #pragma unroll
         for (int k = 0; k < 5; k++) ff[k * kP3FF + 512 + c] = g[k];
         if (speed && own) speed[patch3_own_id(ia, id_a, idw_a, 5)] = sp;
         if (minus) {
-          const int  ax   = m < 32 ? 0 : (m < 64 ? 1 : 2);
-          const bool mown = (ib >> (2 * ax)) & 1u;
-          patch_face3g<T, KIND, NW>(ax, false, mown, (ib >> (6 + 2 * ax)) & 1u, pe + m_r * REC, pe + m_l * REC, area, g, sp);
+          const unsigned ib    = static_cast<unsigned>(spare_of(m_r, 0));   // the boundary cell whose - face this lane takes
+          const int      id_b  = spare_of(m_r, 1), idw_b = spare_of(256 + m_r, 1);
+          const int      ax    = m < 32 ? 0 : (m < 64 ? 1 : 2);
+          const bool     mown  = (ib >> (2 * ax)) & 1u;
+          if (m < 64)   // wavefront 6: x / y per lane; wavefront 7: z
+            patch_face3g<T, KIND, NW>(ax, false, mown, (ib >> (6 + 2 * ax)) & 1u, pe + m_r * REC, pe + m_l * REC, area, g, sp);
+          else
+            patch_face3g<T, KIND, NW>(2, false, mown, (ib >> 10) & 1u, pe + m_r * REC, pe + m_l * REC, area, g, sp);
 #pragma unroll
           for (int k = 0; k < 5; k++) ff[k * kP3FF + 768 + m] = g[k];
           if (speed && mown) speed[patch3_own_id(ib, id_b, idw_b, 2 * ax)] = sp;
@@ -243,12 +288,18 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
 
     // ---- phase 3: six fluxes in ascending face id, RK stage ------------------------------------------------------------------
     if (!side && irr) {   // the six sides in the listed order (ascending face id), - for the faces the cell lists itself
-      const unsigned ord = ia >> 12;
+      const unsigned ia = lr_cur, ord = ia >> 12;
+      int            b_mx, b_my, b_mz;
+      patch3_minus_slots(patch3_fresh(c), b_mx, b_my, b_mz);
+      // (the six flux slots packed 10 bits each: one 64-bit shift per side instead of a chain of five selects)
+      const unsigned long long slots = static_cast<unsigned long long>(b_mx) | static_cast<unsigned long long>(c) << 10 |
+                                       static_cast<unsigned long long>(b_my) << 20 | static_cast<unsigned long long>(256 + c) << 30 |
+                                       static_cast<unsigned long long>(b_mz) << 40 | static_cast<unsigned long long>(512 + c) << 50;
       T              acc[5] = {T(0), T(0), T(0), T(0), T(0)};
 #pragma unroll
       for (int q = 0; q < 6; q++) {
         const int sd  = (ord >> (3 * q)) & 7u;
-        const int pos = sd == 0 ? a_mx : (sd == 1 ? c : (sd == 2 ? a_my : (sd == 3 ? 256 + c : (sd == 4 ? a_mz : 512 + c))));
+        const int pos = static_cast<int>((slots >> (10 * sd)) & 1023u);
         const T   sg  = (ia >> sd) & 1u ? T(-1) : T(1);
 #pragma unroll
         for (int k = 0; k < 5; k++) acc[k] = __builtin_fma(sg, ff[k * kP3FF + pos], acc[k]);
@@ -283,6 +334,10 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
     d0   = d1;
     d1   = d2;
     hs_b = hs_c;
+    if (irr) {
+      lr_cur = lr_nxt;
+      id_cur = id_nxt;
+    }
   }
 }
 

@@ -227,12 +227,14 @@ void find_patches3(TilePlan& P, const int32_t* fn, const double* normals, const 
   // The irregular form (see the top of the file): tried where the regular checks fail. Sides are numbered like t8code
   // faces (0 -x, 1 +x, 2 -y, 3 +y, 4 -z, 5 +z), which is also the order in which an element lists its own faces.
   auto irregular = [&](int32_t e0, Patch& pt) -> bool {
-    pt       = Patch();
-    pt.dim   = 3;
-    pt.nh    = kPatchHalo3;
-    pt.e0    = e0;
-    pt.flags = 0x800;
-    pt.info.assign(3 * kPatchElems, -1);
+    pt.dim    = 3;
+    pt.nh     = kPatchHalo3;
+    pt.e0     = e0;
+    pt.fbase  = 0;
+    pt.flags  = 0x800;
+    pt.volume = 0;
+    pt.info.clear();
+    int32_t info[3 * kPatchElems];   // (nearly every candidate fails at its first cell: nothing is allocated before it passes)
     const int ext[3] = {8, 8, 4};
     for (int t = 0; t < kPatchElems; t++) {
       const int32_t e = e0 + t;
@@ -298,10 +300,11 @@ void find_patches3(TilePlan& P, const int32_t* fn, const double* normals, const 
           if (id_of[sd] != wall_first + __builtin_popcount(wall & ((1u << sd) - 1u))) return false;
         }
       }
-      pt.info[3 * t]     = static_cast<int32_t>(own | (wall << 6) | (order << 12));
-      pt.info[3 * t + 1] = first_id;
-      pt.info[3 * t + 2] = wall_first;
+      info[3 * t]     = static_cast<int32_t>(own | (wall << 6) | (order << 12));
+      info[3 * t + 1] = first_id;
+      info[3 * t + 2] = wall_first;
     }
+    pt.info.assign(info, info + 3 * kPatchElems);
     return true;
   };
   // Every element is tested as a patch START on its own, in parallel: two patches cannot overlap (the checks pin a start
@@ -317,7 +320,7 @@ void find_patches3(TilePlan& P, const int32_t* fn, const double* normals, const 
       Patch pt;
       pt.dim = 3;
       pt.nh  = kPatchHalo3;
-      bool ok = true;
+      bool ok = !(P.want_patches & 16);   // (bit 4: every patch in the irregular form -- one kernel, one launch)
       for (int t = 0; t < kPatchElems && ok; t++) {
         const int32_t e = e0 + t;
         ok = deg[e + 1] - deg[e] == 6;
@@ -866,7 +869,7 @@ void* t8gpu_plan_plain_create_ex(int32_t N, int32_t G, int32_t F, int32_t B, int
   if (N < 0 || F < 0 || B < 0 || ndim < 2 || ndim > 3 || tmax < 1 || tmax > 1024 || fcap < 1) return nullptr;
   TilePlan* P = new TilePlan;
   P->N = N; P->G = G; P->F = F; P->B = B; P->ndim = ndim; P->tmax = tmax; P->fcap = fcap;
-  P->want_patches  = flags & 11;   // bit 0: 2D patches (16 x 16), bit 1: 3D patches (8 x 8 x 4), bit 3: irregular 3D patches too
+  P->want_patches  = flags & 27;   // bit 0: 2D patches (16 x 16), bit 1: 3D patches (8 x 8 x 4), bit 3: irregular 3D patches too, bit 4: no regular 3D ones
   P->skip_face_geo = (flags & 4) != 0;   // bit 2: no face_geo rows if the plan has a geometry dictionary
   build(*P, fn, normals, areas);
   if (P->max_elems + P->max_halo >= 0xFFFF || P->max_faces > 0x7FFE) {

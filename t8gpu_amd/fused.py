@@ -29,7 +29,9 @@ class PlainPlan:
             patches = compressed and os.environ.get("T8GPU_PATCH", "1") != "0"
         self.patches = patches if compressed else False          # True / False, or 2 / 3 for one kind only
         # 3D: blocks next to periodic wraps / walls / coarser - side neighbours become (irregular) patches too
-        self.irregular = os.environ.get("T8GPU_PATCH_IRREGULAR", "1") != "0" if irregular is None else bool(irregular)
+        if irregular is None:
+            irregular = {"0": False, "all": "all"}.get(os.environ.get("T8GPU_PATCH_IRREGULAR", "1"), True)
+        self.irregular = irregular
         # the patch kernels address a plane by a 32-bit byte offset: meshes whose planes reach 4 GiB keep the tile kernels
         if (part.N + part.G) * (4 if dtype == torch.float32 else 8) >= 2 ** 32:
             self.patches = False
@@ -81,6 +83,12 @@ class PlainPlan:
         self._keep = {}
         c = T8gpuPlainPlan()
         h = self.host
+        # What an ADAPTED mesh's plan inherits (amr._inherited_plan_options): where nearly every patch is an irregular one -- thin
+        # refined sheets: c5a has 5 944 irregular and 8 regular patches -- the irregular form buys nothing (it runs at the speed of
+        # the persistent tile kernel on such cells) and costs planning time in every cycle; keep it where regular patches carry
+        # a good part of the mesh (uniform boxes with wraps or walls: c5u +26 %).
+        n_irr = sum(h.n_irregular_class)
+        self.auto_irregular = self.irregular if n_irr <= 4 * (h.n_patches - n_irr) else False
         # the pipelined kernel with a geometry dictionary never reads the per-face rows (32 B per face: 700 MB at c4)
         skip_geo = (compressed and dictionary and h.geo_table.shape[0] > 0 and h.max_elems <= 256 and h.max_slots <= 512
                     and h.max_faces <= 1024)

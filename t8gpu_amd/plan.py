@@ -53,6 +53,8 @@ class HostPlainPlan:
         pflags = {False: 0, True: 3, 2: 1, 3: 2}[patches] | (0 if want_face_geo else 4)
         if irregular and (pflags & 2):
             pflags |= 8       # 3D blocks next to a periodic wrap / wall / coarser - side neighbour become (irregular) patches too
+            if irregular == "all":
+                pflags |= 16  # ... and the regular blocks take the irregular form as well (one kernel, one launch per stage)
         h = lib.t8gpu_plan_plain_create_ex(N, G, F, B, ndim, p(fn), p(nr), p(ar), tmax, fcap, pflags)
         if not h:
             raise ValueError("tile plan exceeds the packed index format (use smaller tmax / fcap)")
