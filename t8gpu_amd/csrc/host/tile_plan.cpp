@@ -380,6 +380,34 @@ void find_patches3(TilePlan& P, const int32_t* fn, const double* normals, const 
       if (P.patches.empty() || q.e0 >= P.patches.back().e0 + kPatchElems) P.patches.push_back(q);
 }
 
+// Small open-addressing hash set / map of int32 keys, emptied in O(1) by moving to the next generation: the faces / halo
+// elements of the tile under construction (greedy tiling) and the face -> position, element -> slot maps of a tile's lists.
+struct StampSet {
+  std::vector<int32_t> key, gen, val;
+  int32_t              cur = 0;
+  uint32_t             mask;
+  int                  shift;
+  explicit StampSet(int log2cap)
+      : key(size_t(1) << log2cap), gen(size_t(1) << log2cap, -1), val(size_t(1) << log2cap), mask((1u << log2cap) - 1u), shift(32 - log2cap) {}
+  void clear() { cur++; }
+  uint32_t slot(int32_t k) const {   // where k is, or the free slot where it would go
+    uint32_t h = (static_cast<uint32_t>(k) * 2654435761u) >> shift;
+    while (gen[h] == cur && key[h] != k) h = (h + 1) & mask;
+    return h;
+  }
+  bool contains(int32_t k) const { return gen[slot(k)] == cur; }
+  bool insert(int32_t k, int32_t v = 0) {   // true: was not there
+    const uint32_t h = slot(k);
+    if (gen[h] == cur) return false;
+    gen[h] = cur;
+    key[h] = k;
+    val[h] = v;
+    return true;
+  }
+  void    set(int32_t k, int32_t v) { val[slot(k)] = v; }   // (k must be there)
+  int32_t at(int32_t k) const { return val[slot(k)]; }       // (k must be there)
+};
+
 void build(TilePlan& P, const int32_t* fn, const double* normals, const double* areas) {
   const int32_t N = P.N, F = P.F, B = P.B;
   PhaseTimer timer("tile_plan");
@@ -419,6 +447,13 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
   std::vector<int32_t> patch_at(static_cast<size_t>(N) + 1, -1);   // patch that starts at an element
   for (size_t k = 0; k < P.patches.size(); k++) patch_at[P.patches[k].e0] = static_cast<int32_t>(k);
   lap("patches");
+  int32_t most = 0;   // faces of one element
+#pragma omp parallel for num_threads(host_threads()) schedule(static) reduction(max : most)
+  for (int32_t e = 0; e < N; e++) most = std::max(most, deg[e + 1] - deg[e]);
+  // capacity of the per-thread hash tables: >= 4 x the entries a tile can hold (a tile ends at fcap faces / lecap slots, plus one
+  // element's worth; a tile of tmax elements has at most tmax * most faces and twice as many halo elements)
+  int log2cap = 12;
+  while (log2cap < 30 && (int64_t(1) << log2cap) < 4 * (int64_t(std::max(P.fcap, P.lecap)) + 2 * int64_t(most) + 64)) log2cap++;
   // greedy tiling: grow the element range while elements <= tmax, distinct faces <= fcap and own + halo
   // elements <= lecap (the kernel's LDS window). The halo count is tracked incrementally: an element that
   // joins the tile stops being halo, its neighbours outside the range become halo.
@@ -437,32 +472,6 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
       while (e < N && patch_at[e] < 0 && e - start < kRunCut) e++;
       runs.push_back({start, e});
     }
-    struct StampSet {   // open addressing, emptied in O(1) by moving to the next generation
-      std::vector<int32_t> key, gen;
-      int32_t              cur = 0;
-      uint32_t             mask;
-      int                  shift;
-      explicit StampSet(int log2cap) : key(size_t(1) << log2cap), gen(size_t(1) << log2cap, -1), mask((1u << log2cap) - 1u), shift(32 - log2cap) {}
-      void clear() { cur++; }
-      bool contains(int32_t k) const {
-        for (uint32_t h = (static_cast<uint32_t>(k) * 2654435761u) >> shift; gen[h] == cur; h = (h + 1) & mask)
-          if (key[h] == k) return true;
-        return false;
-      }
-      bool insert(int32_t k) {   // true: was not there
-        uint32_t h = (static_cast<uint32_t>(k) * 2654435761u) >> shift;
-        for (; gen[h] == cur; h = (h + 1) & mask)
-          if (key[h] == k) return false;
-        gen[h] = cur;
-        key[h] = k;
-        return true;
-      }
-    };
-    int32_t most = 0;   // faces of one element
-#pragma omp parallel for num_threads(host_threads()) schedule(static) reduction(max : most)
-    for (int32_t e = 0; e < N; e++) most = std::max(most, deg[e + 1] - deg[e]);
-    int log2cap = 12;   // >= 4 x the entries a tile can hold (a tile ends at fcap faces / lecap slots, plus one element's worth)
-    while (log2cap < 30 && (int64_t(1) << log2cap) < 4 * (int64_t(std::max(P.fcap, P.lecap)) + 2 * int64_t(most) + 64)) log2cap++;
     std::vector<std::vector<int32_t>> ends(runs.size());
 #pragma omp parallel num_threads(host_threads())
     {
@@ -561,33 +570,37 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
   std::vector<uint8_t> reads_ghost(ntiles, 0);
   P.tile_patch.assign(ntiles, -1);
   for (int32_t t = 0; t < ntiles; t++) P.tile_patch[t] = patch_at[P.elem_off[t]];
-  auto tile_lists = [&](int32_t t, std::vector<int32_t>& tf, std::vector<int32_t>& halo) {
+  auto tile_lists = [&](int32_t t, std::vector<int32_t>& tf, std::vector<int32_t>& halo, StampSet& set) {
     const int32_t e0 = P.elem_off[t], e1 = P.elem_off[t + 1];
     if (P.tile_patch[t] >= 0) {   // no face records; the 64 elements across the sides in the patch kernel's fixed order
       tf.clear();
       halo.assign(P.patches[P.tile_patch[t]].halo, P.patches[P.tile_patch[t]].halo + P.patches[P.tile_patch[t]].nh);
       return;
     }
-    tf.assign(ef.begin() + deg[e0], ef.begin() + deg[e1]);
+    // distinct faces / outside elements through a hash set, then sorted (half the entries of the raw lists are duplicates)
+    tf.clear();
+    set.clear();
+    for (int32_t j = deg[e0]; j < deg[e1]; j++)
+      if (set.insert(ef[j])) tf.push_back(ef[j]);
     std::sort(tf.begin(), tf.end());
-    tf.erase(std::unique(tf.begin(), tf.end()), tf.end());
     halo.clear();
+    set.clear();
     for (int32_t f : tf)
       for (int w = 0; w < 2; w++) {
         const int32_t s = side(f, w);
-        if (s >= 0 && (s < e0 || s >= e1)) halo.push_back(s);
+        if (s >= 0 && (s < e0 || s >= e1) && set.insert(s)) halo.push_back(s);
       }
     std::sort(halo.begin(), halo.end());
-    halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
   };
   // (the lists of pass 1 are kept for pass 2: sorting them twice was 40 % of this phase)
   std::vector<std::vector<int32_t>> tfs(ntiles), halos(ntiles);
 #pragma omp parallel num_threads(host_threads())
   {
+    StampSet set(log2cap);
 #pragma omp for schedule(dynamic, 64)
     for (int32_t t = 0; t < ntiles; t++) {
       std::vector<int32_t>&tf = tfs[t], &halo = halos[t];
-      tile_lists(t, tf, halo);
+      tile_lists(t, tf, halo, set);
       // (an irregular patch keeps its per-cell words where a generic tile keeps face records: 512 entries of face_lr / face_orig)
       const bool irregular = P.tile_patch[t] >= 0 && !P.patches[P.tile_patch[t]].info.empty();
       P.face_off[t + 1] = irregular ? kPatchInfoWords : static_cast<int32_t>(tf.size());
@@ -719,8 +732,9 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
   P.csr_ent.resize(deg[N]);
 #pragma omp parallel num_threads(host_threads())
   {
-    std::vector<int32_t> order, where;
+    std::vector<int32_t> order;
     std::vector<uint8_t> codes;
+    StampSet             face_at(log2cap), slot_at(log2cap);   // face id -> position in the tile's face list, outside element -> halo index
 #pragma omp for schedule(dynamic, 64)
     for (int32_t t = 0; t < ntiles; t++) {
       const int32_t e0 = P.elem_off[t], e1 = P.elem_off[t + 1], ne = e1 - e0;
@@ -745,9 +759,11 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
         }
         continue;
       }
+      slot_at.clear();
+      for (size_t j = 0; j < halo.size(); j++) slot_at.insert(halo[j], static_cast<int32_t>(j));
       auto loc = [&](int32_t s) -> uint32_t {
         if (s >= e0 && s < e1) return static_cast<uint32_t>(s - e0);
-        return static_cast<uint32_t>(ne + (std::lower_bound(halo.begin(), halo.end(), s) - halo.begin()));
+        return static_cast<uint32_t>(ne + slot_at.at(s));
       };
       // Layout of the tile's faces: ascending original id, then inside every block of 256 (one pass of the two-pass
       // kernels = the faces one lane index sees) a stable sort by direction code, so that a wavefront's 64 faces
@@ -755,16 +771,23 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
       // they point at move, and never across a block), so every kernel sums in the same order as before.
       const size_t nft = tf.size();
       order.resize(nft);
-      where.resize(nft);
       codes.resize(nft);
       for (size_t j = 0; j < nft; j++) {
         order[j] = static_cast<int32_t>(j);
         codes[j] = static_cast<uint8_t>(direction_code(normals + static_cast<size_t>(P.ndim) * tf[j], P.ndim));
       }
-      for (size_t b = 0; b < nft; b += 256)
-        std::stable_sort(order.begin() + b, order.begin() + std::min(nft, b + 256),
-                         [&](int32_t x, int32_t y) { return codes[x] < codes[y]; });
-      for (size_t j = 0; j < nft; j++) where[order[j]] = static_cast<int32_t>(j);
+      for (size_t b = 0; b < nft; b += 256) {   // stable counting sort by code (0..6) inside the block
+        const size_t hi = std::min(nft, b + 256);
+        size_t       at[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t j = b; j < hi; j++) at[codes[j] + 1]++;
+        for (int k = 1; k < 8; k++) at[k] += at[k - 1];
+        for (size_t j = b; j < hi; j++) order[b + at[codes[j]]++] = static_cast<int32_t>(j);
+      }
+      face_at.clear();
+      for (size_t j = 0; j < nft; j++) {
+
+        face_at.insert(tf[order[j]], static_cast<int32_t>(j));
+      }
       size_t q = P.face_off[t];
       for (size_t jj = 0; jj < nft; jj++) {
         const int32_t f = tf[order[jj]];
@@ -785,7 +808,7 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
       for (int32_t e = e0; e < e1; e++)
         for (int32_t j = deg[e]; j < deg[e + 1]; j++) {
           const int32_t  f   = ef[j];
-          const uint16_t idx = static_cast<uint16_t>(where[std::lower_bound(tf.begin(), tf.end(), f) - tf.begin()]);
+          const uint16_t idx = static_cast<uint16_t>(face_at.at(f));
           const bool     right = side(f, 0) != e;
           P.csr_ent[j] = static_cast<uint16_t>(idx | (right ? 0x8000u : 0u));
         }
