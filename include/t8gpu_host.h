@@ -32,6 +32,9 @@ void t8gpu_synth_part_counts(const void* part, int64_t* counts);
 /* face_neighbors[2F+B], normals[normal_dim*(F+B)], areas[F+B], level_diff[F], nb_offset[dim*F] (subgrid) */
 void t8gpu_synth_part_connectivity(const void* part, int32_t* face_neighbors, double* normals, double* areas,
                                    int32_t* level_diff, int32_t* nb_offset);
+/* the same arrays in place (no copy): ptrs[5] = {face_neighbors, normals, areas, face_level_difference, face_neighbor_offset},
+ * null where empty; valid until t8gpu_synth_part_release_arrays / _destroy */
+void t8gpu_synth_part_connectivity_ptrs(const void* part, const void** ptrs);
 /* per owned + ghost element: level[N+G], volume[N+G], centre[(N+G)*3] */
 void t8gpu_synth_part_elements(const void* part, int32_t* level, double* volume, double* centre);
 void t8gpu_synth_part_halo(const void* part, int64_t* ghost_global, int32_t* ghost_owner, int32_t* peers,
@@ -97,6 +100,9 @@ void t8gpu_plan_plain_arrays(const void* plan, int32_t* elem_off, int32_t* halo_
 /* ell[sizes[15] * ell_width] (rows for the elements of generic tiles only, see T8gpuPlainPlan), geo_idx[n_faces],
  * geo_table[n_geo*12] = {n, area, t1, 0, t2, 0} rows */
 void t8gpu_plan_plain_compressed(const void* plan, uint16_t* ell, uint16_t* geo_idx, double* geo_table);
+/* the same arrays in place (no copy): ptrs[13] = {elem_off, halo_off, face_off, halo_ids, face_lr, face_geo, face_orig, csr_off,
+ * csr_ent, tile_order, ell, geo_idx, geo_table}, null where empty; valid until t8gpu_plan_plain_destroy */
+void t8gpu_plan_plain_array_ptrs(const void* plan, const void** ptrs);
 /* tile_desc[ntiles][8] of T8gpuPlainPlan (one record per tile in tile_order order) */
 void t8gpu_plan_plain_tile_desc(const void* plan, int32_t* tile_desc);
 

@@ -422,6 +422,17 @@ void t8gpu_synth_part_connectivity(const void* h, int32_t* face_neighbors, doubl
   if (nb_offset && !p->nb_offset.empty()) std::memcpy(nb_offset, p->nb_offset.data(), p->nb_offset.size() * sizeof(int32_t));
 }
 
+// The same arrays without a copy: ptrs[5] = {face_neighbors, normals, areas, face_level_difference, face_neighbor_offset}
+// (null where empty), valid until t8gpu_synth_part_release_arrays / _destroy of this partition.
+void t8gpu_synth_part_connectivity_ptrs(const void* h, const void** ptrs) {
+  const Part* p = static_cast<const Part*>(h);
+  ptrs[0] = p->fn.empty() ? nullptr : p->fn.data();
+  ptrs[1] = p->normals.empty() ? nullptr : p->normals.data();
+  ptrs[2] = p->areas.empty() ? nullptr : p->areas.data();
+  ptrs[3] = p->level_diff.empty() ? nullptr : p->level_diff.data();
+  ptrs[4] = p->nb_offset.empty() ? nullptr : p->nb_offset.data();
+}
+
 // per owned+ghost element: level, volume, centre (N + G entries; centre is [N+G][3])
 void t8gpu_synth_part_elements(const void* h, int32_t* level, double* volume, double* centre) {
   const Part* p   = static_cast<const Part*>(h);

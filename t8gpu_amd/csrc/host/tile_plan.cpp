@@ -997,6 +997,18 @@ void t8gpu_plan_plain_tile_desc(const void* h, int32_t* tile_desc) {
   }
 }
 
+// The arrays of t8gpu_plan_plain_arrays / _compressed in place (no copy): ptrs[13] = {elem_off, halo_off, face_off, halo_ids,
+// face_lr, face_geo, face_orig, csr_off, csr_ent, tile_order, ell, geo_idx, geo_table}, null where empty; sizes as reported by
+// t8gpu_plan_plain_sizes. Valid until t8gpu_plan_plain_destroy.
+void t8gpu_plan_plain_array_ptrs(const void* h, const void** ptrs) {
+  const TilePlan* P = static_cast<const TilePlan*>(h);
+  auto at = [](const auto& v) -> const void* { return v.empty() ? nullptr : static_cast<const void*>(v.data()); };
+  ptrs[0] = at(P->elem_off); ptrs[1] = at(P->halo_off); ptrs[2] = at(P->face_off); ptrs[3] = at(P->halo_ids);
+  ptrs[4] = at(P->face_lr); ptrs[5] = at(P->face_geo); ptrs[6] = at(P->face_orig); ptrs[7] = at(P->csr_off);
+  ptrs[8] = at(P->csr_ent); ptrs[9] = at(P->tile_order); ptrs[10] = at(P->ell); ptrs[11] = at(P->geo_idx);
+  ptrs[12] = at(P->geo_table);
+}
+
 void t8gpu_plan_plain_arrays(const void* h, int32_t* elem_off, int32_t* halo_off, int32_t* face_off,
                              int32_t* halo_ids, uint32_t* face_lr, double* face_geo, int32_t* face_orig,
                              int32_t* csr_off, uint16_t* csr_ent, int32_t* tile_order) {

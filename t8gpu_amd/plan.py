@@ -25,6 +25,7 @@ def _lib():
         lib.t8gpu_plan_plain_destroy.argtypes = [C.c_void_p]
         lib.t8gpu_plan_plain_sizes.argtypes = [C.c_void_p, C.c_void_p]
         lib.t8gpu_plan_plain_arrays.argtypes = [C.c_void_p] * 11
+        lib.t8gpu_plan_plain_array_ptrs.argtypes = [C.c_void_p] * 2
         lib.t8gpu_plan_plain_compressed.argtypes = [C.c_void_p] * 4
         lib.t8gpu_plan_plain_tile_desc.argtypes = [C.c_void_p] * 2
         _ready = True
@@ -58,55 +59,54 @@ class HostPlainPlan:
         h = lib.t8gpu_plan_plain_create_ex(N, G, F, B, ndim, p(fn), p(nr), p(ar), tmax, fcap, pflags)
         if not h:
             raise ValueError("tile plan exceeds the packed index format (use smaller tmax / fcap)")
-        try:
-            sz = np.zeros(16, np.int64)
-            lib.t8gpu_plan_plain_sizes(h, p(sz))
-            (self.ntiles, n_halo, n_faces, n_csr, self.max_elems, self.max_halo, self.max_faces,
-             self.n_interior) = (int(x) for x in sz[:8])
-            self.N, self.F, self.B, self.tmax, self.fcap = N, F, B, tmax, fcap
-            # (np.empty: t8gpu_plan_plain_arrays / _compressed overwrite every entry)
-            self.elem_off = np.zeros(self.ntiles + 1, np.int32)
-            self.halo_off = np.zeros(self.ntiles + 1, np.int32)
-            self.face_off = np.zeros(self.ntiles + 1, np.int32)
-            self.halo_ids = np.empty(n_halo, np.int32)
-            self.face_lr = np.empty(n_faces, np.uint32)
-            n_geo_rows = int(sz[11])
-            self.face_geo = np.empty((0 if (n_geo_rows and not want_face_geo) else n_faces, 4), np.float64)
-            self.face_orig = np.empty(n_faces, np.int32)
-            self.csr_off = np.empty(N + 1, np.int32)
-            self.csr_ent = np.empty(n_csr, np.uint16)
-            self.tile_order = np.zeros(self.ntiles, np.int32)
-            lib.t8gpu_plan_plain_arrays(h, *(p(getattr(self, f)) if getattr(self, f).size else None for f in self.FIELDS))
-            self.ell_width, n_geo, self.max_slots, self.n_deep = int(sz[10]), int(sz[11]), int(sz[12]), int(sz[13])
-            self.n_ell_rows = int(sz[15])                  # rows exist for the elements of generic tiles only (tile_desc word 6)
-            self.ell = (np.empty if self.n_ell_rows else np.zeros)((max(1, self.n_ell_rows), self.ell_width), np.uint16)
-            self.geo_idx = np.empty(n_faces if n_geo else 0, np.uint16)
-            self.geo_table = np.zeros((n_geo, 12), np.float64)
-            lib.t8gpu_plan_plain_compressed(h, p(self.ell), p(self.geo_idx) if n_geo else None,
-                                            p(self.geo_table) if n_geo else None)
-            # volumes of the owned elements (optional): patches of uniform volume carry it in their descriptor
-            self.n_patches_uniform_volume = 0
-            if volumes is not None and patches:
-                vol = np.ascontiguousarray(np.asarray(volumes, np.float64)[:N])
-                self.n_patches_uniform_volume = int(lib.t8gpu_plan_plain_patch_volumes(h, p(vol)))
-            self.tile_desc = np.zeros((max(1, self.ntiles), 8), np.int32)
-            if self.ntiles:
-                lib.t8gpu_plan_plain_tile_desc(h, p(self.tile_desc))
-            cnt = np.zeros(4, np.int32)
-            lib.t8gpu_plan_plain_patch_counts(h, p(cnt))
-            self.n_patch_class, self.n_patches = tuple(int(x) for x in cnt[:3]), int(cnt[3])
-            lib.t8gpu_plan_plain_irregular_counts(h, p(cnt))
-            self.n_irregular_class = tuple(int(x) for x in cnt[:3])      # the last patch tiles of every class (flag 0x800)
-            self.patch_dim = int(lib.t8gpu_plan_plain_patch_dim(h))            # 2 | 3 | 0 (no patch tiles)
-            # per tile (index, not position): is it a patch tile? (tile_desc is in tile_order order)
-            # (word 5 of a GENERIC tile's descriptor is its face count: the flag bits mean something in patch descriptors only,
-            #  so the patch tiles are taken from their positions -- the first n_patch_class[c] of every class)
-            self.tile_patch = np.zeros(self.ntiles, bool)
-            n_deep, n_int = int(sz[13]), int(sz[7])
-            for c, a in enumerate((0, n_deep, n_int)):
-                self.tile_patch[self.tile_order[a:a + self.n_patch_class[c]]] = True
-        finally:
-            lib.t8gpu_plan_plain_destroy(h)
+        # The plan's arrays are VIEWS of the planner's own arrays (no copy: a few hundred MB per plan at 3 M elements); a view
+        # keeps the plan handle alive (synth._view), which is destroyed with the last of them.
+        self._owner = owner = _synth._Handle(h, lib.t8gpu_plan_plain_destroy)
+        sz = np.zeros(16, np.int64)
+        lib.t8gpu_plan_plain_sizes(h, p(sz))
+        (self.ntiles, n_halo, n_faces, n_csr, self.max_elems, self.max_halo, self.max_faces,
+         self.n_interior) = (int(x) for x in sz[:8])
+        self.N, self.F, self.B, self.tmax, self.fcap = N, F, B, tmax, fcap
+        self.ell_width, n_geo, self.max_slots, self.n_deep = int(sz[10]), int(sz[11]), int(sz[12]), int(sz[13])
+        self.n_ell_rows = int(sz[15])                  # rows exist for the elements of generic tiles only (tile_desc word 6)
+        ptrs = (C.c_void_p * 13)()
+        lib.t8gpu_plan_plain_array_ptrs(h, ptrs)
+        view = _synth._view
+        self.elem_off = view(ptrs[0], self.ntiles + 1, np.int32, owner)
+        self.halo_off = view(ptrs[1], self.ntiles + 1, np.int32, owner)
+        self.face_off = view(ptrs[2], self.ntiles + 1, np.int32, owner)
+        self.halo_ids = view(ptrs[3], n_halo, np.int32, owner)
+        self.face_lr = view(ptrs[4], n_faces, np.uint32, owner)
+        n_face_geo = 0 if (n_geo and not want_face_geo) else n_faces       # (flag 4: no rows where a dictionary exists)
+        self.face_geo = view(ptrs[5], 4 * n_face_geo, np.float64, owner).reshape(-1, 4)
+        self.face_orig = view(ptrs[6], n_faces, np.int32, owner)
+        self.csr_off = view(ptrs[7], N + 1, np.int32, owner)
+        self.csr_ent = view(ptrs[8], n_csr, np.uint16, owner)
+        self.tile_order = view(ptrs[9], self.ntiles, np.int32, owner)
+        self.ell = (view(ptrs[10], self.n_ell_rows * self.ell_width, np.uint16, owner).reshape(-1, self.ell_width) if self.n_ell_rows
+                    else np.zeros((1, self.ell_width), np.uint16))
+        self.geo_idx = view(ptrs[11], n_faces if n_geo else 0, np.uint16, owner)
+        self.geo_table = view(ptrs[12], 12 * n_geo, np.float64, owner).reshape(-1, 12)
+        # volumes of the owned elements (optional): patches of uniform volume carry it in their descriptor
+        self.n_patches_uniform_volume = 0
+        if volumes is not None and patches:
+            vol = np.ascontiguousarray(np.asarray(volumes, np.float64)[:N])
+            self.n_patches_uniform_volume = int(lib.t8gpu_plan_plain_patch_volumes(h, p(vol)))
+        self.tile_desc = np.zeros((max(1, self.ntiles), 8), np.int32)
+        if self.ntiles:
+            lib.t8gpu_plan_plain_tile_desc(h, p(self.tile_desc))
+        cnt = np.zeros(4, np.int32)
+        lib.t8gpu_plan_plain_patch_counts(h, p(cnt))
+        self.n_patch_class, self.n_patches = tuple(int(x) for x in cnt[:3]), int(cnt[3])
+        lib.t8gpu_plan_plain_irregular_counts(h, p(cnt))
+        self.n_irregular_class = tuple(int(x) for x in cnt[:3])      # the last patch tiles of every class (flag 0x800)
+        self.patch_dim = int(lib.t8gpu_plan_plain_patch_dim(h))            # 2 | 3 | 0 (no patch tiles)
+        # per tile (index, not position): is it a patch tile? (word 5 of a GENERIC tile's descriptor is its face count: the flag
+        # bits mean something in patch descriptors only, so the patch tiles are taken from their positions -- the first
+        # n_patch_class[c] of every class)
+        self.tile_patch = np.zeros(self.ntiles, bool)
+        for c, a in enumerate((0, self.n_deep, self.n_interior)):
+            self.tile_patch[self.tile_order[a:a + self.n_patch_class[c]]] = True
 
     @classmethod
     def from_partition(cls, part, **kw):

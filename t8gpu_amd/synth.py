@@ -25,6 +25,7 @@ def lib():
         _lib.t8gpu_synth_part_release_arrays.argtypes = [C.c_void_p]
         _lib.t8gpu_synth_part_counts.argtypes = [C.c_void_p, C.c_void_p]
         _lib.t8gpu_synth_part_connectivity.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        _lib.t8gpu_synth_part_connectivity_ptrs.argtypes = [C.c_void_p, C.c_void_p]
         _lib.t8gpu_synth_part_elements.argtypes = [C.c_void_p] + [C.c_void_p] * 3
         _lib.t8gpu_synth_part_halo.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         _lib.t8gpu_synth_part_kh_ic.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
@@ -37,6 +38,30 @@ def lib():
         _lib.t8gpu_synth_mesh_adapt_data.restype = C.c_int
         _lib.t8gpu_synth_mesh_adapt_data.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     return _lib
+
+
+class _Handle:
+    """Owner of a C handle that numpy views point into: destroyed when the last view (and the Python object) is gone."""
+
+    def __init__(self, h, destroy):
+        self.h, self._destroy = h, destroy
+
+    def __del__(self):
+        if self.h:
+            try:
+                self._destroy(self.h)
+            except TypeError:                                   # interpreter shutdown: the module globals are gone
+                pass
+            self.h = None
+
+
+def _view(addr, n, dtype, owner):
+    """numpy array over n items at C address `addr` (no copy); its buffer object keeps `owner` alive."""
+    if not addr or n <= 0:
+        return np.empty(0, dtype)
+    buf = (C.c_char * (int(n) * np.dtype(dtype).itemsize)).from_address(addr)
+    buf._owner = owner
+    return np.frombuffer(buf, dtype=dtype, count=int(n))
 
 
 def _p(a):
@@ -116,38 +141,36 @@ class Partition:
         h = lib().t8gpu_synth_part_create(mesh._h, rank, nranks, int(self.subgrid), normal_dim)
         if not h:
             raise ValueError("invalid partition parameters")
-        try:
-            # (np.empty below: the provider overwrites every entry of these arrays)
-            cnt = np.zeros(8, np.int64)
-            lib().t8gpu_synth_part_counts(h, _p(cnt))
-            self.N, self.G, self.F, self.B, npeer, nsend = (int(x) for x in cnt[:6])
-            self.first_global, self.num_global = int(cnt[6]), int(cnt[7])
-            self.face_neighbors = np.empty(2 * self.F + self.B, np.int32)
-            self.normals = np.empty(normal_dim * (self.F + self.B), np.float64)
-            self.areas = np.empty(self.F + self.B, np.float64)
-            self.level_diff = np.empty(self.F, np.int32) if subgrid else None
-            self.nb_offset = np.empty(dim * self.F, np.int32) if subgrid else None
-            lib().t8gpu_synth_part_connectivity(h, _p(self.face_neighbors), _p(self.normals), _p(self.areas),
-                                                _p(self.level_diff), _p(self.nb_offset))
-            tot = self.N + self.G
-            self.levels = np.empty(tot, np.int32)
-            self.volumes = np.empty(tot, np.float64)
-            self.centres = np.empty((tot, 3), np.float64)
-            lib().t8gpu_synth_part_elements(h, _p(self.levels), _p(self.volumes), _p(self.centres))
-            self.ghost_global = np.zeros(self.G, np.int64)
-            self.ghost_owner = np.zeros(self.G, np.int32)
-            self.peers = np.zeros(npeer, np.int32)
-            self.recv_off = np.zeros(npeer + 1, np.int32)
-            self.send_off = np.zeros(npeer + 1, np.int32)
-            self.send_idx = np.zeros(nsend, np.int32)
-            lib().t8gpu_synth_part_halo(h, _p(self.ghost_global), _p(self.ghost_owner), _p(self.peers),
-                                        _p(self.recv_off), _p(self.send_off), _p(self.send_idx))
-            self._ic = {}                                   # evaluated on demand (kh_initial_state): an adapt cycle never asks
-            lib().t8gpu_synth_part_release_arrays(h)
-            self._h, h = h, None
-        finally:
-            if h:
-                lib().t8gpu_synth_part_destroy(h)
+        # The partition handle belongs to `owner`, which the array views below share: it is destroyed with the last of them.
+        self._owner = owner = _Handle(h, lib().t8gpu_synth_part_destroy)
+        self._h = h
+        cnt = np.zeros(8, np.int64)
+        lib().t8gpu_synth_part_counts(h, _p(cnt))
+        self.N, self.G, self.F, self.B, npeer, nsend = (int(x) for x in cnt[:6])
+        self.first_global, self.num_global = int(cnt[6]), int(cnt[7])
+        # The connectivity arrays are VIEWS of the provider's own arrays (363 MB at 3 M elements: copying them was a third of
+        # the provider's share of an adapt cycle); a view keeps the handle alive (_view), so it may outlive this object.
+        ptrs = (C.c_void_p * 5)()
+        lib().t8gpu_synth_part_connectivity_ptrs(h, ptrs)
+        self.face_neighbors = _view(ptrs[0], 2 * self.F + self.B, np.int32, owner)
+        self.normals = _view(ptrs[1], normal_dim * (self.F + self.B), np.float64, owner)
+        self.areas = _view(ptrs[2], self.F + self.B, np.float64, owner)
+        self.level_diff = _view(ptrs[3], self.F, np.int32, owner) if subgrid else None
+        self.nb_offset = _view(ptrs[4], dim * self.F, np.int32, owner) if subgrid else None
+        tot = self.N + self.G
+        self.levels = np.empty(tot, np.int32)                # (np.empty: the provider overwrites every entry)
+        self.volumes = np.empty(tot, np.float64)
+        self.centres = np.empty((tot, 3), np.float64)
+        lib().t8gpu_synth_part_elements(h, _p(self.levels), _p(self.volumes), _p(self.centres))
+        self.ghost_global = np.zeros(self.G, np.int64)
+        self.ghost_owner = np.zeros(self.G, np.int32)
+        self.peers = np.zeros(npeer, np.int32)
+        self.recv_off = np.zeros(npeer + 1, np.int32)
+        self.send_off = np.zeros(npeer + 1, np.int32)
+        self.send_idx = np.zeros(nsend, np.int32)
+        lib().t8gpu_synth_part_halo(h, _p(self.ghost_global), _p(self.ghost_owner), _p(self.peers),
+                                    _p(self.recv_off), _p(self.send_off), _p(self.send_idx))
+        self._ic = {}                                       # evaluated on demand (kh_initial_state): an adapt cycle never asks
         # ranks[]/indices[] of the reference accessors (mesh_manager.h:141-157): ghosts resolve to local slots.
         self.ranks = np.full(tot, rank, np.int32)
         self.indices = np.arange(tot, dtype=np.int32)
@@ -166,10 +189,4 @@ class Partition:
             self._ic[cpd] = out
         return self._ic[cpd]
 
-    def __del__(self):
-        if getattr(self, "_h", None):
-            try:
-                lib().t8gpu_synth_part_destroy(self._h)
-            except TypeError:                                   # interpreter shutdown: the module globals are gone
-                pass
-            self._h = None
+    # (the partition handle belongs to self._owner, which the array views share: destroyed with the last of them)
