@@ -49,7 +49,7 @@ class PlainPlan:
         # the face cap chosen by the heuristics below, or handed down from the plan of the mesh this one was adapted from
         # (amr._inherited_plan_options); None: the default
         self.auto_fcap = given_fcap
-        retry_768 = given_fcap == 480 and dtype == torch.float64      # an inherited 480 still has to fit the persistent kernel
+        retry_768 = given_fcap in (384, 480) and dtype == torch.float64      # an inherited cap still has to fit the persistent kernel
         if (fcap is None and "T8GPU_FCAP" not in os.environ and not small and dtype == torch.float64 and
                 getattr(part.mesh, "dim", 2) == 3):
             # fp64 on 3D meshes. Curved meshes (no small geometry dictionary) run the one-tile kernel, which holds three
@@ -79,6 +79,15 @@ class PlainPlan:
             if not (compressed and dictionary and self._persistent_accepts(self.host, dtype, flux_kind)):
                 fcap = self.auto_fcap = 768
                 self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary), patches=self.patches, irregular=self.irregular)
+            elif given_fcap is None and self.host.n_patches * 256 > part.N // 2 and self.host.n_patches < self.host.ntiles:
+                # Most of the mesh in patches: the generic tiles are what is left BETWEEN patches -- short stretches (c5: 144
+                # elements / 520 faces each, a 2-cell slab of fine cells beside coarse ones) that a 480-face cap cuts 120 + 24.
+                # Measured on c5 (scripts/fcap_scan.sh): 256: 5 340, 300: 5 640, 360-400: 5 720-5 760, 440: 5 540, 480: 5 420 M/s
+                # (a plan without patches prefers 480: 4 550 against 4 130 at 380).
+                trial = HostPlainPlan.from_partition(part, tmax=tmax, fcap=384, want_face_geo=not (compressed and dictionary), patches=self.patches, irregular=self.irregular)
+                if self._persistent_accepts(trial, dtype, flux_kind):
+                    fcap = self.auto_fcap = 384
+                    self.host = trial
         self.dtype = dtype
         self._keep = {}
         c = T8gpuPlainPlan()
