@@ -29,6 +29,7 @@ class PlainPlan:
             patches = compressed and os.environ.get("T8GPU_PATCH", "1") != "0"
         self.patches = patches if compressed else False          # True / False, or 2 / 3 for one kind only
         # 3D: blocks next to periodic wraps / walls / coarser - side neighbours become (irregular) patches too
+        irregular_auto = irregular is None and "T8GPU_PATCH_IRREGULAR" not in os.environ   # (nobody asked: the rules below may drop it)
         if irregular is None:
             irregular = {"0": False, "all": "all"}.get(os.environ.get("T8GPU_PATCH_IRREGULAR", "1"), True)
         self.irregular = irregular
@@ -79,15 +80,28 @@ class PlainPlan:
             if not (compressed and dictionary and self._persistent_accepts(self.host, dtype, flux_kind)):
                 fcap = self.auto_fcap = 768
                 self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary), patches=self.patches, irregular=self.irregular)
-            elif given_fcap is None and self.host.n_patches * 256 > part.N // 2 and self.host.n_patches < self.host.ntiles:
-                # Most of the mesh in patches: the generic tiles are what is left BETWEEN patches -- short stretches (c5: 144
-                # elements / 520 faces each, a 2-cell slab of fine cells beside coarse ones) that a 480-face cap cuts 120 + 24.
-                # Measured on c5 (scripts/fcap_scan.sh): 256: 5 340, 300: 5 640, 360-400: 5 720-5 760, 440: 5 540, 480: 5 420 M/s
-                # (a plan without patches prefers 480: 4 550 against 4 130 at 380).
-                trial = HostPlainPlan.from_partition(part, tmax=tmax, fcap=384, want_face_geo=not (compressed and dictionary), patches=self.patches, irregular=self.irregular)
-                if self._persistent_accepts(trial, dtype, flux_kind):
-                    fcap = self.auto_fcap = 384
-                    self.host = trial
+        if (given_fcap is None and "T8GPU_FCAP" not in os.environ and compressed and dictionary and fcap in (480, 512)
+                and getattr(part.mesh, "dim", 2) == 3 and self.host.n_patches * 256 > part.N // 2
+                and self.host.n_patches < self.host.ntiles):
+            # Most of a 3D mesh in patches: the generic tiles are what is left BETWEEN patches -- short stretches (c5: 144
+            # elements / 520 faces each, a 2-cell slab of fine cells beside coarse ones) that a 480-face cap cuts 120 + 24 and a
+            # 512-face cap 140 + 4. Measured on c5, fp64 (scripts/fcap_scan.sh): 256: 5 340, 300: 5 640, 360-400: 5 720-5 760,
+            # 440: 5 540, 480: 5 420 M/s; fp32: 512: 9 310, 384: 9 950 (a plan without patches prefers 480: 4 550 against
+            # 4 130 at 380).
+            trial = HostPlainPlan.from_partition(part, tmax=tmax, fcap=384, want_face_geo=False, patches=self.patches, irregular=self.irregular)
+            # (fp64: only if the persistent kernel still takes the plan -- the one-tile kernel wants 768; fp32 runs either kernel well)
+            if dtype == torch.float32 or self._persistent_accepts(trial, dtype, flux_kind):
+                fcap = self.auto_fcap = 384
+                self.host = trial
+        # fp32: the irregular patch form pays only where the alternative is a launch of generic tiles too small for the
+        # persistent kernel (the uniform box c5u: 10 480 -> 12 680 M/s); where the blocks would simply join a large generic
+        # launch it costs (c5: 10 630 -> 9 960) -- in fp32 its selects and signs weigh more against the flux than in fp64
+        # (c5 fp64: 5 560 -> 5 760). Asked of the launcher with the tile count the plan would have without the form.
+        n_irr = sum(self.host.n_irregular_class)
+        if (dtype == torch.float32 and self.irregular is True and irregular_auto and n_irr and compressed and dictionary
+                and self._persistent_accepts(self.host, dtype, flux_kind, n_generic=self.host.ntiles - self.host.n_patches + 2 * n_irr)):
+            self.irregular = False
+            self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=False, patches=self.patches, irregular=False)
         self.dtype = dtype
         self._keep = {}
         c = T8gpuPlainPlan()
@@ -139,7 +153,7 @@ class PlainPlan:
         self.c = c
 
     @staticmethod
-    def _persistent_accepts(h, dtype, flux_kind=None):
+    def _persistent_accepts(h, dtype, flux_kind=None, n_generic=None):
         """Would a whole-plan launch of host plan `h` run the persistent tile kernel? (t8gpu_hip_plain_persistent_accepts:
         the launcher's decision; only integer fields and the presence of the compressed arrays matter, so it can be asked
         before anything is uploaded -- and without a GPU.)"""
@@ -152,7 +166,7 @@ class PlainPlan:
         c.ntiles, c.max_elems, c.max_halo, c.max_faces, c.max_slots = h.ntiles, h.max_elems, h.max_halo, h.max_faces, h.max_slots
         fn = hip.lib().t8gpu_hip_plain_persistent_accepts
         fn.restype = C.c_int
-        n_generic = h.ntiles - h.n_patches
+        n_generic = h.ntiles - h.n_patches if n_generic is None else n_generic
         return bool(fn(C.byref(c), int(hip.KEPES if flux_kind is None else flux_kind), 4 if dtype == torch.float32 else 8, int(n_generic)))
 
     @staticmethod

@@ -69,7 +69,7 @@ def test_patch3_kernel_vs_oracle_and_bitwise_vs_tile_kernels(dtype, kind, mesh_a
     mesh = SynthMesh(**mesh_args)
     part = mesh.partition()
     st = perturbed_state(part, 41)
-    a, b = _pair(part, dtype, kind, st)
+    a, b = _pair(part, dtype, kind, st, irregular=True)     # (asked for: left alone, fp32 plans drop the form where it does not pay)
     assert a.plan.host.patch_dim == 3
     # every one of these meshes has blocks next to a periodic wrap, a coarser neighbour or a wall: IRREGULAR patches (the
     # irregular instantiation of k_plain_patch3) beside the regular ones
