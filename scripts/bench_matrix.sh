@@ -20,7 +20,7 @@ run --workload c5
 run --workload c5p
 run --workload c5t
 run --workload c5u
-run --workload c5a --steps 60
+run --workload c5a --steps 100
 python3 - "$OUT" <<'PY'
 import json, sys
 for l in open(sys.argv[1]):
