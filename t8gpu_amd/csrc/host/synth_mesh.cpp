@@ -38,6 +38,9 @@ struct Mesh {
   double band = 0, shrink = 1;
   std::vector<Leaf>    leaves;
   std::vector<int32_t> owner;  // finest-level grid -> leaf index
+  // set by the one-pass adapt: the forest this one was adapted from and the first old element of every new element
+  const void*          adapted_from = nullptr;
+  std::vector<int32_t> adapt_data;
 
   size_t grid_index(const uint32_t p[3]) const {
     size_t i = dim == 3 ? p[2] : 0;
@@ -527,27 +530,20 @@ void t8gpu_synth_mesh_marks(const void* mesh, const double* criteria, double thr
   const size_t n    = M.leaves.size();
   const int    nsub = 1 << M.dim;
   const int    navg = family_members_averaged > 0 ? std::min(family_members_averaged, nsub) : nsub;
-  std::fill(marks, marks + n, static_cast<int8_t>(0));
   // t8code calls the callback element by element; with is_family = 1 only when the element opens a
   // complete family. Refinement is tested first and on the element's own criterion only; -1 coarsens
-  // the whole family and skips its other members.
-  for (size_t e = 0; e < n;) {
-    const Leaf& l   = M.leaves[e];
-    const bool  fam = is_family_start(M, e);
-    if (l.level < max_level && criteria[e] > threshold) {
-      marks[e++] = 1;
-      continue;
-    }
-    if (l.level > min_level && fam) {
-      double mean = 0;
-      for (int ch = 0; ch < navg; ch++) mean += criteria[e + ch] / navg;
-      if (mean < threshold) {
-        for (int ch = 0; ch < nsub; ch++) marks[e + ch] = -1;
-        e += nsub;
-        continue;
-      }
-    }
-    e++;
+  // the whole family and skips its other members. Two parallel passes give the marks of that sequential walk: every
+  // element's own refinement test, then the families (disjoint: child 0 opens one) whose first member does not refine.
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
+  for (int64_t e = 0; e < static_cast<int64_t>(n); e++)
+    marks[e] = (M.leaves[e].level < max_level && criteria[e] > threshold) ? 1 : 0;
+#pragma omp parallel for num_threads(host_threads()) schedule(static)
+  for (int64_t e = 0; e < static_cast<int64_t>(n); e++) {
+    if (__atomic_load_n(&marks[e], __ATOMIC_RELAXED) != 0 || M.leaves[e].level <= min_level || !is_family_start(M, static_cast<size_t>(e))) continue;
+    double mean = 0;
+    for (int ch = 0; ch < navg; ch++) mean += criteria[e + ch] / navg;
+    if (mean < threshold)
+      for (int ch = 0; ch < nsub; ch++) __atomic_store_n(&marks[e + ch], static_cast<int8_t>(-1), __ATOMIC_RELAXED);
   }
 }
 
@@ -726,11 +722,15 @@ void* t8gpu_synth_mesh_adapt(const void* mesh, const int8_t* marks) {
   M->dim = O.dim; M->base = O.base; M->band = O.band; M->shrink = O.shrink; M->periodic = O.periodic;
   M->lmax = newmax;
   M->leaves.resize(static_cast<size_t>(at[n]));
+  M->adapted_from = mesh;   // (t8gpu_synth_mesh_adapt_data copies the correspondence instead of walking the two forests)
+  M->adapt_data.resize(static_cast<size_t>(at[n]) + 1);
+  M->adapt_data[static_cast<size_t>(at[n])] = static_cast<int32_t>(n);
 #pragma omp parallel for num_threads(host_threads()) schedule(static)
   for (int64_t e = 0; e < n; e++) {
     const Leaf& l = O.leaves[e];
     Leaf*       o = M->leaves.data() + at[e];
     if (at[e + 1] == at[e]) continue;
+    for (int64_t i = at[e]; i < at[e + 1]; i++) M->adapt_data[static_cast<size_t>(i)] = static_cast<int32_t>(e);
     if (d[e] > 0) {
       for (int ch = 0; ch < nsub; ch++) {
         o[ch].level = l.level + 1;
@@ -755,6 +755,11 @@ void* t8gpu_synth_mesh_adapt_by_rounds(const void* mesh, const int8_t* marks) { 
 int t8gpu_synth_mesh_adapt_data(const void* old_mesh, const void* new_mesh, int32_t* adapt_data) {
   const Mesh&  O = *static_cast<const Mesh*>(old_mesh);
   const Mesh&  N = *static_cast<const Mesh*>(new_mesh);
+  if (N.adapted_from == old_mesh && N.adapt_data.size() == N.leaves.size() + 1 &&
+      N.adapt_data.back() == static_cast<int32_t>(O.leaves.size())) {   // recorded by the one-pass adapt
+    std::memcpy(adapt_data, N.adapt_data.data(), N.adapt_data.size() * sizeof(int32_t));
+    return 0;
+  }
   const int    nsub = 1 << O.dim;
   size_t       oi = 0, ni = 0;
   const size_t no = O.leaves.size(), nn = N.leaves.size();
