@@ -24,6 +24,20 @@ class PlainPlan:
         with per-face geometry rows even where the mesh has few distinct ones (what curved meshes get anyway).
         patches: cut structured 16 x 16 patches out of the tiling for the patch kernel (default: yes for the compressed
         plan; T8GPU_PATCH=0 switches it off -- same results bit for bit, every element through the tile kernels)."""
+        skip_geo = self._plan_on_host(part, dtype, tmax, fcap, compressed, dictionary, patches, flux_kind, irregular)
+        self._upload(dtype, compressed, dictionary, skip_geo, part)
+
+    @classmethod
+    def on_host(cls, part, dtype, **kw):
+        """The host half alone (no GPU): the tile plan and the caps / patch forms the rules below settle on (`host`, `auto_fcap`,
+        `irregular`, `auto_irregular`). Tests pin the rules through this."""
+        self = object.__new__(cls)
+        args = dict(tmax=None, fcap=None, compressed=True, dictionary=True, patches=None, flux_kind=None, irregular=None)
+        args.update(kw)
+        self._plan_on_host(part, dtype, **args)
+        return self
+
+    def _plan_on_host(self, part, dtype, tmax, fcap, compressed, dictionary, patches, flux_kind, irregular):
         import os
         if patches is None:
             patches = compressed and os.environ.get("T8GPU_PATCH", "1") != "0"
@@ -102,9 +116,6 @@ class PlainPlan:
                 and self._persistent_accepts(self.host, dtype, flux_kind, n_generic=self.host.ntiles - self.host.n_patches + 2 * n_irr)):
             self.irregular = False
             self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=False, patches=self.patches, irregular=False)
-        self.dtype = dtype
-        self._keep = {}
-        c = T8gpuPlainPlan()
         h = self.host
         # What an ADAPTED mesh's plan inherits (amr._inherited_plan_options): where nearly every patch is an irregular one -- thin
         # refined sheets: c5a has 5 944 irregular and 8 regular patches -- the irregular form buys nothing (it runs at the speed of
@@ -117,6 +128,13 @@ class PlainPlan:
                     and h.max_faces <= 1024)
         if not skip_geo and h.face_geo.shape[0] == 0 and h.face_lr.size:     # the kernels this plan gets do read the rows
             self.host = h = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=True, patches=self.patches, irregular=self.irregular)
+        return skip_geo
+
+    def _upload(self, dtype, compressed, dictionary, skip_geo, part):
+        """device copies of the host plan's arrays and the T8gpuPlainPlan that points at them"""
+        self.dtype = dtype
+        self._keep = {}
+        c = T8gpuPlainPlan()
         for name in HostPlainPlan.FIELDS:
             a = getattr(self.host, name)
             if name == "face_geo":

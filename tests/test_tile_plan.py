@@ -286,3 +286,28 @@ def test_tile_cap_heuristics_ask_the_launchers_own_test():
     assert acc(large, torch.float64, hip.KEPES) and acc(large, torch.float64, hip.HLL)
     wide = HostPlainPlan.from_partition(SynthMesh(3, 6, 8, band=0.05).partition(), tmax=256, fcap=512, want_face_geo=False)
     assert not acc(wide, torch.float64, hip.KEPES)          # 512-face 3D tiles: the third workgroup per CU does not fit
+
+
+def test_patch_form_and_cap_rules_of_the_device_plan():
+    """fused.PlainPlan.on_host (no GPU): on the c5 benchmark mesh -- patches carry 83 % of it, the generic tiles are the short
+    stretches between them -- both float types settle on 384-face tiles; fp64 keeps the irregular patch form, fp32 drops it
+    (the plan without it is large enough for the persistent kernel); a uniform periodic box keeps it in both (the wrap
+    layers alone would be a launch too small for that kernel); asked for explicitly it always stays."""
+    import torch
+    from t8gpu_amd.fused import PlainPlan
+    c5 = SynthMesh(3, 6, 8, band=0.05).partition()
+    p64 = PlainPlan.on_host(c5, torch.float64)
+    assert p64.auto_fcap == 384 and p64.irregular is True and p64.auto_irregular is True
+    assert sum(p64.host.n_irregular_class) > 0 and p64.host.n_patches * 256 > 0.8 * c5.N and p64.host.max_faces <= 384
+    p32 = PlainPlan.on_host(c5, torch.float32)
+    assert p32.auto_fcap == 384 and p32.irregular is False and sum(p32.host.n_irregular_class) == 0
+    assert PlainPlan.on_host(c5, torch.float32, irregular=True).host.n_irregular_class != (0, 0, 0)
+    box = SynthMesh(3, 7, 7).partition()
+    for dt in (torch.float64, torch.float32):
+        b = PlainPlan.on_host(box, dt)
+        assert b.irregular is True and b.host.n_patches == b.host.ntiles and sum(b.host.n_irregular_class) > 0
+    # a plan whose patches are nearly all irregular hands "no irregular form" down to the meshes adapted from it
+    sheet = SynthMesh(3, 4, 6, band=0.02).partition()
+    s = PlainPlan.on_host(sheet, torch.float64)
+    n_irr = sum(s.host.n_irregular_class)
+    assert s.auto_irregular == (n_irr <= 4 * (s.host.n_patches - n_irr))
