@@ -110,6 +110,9 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
   // records of the right operands of the cell's + faces; flux slots of its - faces (the + faces of the cells across)
   patch3_plus_slots(c, rx, ry, rz);
   patch3_minus_slots(c, a_mx, a_my, a_mz);
+  // (the IRREGULAR instantiation holds the three operand slots packed 10 bits each in one register; the flux slots of the - faces
+  //  it recomputes per patch from an opaque copy of c: one more register held across the loop would spill)
+  const unsigned pk_plus  = static_cast<unsigned>(rx) | static_cast<unsigned>(ry) << 10 | static_cast<unsigned>(rz) << 20;
   // pairwise order of the - faces (true: the second-named axis' face has the smaller id); where both coordinates of the pair
   // are 0 the patch's flags decide (bits 0 / 1 / 2)
   const bool r_yx = patch3_ctz(cj) >= patch3_ctz(ci), r_zx = patch3_ctz(ck) >= patch3_ctz(ci), r_zy = patch3_ctz(ck) >= patch3_ctz(cj);
@@ -210,8 +213,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
       const unsigned ia    = side ? static_cast<unsigned>(spare_of(c, 0)) : lr_cur;
       const int      id_a  = side ? spare_of(c, 1) : id_cur;
       const int      idw_a = side ? id_cur : spare_of(256 + c, 1);
-      int            qx, qy, qz;
-      patch3_plus_slots(patch3_fresh(c), qx, qy, qz);
+      const int      qx = pk_plus & 1023u, qy = (pk_plus >> 10) & 1023u, qz = pk_plus >> 20;
       if (!side) {   // the +x and the +y face of the lane's cell (compile-time axes: a run-time axis costs ~50 selects per face)
         {
           const bool own = (ia >> 1) & 1u;
