@@ -196,11 +196,15 @@ void build_part(Part& P) {
   uvector<RawFace> faces, walls;   // (sized by the counting pass, written by the second)
   // the faces a rank lists, in element order then face order (the single-rank listing rule). Two passes over the
   // elements that can touch the rank's range -- count, prefix sum, fill -- both parallel over elements.
+  // (the counting pass keeps the neighbours it looked up -- six random reads of the 512 MB lookup grid per element -- for the
+  // filling pass)
+  uvector<int32_t> nbs(static_cast<size_t>(n) * 2 * dim);
   auto visit = [&](int64_t e, RawFace* fo, RawFace* wo, int32_t& nf, int32_t& nw) {
     const bool mine = e >= lo && e < hi;
     nf = nw = 0;
+    int32_t* const cache = nbs.data() + static_cast<size_t>(e) * 2 * dim;
     for (int f = 0; f < 2 * dim; f++) {
-      const int32_t nb = M.across(static_cast<size_t>(e), f);
+      const int32_t nb = fo || wo ? cache[f] : (cache[f] = M.across(static_cast<size_t>(e), f));
       if (nb < 0) {
         if (mine) {
           if (wo) wo[nw] = {e, -1, f};

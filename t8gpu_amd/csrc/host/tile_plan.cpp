@@ -516,8 +516,10 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
     }
   }
   lap("greedy tiling");
-  // a tile must fit the kernel's LDS window: own + halo elements <= lecap; halve offenders (per greedy tile, in parallel)
-  {
+  // A tile must fit the kernel's LDS window: own + halo elements <= lecap. The greedy loop counts the halo as it goes, so this
+  // holds by construction; the sizing pass below checks it on the exact lists it builds anyway, and only if a tile should
+  // ever exceed the window are the offenders halved (per greedy tile, in parallel) and the lists sized again.
+  auto halve_oversized = [&]() {
     const int32_t nt0 = static_cast<int32_t>(P.elem_off.size()) - 1;
     std::vector<std::vector<int32_t>> cuts(nt0);   // extra offsets inside a greedy tile (almost always none)
 #pragma omp parallel num_threads(host_threads())
@@ -558,66 +560,73 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
       off.push_back(P.elem_off[t + 1]);
     }
     P.elem_off.swap(off);
-  }
-  lap("LDS window check");
-  const int32_t ntiles = static_cast<int32_t>(P.elem_off.size()) - 1;
-  // Per-tile lists. Tiles are independent: pass 1 sizes them (faces = sorted distinct faces of the tile's
-  // elements, halo = sorted distinct outside elements those faces touch), a prefix sum places them, pass 2
-  // fills the arrays in place. Both passes run over the tiles in parallel.
-  P.halo_off.assign(static_cast<size_t>(ntiles) + 1, 0);
-  P.face_off.assign(static_cast<size_t>(ntiles) + 1, 0);
-  P.csr_off.assign(static_cast<size_t>(N) + 1, 0);
-  std::vector<uint8_t> reads_ghost(ntiles, 0);
-  P.tile_patch.assign(ntiles, -1);
-  for (int32_t t = 0; t < ntiles; t++) P.tile_patch[t] = patch_at[P.elem_off[t]];
-  auto tile_lists = [&](int32_t t, std::vector<int32_t>& tf, std::vector<int32_t>& halo, StampSet& set) {
-    const int32_t e0 = P.elem_off[t], e1 = P.elem_off[t + 1];
-    if (P.tile_patch[t] >= 0) {   // no face records; the 64 elements across the sides in the patch kernel's fixed order
-      tf.clear();
-      halo.assign(P.patches[P.tile_patch[t]].halo, P.patches[P.tile_patch[t]].halo + P.patches[P.tile_patch[t]].nh);
-      return;
-    }
-    // distinct faces / outside elements through a hash set, then sorted (half the entries of the raw lists are duplicates)
-    tf.clear();
-    set.clear();
-    for (int32_t j = deg[e0]; j < deg[e1]; j++)
-      if (set.insert(ef[j])) tf.push_back(ef[j]);
-    std::sort(tf.begin(), tf.end());
-    halo.clear();
-    set.clear();
-    for (int32_t f : tf)
-      for (int w = 0; w < 2; w++) {
-        const int32_t s = side(f, w);
-        if (s >= 0 && (s < e0 || s >= e1) && set.insert(s)) halo.push_back(s);
-      }
-    std::sort(halo.begin(), halo.end());
   };
-  // (the lists of pass 1 are kept for pass 2: sorting them twice was 40 % of this phase)
-  std::vector<std::vector<int32_t>> tfs(ntiles), halos(ntiles);
+  int32_t ntiles = 0;
+  std::vector<uint8_t>              reads_ghost;
+  std::vector<std::vector<int32_t>> tfs, halos;   // (the lists of pass 1 are kept for pass 2: sorting them twice was 40 % of this phase)
+  for (int attempt = 0;; attempt++) {
+    ntiles = static_cast<int32_t>(P.elem_off.size()) - 1;
+    // Per-tile lists. Tiles are independent: pass 1 sizes them (faces = sorted distinct faces of the tile's
+    // elements, halo = sorted distinct outside elements those faces touch), a prefix sum places them, pass 2
+    // fills the arrays in place. Both passes run over the tiles in parallel.
+    P.halo_off.assign(static_cast<size_t>(ntiles) + 1, 0);
+    P.face_off.assign(static_cast<size_t>(ntiles) + 1, 0);
+    P.csr_off.assign(static_cast<size_t>(N) + 1, 0);
+    reads_ghost.assign(ntiles, 0);
+    P.tile_patch.assign(ntiles, -1);
+    for (int32_t t = 0; t < ntiles; t++) P.tile_patch[t] = patch_at[P.elem_off[t]];
+    auto tile_lists = [&](int32_t t, std::vector<int32_t>& tf, std::vector<int32_t>& halo, StampSet& set) {
+      const int32_t e0 = P.elem_off[t], e1 = P.elem_off[t + 1];
+      if (P.tile_patch[t] >= 0) {   // no face records; the 64 elements across the sides in the patch kernel's fixed order
+        tf.clear();
+        halo.assign(P.patches[P.tile_patch[t]].halo, P.patches[P.tile_patch[t]].halo + P.patches[P.tile_patch[t]].nh);
+        return;
+      }
+      // distinct faces / outside elements through a hash set, then sorted (half the entries of the raw lists are duplicates)
+      tf.clear();
+      set.clear();
+      for (int32_t j = deg[e0]; j < deg[e1]; j++)
+        if (set.insert(ef[j])) tf.push_back(ef[j]);
+      std::sort(tf.begin(), tf.end());
+      halo.clear();
+      set.clear();
+      for (int32_t f : tf)
+        for (int w = 0; w < 2; w++) {
+          const int32_t s = side(f, w);
+          if (s >= 0 && (s < e0 || s >= e1) && set.insert(s)) halo.push_back(s);
+        }
+      std::sort(halo.begin(), halo.end());
+    };
+    tfs.assign(ntiles, {});
+    halos.assign(ntiles, {});
+    P.max_halo = P.max_faces = P.max_elems = P.max_slots = 0;
 #pragma omp parallel num_threads(host_threads())
-  {
-    StampSet set(log2cap);
+    {
+      StampSet set(log2cap);
 #pragma omp for schedule(dynamic, 64)
+      for (int32_t t = 0; t < ntiles; t++) {
+        std::vector<int32_t>&tf = tfs[t], &halo = halos[t];
+        tile_lists(t, tf, halo, set);
+        // (an irregular patch keeps its per-cell words where a generic tile keeps face records: 512 entries of face_lr / face_orig)
+        const bool irregular = P.tile_patch[t] >= 0 && !P.patches[P.tile_patch[t]].info.empty();
+        P.face_off[t + 1] = irregular ? kPatchInfoWords : static_cast<int32_t>(tf.size());
+        P.halo_off[t + 1] = static_cast<int32_t>(halo.size());
+        reads_ghost[t]    = !halo.empty() && *std::max_element(halo.begin(), halo.end()) >= N;
+      }
+    }
     for (int32_t t = 0; t < ntiles; t++) {
-      std::vector<int32_t>&tf = tfs[t], &halo = halos[t];
-      tile_lists(t, tf, halo, set);
-      // (an irregular patch keeps its per-cell words where a generic tile keeps face records: 512 entries of face_lr / face_orig)
-      const bool irregular = P.tile_patch[t] >= 0 && !P.patches[P.tile_patch[t]].info.empty();
-      P.face_off[t + 1] = irregular ? kPatchInfoWords : static_cast<int32_t>(tf.size());
-      P.halo_off[t + 1] = static_cast<int32_t>(halo.size());
-      reads_ghost[t]    = !halo.empty() && *std::max_element(halo.begin(), halo.end()) >= N;
+      const int32_t ne = P.elem_off[t + 1] - P.elem_off[t], nh = P.halo_off[t + 1], nf = P.face_off[t + 1];
+      if (P.tile_patch[t] < 0) {   // the maxima size the generic kernels' LDS windows: patch tiles are not theirs
+        P.max_halo  = std::max(P.max_halo, nh);
+        P.max_faces = std::max(P.max_faces, nf);
+        P.max_elems = std::max(P.max_elems, ne);
+        P.max_slots = std::max(P.max_slots, ne + nh);
+      }
+      P.halo_off[t + 1] += P.halo_off[t];
+      P.face_off[t + 1] += P.face_off[t];
     }
-  }
-  for (int32_t t = 0; t < ntiles; t++) {
-    const int32_t ne = P.elem_off[t + 1] - P.elem_off[t], nh = P.halo_off[t + 1], nf = P.face_off[t + 1];
-    if (P.tile_patch[t] < 0) {   // the maxima size the generic kernels' LDS windows: patch tiles are not theirs
-      P.max_halo  = std::max(P.max_halo, nh);
-      P.max_faces = std::max(P.max_faces, nf);
-      P.max_elems = std::max(P.max_elems, ne);
-      P.max_slots = std::max(P.max_slots, ne + nh);
-    }
-    P.halo_off[t + 1] += P.halo_off[t];
-    P.face_off[t + 1] += P.face_off[t];
+    if (P.max_slots <= P.lecap || attempt > 0) break;
+    halve_oversized();
   }
   lap("per-tile lists (sizes)");
   // Dictionary of the distinct {nx, ny, nz, area} tuples (exact bit patterns) of the mesh's faces: Cartesian AMR meshes
