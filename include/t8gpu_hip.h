@@ -138,7 +138,8 @@ typedef struct T8gpuPlainPlan {
   const uint32_t* face_lr;    /* tile-local l | r << 16 (r = 0xFFFF: reflective wall)             */
   const void*     face_geo;   /* float_type [n_faces][4] = nx, ny, nz, area                       */
   const int32_t*  face_orig;  /* original face index if this tile reports the speed, else -1      */
-  const int32_t*  csr_off;    /* [N+1] into csr_ent                                               */
+  const int32_t*  csr_off;    /* [N+1] into csr_ent. The two CSR arrays are read by the generic kernel only: may be NULL where `ell`
+                               * and `tile_desc` are given and max_elems <= 256, max_slots <= 512, max_faces <= 1024 (the pipelined kernels) */
   const uint16_t* csr_ent;    /* tile-local face | 0x8000 when the element is the face's right side */
   const int32_t*  tile_order; /* [ntiles] deep-interior tiles, then interior tiles that read an element
                                * owned by a ghost-reading tile, then the tiles reading ghost slots */

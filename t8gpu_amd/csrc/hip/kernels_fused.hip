@@ -149,6 +149,9 @@ int plain_generic_stage(int kind, int stage, const T8gpuPlainPlan* plan, int til
   const bool  pipelined = plan->ell && plan->tile_desc && plan->ell_width >= 8 && plan->ell_width % 8 == 0 && plan->max_elems <= 256 &&
                          slots <= 512 && plan->max_faces <= 1024;
   const bool  four = plan->max_faces > 512;
+  // (the generic kernel walks the CSR lists; callers that know their plan stays inside the pipelined kernels' limits need not
+  //  upload them -- t8gpu_amd/fused.py does not)
+  if (!pipelined && (!plan->csr_off || !plan->csr_ent)) return static_cast<int>(hipErrorInvalidValue);
   static const bool scatter = std::getenv("T8GPU_LDS_SCATTER") && std::getenv("T8GPU_LDS_SCATTER")[0] == '1';   // measured alternative
   // The persistent, software-pipelined kernel (kernels_fused_persistent.hip) for launches that cover the whole plan.
   // A multi-rank stage is split into tile classes on three streams beside the pack / RCCL / unpack kernels

@@ -135,8 +135,15 @@ class PlainPlan:
         self.dtype = dtype
         self._keep = {}
         c = T8gpuPlainPlan()
+        # the per-element CSR lists are what the generic kernel walks; a compressed plan inside the pipelined kernels' limits
+        # (the launcher's own condition, kernels_fused.hip: plain_generic_stage) never runs it: 2 + 4 bytes per incidence
+        # less to upload (50 MB at 3 M elements in 3D)
+        h = self.host
+        skip_csr = compressed and h.max_elems <= 256 and h.max_slots <= 512 and h.max_faces <= 1024 and h.ell_width % 8 == 0
         for name in HostPlainPlan.FIELDS:
             a = getattr(self.host, name)
+            if skip_csr and name in ("csr_off", "csr_ent"):
+                continue
             if name == "face_geo":
                 if skip_geo:
                     continue
