@@ -368,6 +368,8 @@ def bench_adaptive(args, w, dts, tdtype, kindf, mode, rank, world, dist, rehears
     from t8gpu_amd.synth import SynthMesh
     if os.environ.get("T8GPU_KEEP_HEAP", "1") != "0":
         hostmem.keep_heap()     # the cycle's host arrays are reused instead of page-faulted in again every adapt
+    if os.environ.get("T8GPU_PINNED_UPLOADS", "1") != "0" and not rehearsal:
+        hostmem.use_pinned_uploads()   # ~300 MB of plan / connectivity arrays per cycle through one pinned staging buffer
     a = dict(w["adaptive"])
     if os.environ.get("T8GPU_C5A_LEVELS"):      # "min,max": a small version of the same loop (tests)
         a["min_level"], a["max_level"] = (int(x) for x in os.environ["T8GPU_C5A_LEVELS"].split(","))

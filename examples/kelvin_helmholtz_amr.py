@@ -37,6 +37,8 @@ def main():
     args = ap.parse_args()
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
     hostmem.keep_heap()      # host arrays of an adapt cycle are reused by the next one (t8gpu_amd/hostmem.py)
+    if os.environ.get("T8GPU_REHEARSAL", "0") != "1":
+        hostmem.use_pinned_uploads()   # ... and uploaded through one pinned staging buffer
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     rehearsal = os.environ.get("T8GPU_REHEARSAL", "0") == "1"
     dist = None

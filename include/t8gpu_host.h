@@ -177,6 +177,10 @@ int t8gpu_host_write_vtu(const char* path, int dim, int64_t num_elements, const 
 int t8gpu_host_write_pvtu(const char* path, int num_pieces, const char* const* piece_files, int num_fields,
                           const char* const* names, const int32_t* components);
 
+/* ---- host utilities ------------------------------------------------------------------------------ */
+/* memcpy over the planners' OpenMP threads (staging of large uploads into an application-owned pinned buffer) */
+void t8gpu_host_parallel_copy(void* dst, const void* src, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import hip
+from . import hip, hostmem
 from .plan import HostPlainPlan
 
 
@@ -152,7 +152,7 @@ class PlainPlan:
                 a = a.view(np.int32)
             if a.dtype == np.uint16:
                 a = a.view(np.int16)
-            t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            t = hostmem.to_device(a)
             self._keep[name] = t
             setattr(c, name, t.data_ptr())
         npf = np.float32 if dtype == torch.float32 else np.float64
@@ -164,7 +164,7 @@ class PlainPlan:
                 extra["geo_table"] = self.host.geo_table.astype(npf)
                 c.n_geo = self.host.geo_table.shape[0]
             for name, a in extra.items():
-                t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+                t = hostmem.to_device(a)
                 self._keep[name] = t
                 setattr(c, name, t.data_ptr())
         c.ntiles, c.n_interior_tiles = self.host.ntiles, self.host.n_interior

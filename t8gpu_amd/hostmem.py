@@ -25,3 +25,74 @@ def keep_heap(top_pad=1 << 30):
         return False
     _done = bool(ok)
     return _done
+
+
+class PinnedUploader:
+    """Host -> device copies of large numpy arrays through ONE pinned staging buffer the application owns.
+
+    `tensor.cuda()` on a pageable array lets the runtime stage it through its own pinned bounce buffers at ~10 GB/s; an adapt
+    cycle uploads ~300 MB that way. Here a chunk is copied into the pinned buffer by the planners' threads
+    (t8gpu_host_parallel_copy), handed to the DMA engine asynchronously, and the next chunk is staged meanwhile in the rest of
+    the buffer; when the buffer is full the stream is synchronised and it starts over. Opt-in (use_pinned_uploads(): bench c5a,
+    the example): the default path of the package stays `tensor.cuda()`."""
+
+    def __init__(self, megabytes=256, chunk_megabytes=32):
+        import torch
+        from . import synth
+        self.cap, self.chunk = int(megabytes) << 20, int(chunk_megabytes) << 20
+        self.buf = torch.empty(self.cap, dtype=torch.uint8, pin_memory=True)
+        self.off = 0
+        self._copy = synth.lib().t8gpu_host_parallel_copy
+        self._copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        self._copy.restype = None
+
+    def upload(self, a):
+        """numpy array (C-contiguous) -> CUDA tensor of the same dtype and shape (asynchronous on the current stream)."""
+        import numpy as np
+        import torch
+        a = np.ascontiguousarray(a)
+        out = torch.empty(a.shape, dtype=torch.from_numpy(a.reshape(-1)[:1]).dtype, device="cuda")
+        n = a.nbytes
+        if n == 0:
+            return out
+        if n < (1 << 20):                      # small arrays: not worth staging
+            out.copy_(torch.from_numpy(a))
+            return out
+        dst = out.view(torch.uint8).reshape(-1)
+        src, done = a.ctypes.data, 0
+        while done < n:
+            take = min(self.chunk, n - done)
+            if self.off + take > self.cap:     # the DMA engine may still read what is staged: drain it, start over
+                torch.cuda.current_stream().synchronize()
+                self.off = 0
+            self._copy(self.buf.data_ptr() + self.off, src + done, take)
+            dst[done:done + take].copy_(self.buf[self.off:self.off + take], non_blocking=True)
+            self.off += (take + 255) & ~255
+            done += take
+        return out
+
+
+_uploader = None
+
+
+def use_pinned_uploads(megabytes=256):
+    """From now on solver / plan uploads of this process go through a PinnedUploader (uploader() returns it)."""
+    global _uploader
+    if _uploader is None:
+        _uploader = PinnedUploader(megabytes)
+    return _uploader
+
+
+def uploader():
+    return _uploader
+
+
+def to_device(a, dtype=None):
+    """numpy array -> CUDA tensor (of `dtype` if given): through the pinned uploader if the application switched it on."""
+    import numpy as np
+    import torch
+    if _uploader is None:
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        return (t if dtype is None else t.to(dtype)).cuda()
+    t = _uploader.upload(a)
+    return t if dtype is None or t.dtype == dtype else t.to(dtype)

@@ -35,10 +35,8 @@ def _timer_end(solver, ev):
 
 
 def _dev(a, dtype=None):
-    t = torch.from_numpy(np.ascontiguousarray(a))
-    if dtype is not None:
-        t = t.to(dtype)
-    return t.cuda()
+    from . import hostmem
+    return hostmem.to_device(a, dtype)          # (tensor.cuda(), or the application's pinned staging buffer: hostmem.py)
 
 
 class PlainSolver:
