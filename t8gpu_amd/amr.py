@@ -23,6 +23,7 @@ def _inherited_plan_options(solver):
     opts = {}
     if getattr(plan, "auto_fcap", None) is not None:
         opts["fcap"] = plan.auto_fcap
+        opts["fcap_elements"] = getattr(plan, "auto_fcap_elements", None)     # (the mesh size the cap was chosen for)
     if getattr(plan, "auto_irregular", None) is not None:
         opts["irregular"] = plan.auto_irregular
     return opts or None

@@ -19,12 +19,12 @@ class T8gpuPlainPlan(C.Structure):
 
 class PlainPlan:
     def __init__(self, part, dtype, tmax=None, fcap=None, compressed=True, dictionary=True, patches=None, flux_kind=None,
-                 irregular=None):
+                 irregular=None, fcap_elements=None):
         """compressed=False: generic kernel (CSR lists, full geometry). dictionary=False: pipelined kernel
         with per-face geometry rows even where the mesh has few distinct ones (what curved meshes get anyway).
         patches: cut structured 16 x 16 patches out of the tiling for the patch kernel (default: yes for the compressed
         plan; T8GPU_PATCH=0 switches it off -- same results bit for bit, every element through the tile kernels)."""
-        skip_geo = self._plan_on_host(part, dtype, tmax, fcap, compressed, dictionary, patches, flux_kind, irregular)
+        skip_geo = self._plan_on_host(part, dtype, tmax, fcap, compressed, dictionary, patches, flux_kind, irregular, fcap_elements)
         self._upload(dtype, compressed, dictionary, skip_geo, part)
 
     @classmethod
@@ -32,13 +32,19 @@ class PlainPlan:
         """The host half alone (no GPU): the tile plan and the caps / patch forms the rules below settle on (`host`, `auto_fcap`,
         `irregular`, `auto_irregular`). Tests pin the rules through this."""
         self = object.__new__(cls)
-        args = dict(tmax=None, fcap=None, compressed=True, dictionary=True, patches=None, flux_kind=None, irregular=None)
+        args = dict(tmax=None, fcap=None, compressed=True, dictionary=True, patches=None, flux_kind=None, irregular=None, fcap_elements=None)
         args.update(kw)
         self._plan_on_host(part, dtype, **args)
         return self
 
-    def _plan_on_host(self, part, dtype, tmax, fcap, compressed, dictionary, patches, flux_kind, irregular):
+    def _plan_on_host(self, part, dtype, tmax, fcap, compressed, dictionary, patches, flux_kind, irregular, fcap_elements=None):
         import os
+        # An inherited face cap (amr._inherited_plan_options) was chosen for a mesh of `fcap_elements` elements: which kernel a
+        # plan gets depends on its tile count, so a mesh that has since grown or shrunk by more than a factor two decides again
+        # (a run that starts from a coarse mesh would otherwise keep the small mesh's 768-face one-tile plan for good).
+        if fcap is not None and fcap_elements and not (fcap_elements // 2 <= part.N <= 2 * fcap_elements):
+            fcap = None
+        self.auto_fcap_elements = fcap_elements if fcap is not None and fcap_elements else part.N
         if patches is None:
             patches = compressed and os.environ.get("T8GPU_PATCH", "1") != "0"
         self.patches = patches if compressed else False          # True / False, or 2 / 3 for one kind only
