@@ -180,6 +180,22 @@ typedef struct T8gpuPlainPlan {
                                * (t8gpu_host.h: t8gpu_plan_plain_create_ex flag 8): descriptor word 5 has 0x800, word 4 is the
                                * first of 512 face_lr / face_orig entries with the per-cell words. They run through the
                                * irregular instantiation of k_plain_patch3 in a launch of their own */
+  /* GHOST WINDOW (ABI 7). Run-time attachments of the multi-rank step driver (csrc/hip/stepper.hip), all NULL / 0 in a plan
+   * that comes from the planner -- callers of t8gpu_hip_plain_fused_stage_* leave them so unless they do what the driver does.
+   * With them a launch of the ghost-reading tiles needs no pack and no unpack kernel around the RCCL exchange:
+   *   ghost_buf != NULL: a slot s >= n_owned is read from ghost_buf[5 * (s - n_owned) + var] -- the receive buffer of the
+   *     exchange in its wire format -- instead of the mirror slot s of the planes (which is then neither read nor written);
+   *   send_map != NULL: after the RK update of owned element e the five new values also go to send_buf[5 * t + var] for every
+   *     send slot t of e: send_map[e] = -1 (not sent), t >= 0 (one slot), or -(2 + i) (several: send_list[i], send_list[i+1],
+   *     ... up to and including the first entry with bit 31 set; slot = entry & 0x7FFFFFFF).
+   * Taken by the 2D patch kernel and the one-tile kernels (launches with either pointer set run one tile per workgroup); the
+   * launchers refuse them for 3D patch tiles (hipErrorInvalidValue). */
+  const void*    ghost_buf;   /* DEVICE float_type [5 * G], element-major                                   */
+  const int32_t* send_map;    /* DEVICE [n_owned]                                                           */
+  const int32_t* send_list;   /* DEVICE, may be NULL when no element has more than one send slot            */
+  void*          send_buf;    /* DEVICE float_type [5 * n_send], element-major                              */
+  int32_t        n_owned;     /* N: first ghost slot                                                        */
+  int32_t        reserved7;
 } T8gpuPlainPlan;
 
 /* tile_begin/tile_count select a range of tile_order (0, ntiles = everything; [0, n_interior) can run
@@ -229,6 +245,12 @@ int t8gpu_hip_comm_create(const char* id128, int rank, int nranks, void** comm);
 int t8gpu_hip_comm_destroy(void* comm);
 int t8gpu_hip_comm_abort(void* comm);
 int t8gpu_hip_stream_wait(void* stream, double timeout_s); /* 0 idle, 1 timed out, else hipError_t */
+/* out4 = {RCCL version of the headers this library was compiled with (NCCL_VERSION_CODE), RCCL version of the library the
+ * process bound (ncclGetVersion), HIP_VERSION of the headers, hipRuntimeGetVersion}. A process may bind another build than
+ * the headers came from (the torch wheel's librccl / libamdhip64 against /opt/rocm's headers): t8gpu_hip_comm_create checks
+ * the pairs -- same major versions, RCCL >= 2.7 (the send / recv API this library uses, unchanged since) -- and returns
+ * hipErrorNotSupported otherwise; bench.py reports both pairs. */
+int t8gpu_hip_runtime_versions(int out4[4]);
 
 typedef struct T8gpuHalo {
   int32_t num_elements, num_ghosts, n_peers, n_send;
@@ -279,8 +301,15 @@ int t8gpu_hip_plain_stepper_iterate_steps_f64(void* stepper, int flux_kind, doub
  * (tests/test_gpu_graph.py), never yet across xGMI. T8GPU_GRAPH_RCCL=0 keeps the direct enqueue for steppers with a halo. */
 int t8gpu_hip_plain_stepper_graph(void* stepper, int enable, int* counts);
 int t8gpu_hip_plain_stepper_timing(void* stepper, int enable);
+/* Diagnostics (scripts/halo_overhead.py): with T8GPU_STEPPER_PROFILE=1 in the environment the step drivers time their own
+ * host calls; ns4 / calls4 (may be NULL) receive nanoseconds and counts for {kernel launches, RCCL groups, event records,
+ * stream waits} since the last reset. Returns 1 when the profile is on, 0 when off (all zeros). */
+int t8gpu_hip_stepper_host_profile(int reset, double* ns4, long long* calls4);
 int t8gpu_hip_plain_stepper_elapsed(void* stepper, double* total_ms, int* launches);
 int t8gpu_hip_plain_stepper_timed_stages(void* stepper); /* RK stages covered by elapsed() */
+/* host time the multi-rank driver spent enqueueing (wall time of its iterate calls) and the steps that covers, since
+ * creation or the last reset; 0 / 0 for single-rank steppers */
+int t8gpu_hip_plain_stepper_host_time(void* stepper, int reset, double* total_ms, long long* steps);
 
 /* ---- Subgrid<4,4,4> and Subgrid<4,4>, fused block kernels ("fast" tier) -----------------------------
  * One launch per RK stage replaces compute_inner_fluxes + compute_boundary_fluxes + compute_outer_fluxes

@@ -82,8 +82,20 @@ def main():
     print(f"(b) self-exchange per stage: {tb:.4f} ms/step  ({len(m)} messages of {m.tolist()} elements; "
           f"{b.plan.host.n_deep} deep / {b.plan.host.n_interior - b.plan.host.n_deep} near-boundary / "
           f"{b.plan.host.ntiles - b.plan.host.n_interior} ghost-reading tiles)", flush=True)
+    import ctypes as C
+    from t8gpu_amd import hip as _hip
+    _hip.lib().t8gpu_hip_stepper_host_profile(1, None, None)
     tc = timed(b, many=True)
+    ns, calls = (C.c_double * 4)(), (C.c_longlong * 4)()
+    if _hip.lib().t8gpu_hip_stepper_host_profile(1, ns, calls):
+        for c, name in enumerate(("kernel launches", "RCCL groups", "event records", "stream waits")):
+            print(f"    host profile of (c): {name:16s} {calls[c]:6d} calls, {ns[c] / max(1, calls[c]) * 1e-3:6.2f} us each, "
+                  f"{ns[c] * 1e-3 / (steps + 20):7.2f} us per step", flush=True)
     print(f"(c) same, all steps in one call: {tc:.4f} ms/step; the host needs {timed.host_ms:.4f} ms to enqueue a step", flush=True)
+    if __import__("os").environ.get("T8GPU_HALO_ONLY") == "c":   # (kernel traces: the window ends with the direct enqueue)
+        del a, b
+        comm.destroy()
+        return
     # (d) the same call through a hipGraph: captured once (RCCL groups included, on the capture's origin stream), then ONE
     # hipGraphLaunch per call -- the host cost of a step drops to the replay's
     b.stepper.graph(True)
@@ -99,8 +111,16 @@ def main():
     print(f"projected strong-scaling speedup at {world} ranks if every rank behaves like this one: "
           f"{one / tb:.2f}x direct enqueue per step, {one / tc:.2f}x all steps in one call, {one / td:.2f}x graph replay "
           f"(no exchange: {one / ta:.2f}x) -- a PROJECTION from one GPU: no byte crosses xGMI here", flush=True)
+    del a, b                                        # (T8GPU_STEPPER_PROFILE=1: the steppers print their host-cost profile here)
+    import gc
+    gc.collect()
     comm.destroy()
+    print("done", flush=True)
 
 
 if __name__ == "__main__":
-    main()
+    if __import__("os").environ.get("T8GPU_HALO_OWN_STREAM") == "1":     # the caller's stream is not the legacy default stream
+        with torch.cuda.stream(torch.cuda.Stream()):
+            main()
+    else:
+        main()

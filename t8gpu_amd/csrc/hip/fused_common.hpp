@@ -49,6 +49,35 @@ FVars<T> fmk(const V& v) {
   return o;
 }
 
+// ---- ghost window (T8gpuPlainPlan::ghost_buf / send_map: the multi-rank step driver's zero-copy exchange) -------------
+// State value `k` of slot `slot`: ghosts (slot >= n_owned) come from the exchange's receive buffer in its wire format.
+template <class T>
+T8_DEV T ghost_window_load(const T8gpuPlainPlan& P, const FVars<T>& src, int slot, int k) {
+  const T* gb = static_cast<const T*>(P.ghost_buf);
+  const T* p  = slot >= P.n_owned ? gb + (5 * static_cast<size_t>(slot - P.n_owned) + k) : src.p[k] + slot;
+  return *p;
+}
+// The five new values of owned element e also go to its send slots (a no-op for the elements no peer mirrors).
+template <class T>
+T8_DEV void ghost_window_send(const T8gpuPlainPlan& P, int e, const T v[5]) {
+  const int m = P.send_map[e];
+  if (m == -1) return;
+  T* const sb = static_cast<T*>(P.send_buf);
+  if (m >= 0) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) sb[5 * static_cast<size_t>(m) + k] = v[k];
+    return;
+  }
+  const int32_t* l = P.send_list + (-m - 2);
+  for (;;) {
+    const int ent = *l++;
+    const size_t t = static_cast<size_t>(ent & 0x7FFFFFFF);
+#pragma unroll
+    for (int k = 0; k < 5; k++) sb[5 * t + k] = v[k];
+    if (ent < 0) break;
+  }
+}
+
 // ---- LDS records of the persistent kernels (kernels_fused_persistent.hip, kernels_fused_patch.hip) ---------------
 template <class T>
 struct vec16;

@@ -101,10 +101,17 @@ T8_DEV void plain_tile_body(const T8gpuPlainPlan& P, int pos, const FVars<T>& pr
   const int  slot0 = own ? e0 + tid : (a0 ? P.halo_ids[h0 + (tid - ne)] : e0);
   const int  slot1 = a1 ? P.halo_ids[h0 + (i1 - ne)] : e0;
   T          s0[5], s1[5];
+  if (P.ghost_buf) {   // (wave-uniform: launches of the multi-rank driver's ghost-reading class; t8gpu_hip.h "ghost window")
 #pragma unroll
-  for (int k = 0; k < 5; k++) s0[k] = src.p[k][slot0];
+    for (int k = 0; k < 5; k++) s0[k] = ghost_window_load<T>(P, src, slot0, k);
 #pragma unroll
-  for (int k = 0; k < 5; k++) s1[k] = src.p[k][slot1];
+    for (int k = 0; k < 5; k++) s1[k] = ghost_window_load<T>(P, src, slot1, k);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 5; k++) s0[k] = src.p[k][slot0];
+#pragma unroll
+    for (int k = 0; k < 5; k++) s1[k] = src.p[k][slot1];
+  }
   // one pass's worth of the lane's face: packed slots, geometry (row index or the row itself), original id
   struct FaceIn {
     bool     valid;
@@ -305,10 +312,12 @@ T8_DEV void plain_tile_body(const T8gpuPlainPlan& P, int pos, const FVars<T>& pr
   // ---- RK stage (ssp_runge_kutta.inl:30-99) ---------------------------------------------------------
   if (own) {
     const T scale = dt / volume;
+    T       res[5];
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-      out.p[k][e] = rk_stage_update<T, STAGE>(pv[k], s0[k], scale, acc[k]);
-    }
+    for (int k = 0; k < 5; k++) res[k] = rk_stage_update<T, STAGE>(pv[k], s0[k], scale, acc[k]);
+#pragma unroll
+    for (int k = 0; k < 5; k++) out.p[k][e] = res[k];
+    if (P.send_map) ghost_window_send<T>(P, e, res);
   }
 }
 

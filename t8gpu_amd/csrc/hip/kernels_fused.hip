@@ -47,8 +47,13 @@ __global__ __launch_bounds__(256) void k_plain_fused(T8gpuPlainPlan P, int tile_
   for (int i = tid; i < ne + nh; i += 256) {
     const int slot = i < ne ? e0 + i : P.halo_ids[h0 + (i - ne)];
     T         s[5];
+    if (P.ghost_buf) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) s[k] = src.p[k][slot];
+      for (int k = 0; k < 5; k++) s[k] = ghost_window_load<T>(P, src, slot, k);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 5; k++) s[k] = src.p[k][slot];
+    }
     if (KIND == 0) {
       const Prim<T> q = prim_from_state<T, kTab>(s, lt);
       pe[0 * LE + i]  = q.rho;
@@ -121,11 +126,14 @@ __global__ __launch_bounds__(256) void k_plain_fused(T8gpuPlainPlan P, int tile_
       }
     }
     const T scale = dt / vol[e];
+    T       res[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) {
       // (stage 1: prev is the stage's source state, plain_fused_stage() checks it)
-      out.p[k][e] = rk_stage_update<T, STAGE>(prev.p[k][e], STAGE == 1 ? prev.p[k][e] : src.p[k][e], scale, acc[k]);
+      res[k] = rk_stage_update<T, STAGE>(prev.p[k][e], STAGE == 1 ? prev.p[k][e] : src.p[k][e], scale, acc[k]);
+      out.p[k][e] = res[k];
     }
+    if (P.send_map) ghost_window_send<T>(P, e, res);
   }
 }
 
@@ -159,7 +167,8 @@ int plain_generic_stage(int kind, int stage, const T8gpuPlainPlan* plan, int til
   // done and keep those small kernels -- the exchange the split exists to overlap -- from starting, so partial
   // ranges use the one-tile-per-workgroup kernels, whose slots free up continuously. Both give the same bits.
   static const bool persistent_always = std::getenv("T8GPU_PERSISTENT") && std::getenv("T8GPU_PERSISTENT")[0] == '2';
-  if (!scatter && (persistent_always || whole_plan)) {
+  // (the persistent kernel knows no ghost window -- t8gpu_hip.h: such launches run one tile per workgroup)
+  if (!scatter && (persistent_always || whole_plan) && !plan->ghost_buf && !plan->send_map) {
     const int rc = plain_persistent_stage<T>(kind, stage, plan, tile_begin, tile_count, fmk<T>(prev), fmk<T>(mid), fmk<T>(out), volume,
                                              dt, speed, s);
     if (rc >= 0) return rc;
@@ -232,6 +241,7 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
     for (int k = 0; k < 5; k++)
       if (prev.p[k] != mid.p[k]) return static_cast<int>(hipErrorInvalidValue);
   if (tile_count == 0) return 0;
+  if ((plan->ghost_buf || plan->send_map) && (plan->n_owned <= 0 || (plan->send_map && !plan->send_buf))) return static_cast<int>(hipErrorInvalidValue);
   stage_kernel_note_reset();
   const bool whole = tile_begin == 0 && tile_count == plan->ntiles;
   const int  np_total = plan->n_patch_tiles[0] + plan->n_patch_tiles[1] + plan->n_patch_tiles[2];
@@ -258,6 +268,7 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
     const int pb = b > s0 ? b : s0, pe = e < p1 ? e : p1;   // patch tiles of this class inside the range
     int       qb = b > p1 ? b : p1, qe = e < s1 ? e : s1;   // its generic tiles
     if (pe > pb && plan->patch_dim == 3) {   // 8 x 8 x 4 hexahedral patches: their own kernel, the generic tiles apart
+      if (plan->ghost_buf || plan->send_map) return static_cast<int>(hipErrorInvalidValue);   // (no ghost window in k_plain_patch3)
       if (int rc = flush()) return rc;
       // (Measured and dropped: the generic tiles on a side stream forked from / joined to the caller's stream by events, so
       //  that they run BESIDE the patches -- c5 5 235 -> 5 078, c5u 5 070 -> 4 716 M/s: the fork / join events cost more than

@@ -104,11 +104,16 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
   struct Pre {
     T s0[5], sh[5];
   };
-  auto prefetch = [&](const Desc& d, int hslot) {
+  // first: the prologue's request. A launch with a ghost window (t8gpu_hip.h; the multi-rank driver's ghost-reading class)
+  // runs one patch per workgroup -- plain_patch_stage() sees to it -- so only that request can meet a ghost slot.
+  auto prefetch = [&](const Desc& d, int hslot, bool first) {
     Pre p;
 #pragma unroll
     for (int k = 0; k < 5; k++) p.s0[k] = at32<T>(src.p[k], static_cast<unsigned>(d.e0 + tid));
-    if (halo_wave) {
+    if (halo_wave && first && P.ghost_buf) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) p.sh[k] = ghost_window_load<T>(P, src, hslot, k);
+    } else if (halo_wave) {
 #pragma unroll
       for (int k = 0; k < 5; k++) p.sh[k] = at32<T>(src.p[k], static_cast<unsigned>(hslot));
     } else {
@@ -121,7 +126,7 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
   const int stride = nx;
   Desc      d0 = load_desc(t), d1 = load_desc(t + stride);
   int       hs_a = halo_wave ? P.halo_ids[d0.h0 + hl] : 0, hs_b = halo_wave ? P.halo_ids[d1.h0 + hl] : 0;
-  Pre       cur = prefetch(d0, hs_a);
+  Pre       cur = prefetch(d0, hs_a, true);
   T         res[5] = {T(0), T(0), T(0), T(0), T(0)};
   int       res_e  = -1;
   __builtin_amdgcn_s_waitcnt(0);   // (see k_plain_persistent: the prologue's loads must not become a wait inside the loop)
@@ -130,7 +135,7 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
     const Desc d2   = load_desc(t + 2 * stride);
     const int  hs_c = halo_wave ? P.halo_ids[d2.h0 + hl] : 0;
     Pre        nxt;
-    if (t + stride < tend) nxt = prefetch(d1, hs_b);
+    if (t + stride < tend) nxt = prefetch(d1, hs_b, false);
     const int e = d0.e0 + tid;
     T         pv[5] = {T(0), T(0), T(0), T(0), T(0)};
     if (STAGE > 1) {
@@ -226,6 +231,7 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
   if (res_e >= 0) {
 #pragma unroll
     for (int k = 0; k < 5; k++) at32<T>(out.p[k], static_cast<unsigned>(res_e)) = res[k];
+    if (P.send_map) ghost_window_send<T>(P, res_e, res);   // (one patch per workgroup there: this is its only store)
   }
 }
 
@@ -306,6 +312,8 @@ int plain_patch_stage(int kind, int stage, const T8gpuPlainPlan* plan, int patch
   // workgroups that never leave.
   static const bool never_persistent = std::getenv("T8GPU_PATCH_PERSISTENT") && std::getenv("T8GPU_PATCH_PERSISTENT")[0] == '0';   // (measurements)
   if (never_persistent) persistent = false;
+  // a ghost window (t8gpu_hip.h) is honoured by a workgroup's FIRST patch only (plain_patch_body): one patch per workgroup
+  if (plan->ghost_buf || plan->send_map) persistent = false;
   const int  per_cu    = per_cu_env > 0 ? per_cu_env : (sizeof(T) == 8 ? 3 : 5);
   const int  resident  = cus * per_cu;
   const int  patch_wgs = (!persistent || patch_count < resident) ? patch_count : resident;

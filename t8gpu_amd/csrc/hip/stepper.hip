@@ -8,10 +8,14 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -32,6 +36,32 @@ inline int nccl_code(ncclResult_t r) { return r == ncclSuccess ? 0 : 10000 + sta
     int c__ = (expr);           \
     if (c__ != 0) return c__;   \
   } while (0)
+
+// Host cost of the enqueue by category (T8GPU_STEPPER_PROFILE=1; printed when the stepper is destroyed): where the time of a
+// multi-rank stage goes on the host -- kernel launches, the RCCL group, event records / waits.
+struct HostProfile {
+  bool   on = std::getenv("T8GPU_STEPPER_PROFILE") != nullptr;
+  double ns[4] = {0, 0, 0, 0};
+  long   calls[4] = {0, 0, 0, 0};
+};
+HostProfile& host_profile() {
+  static HostProfile p;
+  return p;
+}
+struct HostTimer {   // cat: 0 kernel launch, 1 RCCL group, 2 event record, 3 stream wait
+  int cat;
+  std::chrono::steady_clock::time_point t0;
+  explicit HostTimer(int c) : cat(c) {
+    if (host_profile().on) t0 = std::chrono::steady_clock::now();
+  }
+  ~HostTimer() {
+    if (!host_profile().on) return;
+    static std::mutex m;   // (two host threads enqueue: stepper lanes)
+    std::lock_guard<std::mutex> lk(m);
+    host_profile().ns[cat] += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
+    host_profile().calls[cat]++;
+  }
+};
 
 struct Stepper {
   T8gpuPlainPlan   plan{};      // plain elements: units = tiles of the plan
@@ -68,6 +98,35 @@ struct Stepper {
                                         // 5 = exchange chain on a FORKED stream of the capture (the layout that crashes)
   void*           scratch = nullptr;
   std::vector<hipEvent_t> capture_events;   // one event per (stage, role) of a captured call (see stage_event)
+
+  // ---- two-lane driver (iterate_lanes; round 4) ----------------------------------------------------------------------
+  static constexpr int kRing = 4;
+  struct Lane {
+    hipStream_t        stream = nullptr;
+    hipEvent_t         ring[kRing] = {nullptr, nullptr, nullptr, nullptr};   // the record of stage g uses ring[g % kRing]
+    std::atomic<long>  recorded{0};     // stages of the current call whose record has been issued
+    std::vector<hipEvent_t> pool;       // timing events of this lane
+    size_t             used = 0;
+  };
+  Lane            deep_lane, comm_lane;     // C tiles | RCCL, A tiles, B tiles
+  hipStream_t     deep_stream = nullptr;    // own stream of the C tiles (only with a CU mask: T8GPU_COMM_CUS), else the caller's
+  bool            zero_copy = false;        // ghost window: A tiles read the receive buffer and fill the send buffer themselves
+  T8gpuPlainPlan  plan_a{};                 // `plan` + the ghost window (launches of the A class)
+  void*           d_send_map = nullptr;
+  void*           d_send_list = nullptr;
+  std::atomic<bool> lane_abort{false};
+  // the comm lane's host thread (enqueues its lane while the caller's thread enqueues the deep lane)
+  std::thread               worker;
+  std::mutex                mu;
+  std::condition_variable   cv;
+  std::function<int()>      job;            // guarded by mu
+  std::atomic<int>          job_state{0};   // 0 idle, 1 posted, 2 done
+  int                       job_rc = 0;
+  bool                      worker_exit = false;
+  int                       device = 0;
+  bool                      threads = true;
+  double                    host_ns = 0;    // host time inside iterate_lanes (both threads overlap: wall time of the call)
+  long                      host_steps = 0;
 };
 
 // Events that order the three streams. Direct enqueue: one event per role, re-recorded every stage. Inside a capture
@@ -104,6 +163,7 @@ int exchange(const T8gpuHalo& h, const int32_t* peers, const int32_t* send_off, 
   T*       sb = static_cast<T*>(h.sendbuf);
   T*       rb = static_cast<T*>(h.recvbuf);
   const int cells = h.cells_per_element < 1 ? 1 : h.cells_per_element;
+  HostTimer htp(0);
   if constexpr (sizeof(T) == 4) {
     T8_TRY(t8gpu_hip_halo_pack_f32(h.n_send, cells, h.send_idx, state, sb, s));
   } else {
@@ -115,6 +175,7 @@ int exchange(const T8gpuHalo& h, const int32_t* peers, const int32_t* send_off, 
   ncclComm_t comm = static_cast<ncclComm_t>(h.comm);
 #ifndef T8GPU_EXP_NO_RCCL
   {
+  HostTimer ht(1);
   T8_TRY(nccl_code(ncclGroupStart()));
   for (int j = 0; j < h.n_peers; j++) {
     const size_t w  = 5 * static_cast<size_t>(cells);   // values per element on the wire
@@ -155,6 +216,276 @@ int tick(Stepper* S, hipStream_t s) {
   return 0;
 }
 
+
+// ---- the two-lane driver (round 4) ------------------------------------------------------------------------------------
+// What the three-stream pipeline above costs at 8 ranks (profiles/r04_halo_*.md): the exchange chain
+// pack -> RCCL -> unpack -> A tiles is the critical path of a stage (the RCCL kernel alone takes ~50 us beside the tile
+// kernels), and the host needs ~55 us to enqueue a stage (13 HIP calls + the RCCL group) that the GPU finishes in ~50.
+// This driver shortens both:
+//   * GHOST WINDOW (plain 2D / tile plans): the A tiles read their ghosts straight from the receive buffer of the
+//     exchange, in its wire format, and write the elements a peer mirrors into the send buffer in their RK epilogue
+//     (T8gpuPlainPlan::ghost_buf / send_map, fused_common.hpp). No pack kernel (except for the first stage of a call, whose
+//     source state comes from outside) and no unpack kernel: the chain is RCCL -> A tiles.
+//   * TWO LANES, each depending only on the OTHER lane's PREVIOUS stage:
+//       deep lane (caller's stream)  : [A_(g-1)] -> I_g          I = all interior tiles [0, n_interior): one launch
+//       comm lane                    : RCCL_g -> [I_(g-1)] -> A_g
+//     I_g reads what I- and A-tiles of stage g-1 wrote; A_g reads the ghosts of stage g and what A- and I-tiles of stage
+//     g-1 wrote; RCCL_g sends what A_(g-1) put into the send buffer. Both waits refer to work that ended most of a stage
+//     earlier (the chain RCCL + A, ~35 us, is shorter than I, ~45 us, beside it), so neither lane ever stalls on the
+//     other and the long launches run back to back. With the three-stream pipeline the deep tiles of stage g + 1 waited
+//     for B_g, which sat behind the whole exchange chain, across queues: ~10 us of idle GPU per stage.
+//     The RCCL kernel needs 264 VGPRs per lane (rcclGenericKernel<1, false> of RCCL 2.26.6 for gfx950): beside tile kernels
+//     that hold 3 x 160 of a SIMD's 512 it is not dispatched before the tile launch has handed out its last workgroup.
+//     Here it is queued a whole stage ahead of its deadline and slips in at the drain between two interior launches.
+//     (T8GPU_STEPPER_CLASSES=3 keeps the deep / near-boundary split: C_g on the deep lane behind [B_(g-1)], B_g on the comm
+//     lane behind A_g and [C_(g-1)].)
+//   * The comm lane is enqueued by a HOST THREAD of its own while the caller's thread enqueues the deep lane; the threads
+//     meet through two counters (a wait on stage g's event may only be issued once the other thread has recorded it).
+// Plans the ghost window does not cover (Subgrid blocks, 3D patch tiles) run the same two lanes with the pack / unpack
+// kernels around the group.
+template <class T>
+int exchange_wire(const T8gpuHalo& h, const int32_t* peers, const int32_t* send_off, const int32_t* recv_off, hipStream_t s) {
+#ifndef T8GPU_EXP_NO_RCCL
+  HostTimer   ht(1);
+  T*          sb    = static_cast<T*>(h.sendbuf);
+  T*          rb    = static_cast<T*>(h.recvbuf);
+  const int   cells = h.cells_per_element < 1 ? 1 : h.cells_per_element;
+  ncclComm_t  comm  = static_cast<ncclComm_t>(h.comm);
+  T8_TRY(nccl_code(ncclGroupStart()));
+  for (int j = 0; j < h.n_peers; j++) {
+    const size_t w  = 5 * static_cast<size_t>(cells);   // values per element on the wire
+    const size_t rc = w * static_cast<size_t>(recv_off[j + 1] - recv_off[j]);
+    const size_t sc = w * static_cast<size_t>(send_off[j + 1] - send_off[j]);
+    if (rc) T8_TRY(nccl_code(ncclRecv(rb + w * static_cast<size_t>(recv_off[j]), rc, nccl_type<T>(), peers[j], comm, s)));
+    if (sc) T8_TRY(nccl_code(ncclSend(sb + w * static_cast<size_t>(send_off[j]), sc, nccl_type<T>(), peers[j], comm, s)));
+  }
+  T8_TRY(nccl_code(ncclGroupEnd()));
+#else
+  (void)h; (void)peers; (void)send_off; (void)recv_off; (void)s;
+#endif
+  return 0;
+}
+
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#endif
+}
+
+int lane_tick(Stepper* S, Stepper::Lane& L) {
+  if (!S->timing || !S->sample) return 0;
+  if (L.used == L.pool.size()) {
+    hipEvent_t e;
+    T8_HIP_TRY(hipEventCreate(&e));
+    L.pool.push_back(e);
+  }
+  T8_HIP_TRY(hipEventRecord(L.pool[L.used++], L.stream));
+  return 0;
+}
+
+// wait until the other lane's host thread has RECORDED stage g (only then may a wait on that event be issued)
+inline bool lane_wait_recorded(Stepper* S, Stepper::Lane& other, long g) {
+  while (other.recorded.load(std::memory_order_acquire) <= g) {
+    if (S->lane_abort.load(std::memory_order_relaxed)) return false;
+    cpu_relax();
+  }
+  return true;
+}
+
+void worker_main(Stepper* S) {
+  (void)hipSetDevice(S->device);
+  std::unique_lock<std::mutex> lk(S->mu);
+  for (;;) {
+    // spin briefly for the next call (a step loop calls again within microseconds), then sleep
+    lk.unlock();
+    const auto t0 = std::chrono::steady_clock::now();
+    while (S->job_state.load(std::memory_order_acquire) != 1 &&
+           std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 300.0)
+      cpu_relax();
+    lk.lock();
+    S->cv.wait(lk, [&] { return S->job_state.load(std::memory_order_acquire) == 1 || S->worker_exit; });
+    if (S->worker_exit) return;
+    std::function<int()> job = std::move(S->job);
+    lk.unlock();
+    const int rc = job();
+    lk.lock();
+    S->job_rc = rc;
+    S->job_state.store(2, std::memory_order_release);
+  }
+}
+
+template <class T, class V>
+int iterate_lanes(Stepper* S, int kind, T* planes, size_t stride, const T* vol, int prev, int next, T dt, T* speed, int n_steps,
+                  hipStream_t s) {
+  if (n_steps <= 0) return 0;
+  const auto host_t0 = std::chrono::steady_clock::now();
+  const int  nt = S->subgrid ? S->splan.num_elements : S->plan.ntiles;
+  const int  ni = S->subgrid ? S->splan.n_interior_blocks : S->plan.n_interior_tiles;
+  const int  ndeep = S->subgrid ? S->splan.n_deep_blocks : S->plan.n_deep_tiles;
+  // T8GPU_STEPPER_CLASSES=3 (measurements): the deep / near-boundary split of the interior tiles, B_g behind A_g on the comm
+  // lane. Default: the interior tiles [0, ni) are ONE launch per stage on the deep lane.
+  static const bool three = std::getenv("T8GPU_STEPPER_CLASSES") && std::getenv("T8GPU_STEPPER_CLASSES")[0] == '3';
+  const int  nd = three ? ((ndeep > 0 && ndeep <= ni) ? ndeep : 0) : ni;
+  const int  G  = 3 * n_steps;
+  t8gpu_hip::Range whole("t8gpu.iterate_steps (exchange -> ghost-reading tiles || interior tiles, two lanes)");
+  Stepper::Lane& DL = S->deep_lane;
+  Stepper::Lane& XL = S->comm_lane;
+  DL.stream = S->deep_stream ? S->deep_stream : s;
+  XL.stream = S->comm_stream;
+  DL.recorded.store(0, std::memory_order_relaxed);
+  XL.recorded.store(0, std::memory_order_relaxed);
+  S->lane_abort.store(false, std::memory_order_relaxed);
+  const int timing = S->timing;
+  if (timing > 0) S->stages_timed += 3 * ((n_steps + timing - 1) / timing);
+
+  // entry: the lanes see everything the caller queued on s
+  T8_HIP_TRY(hipEventRecord(S->ev_state, s));
+  T8_HIP_TRY(hipStreamWaitEvent(XL.stream, S->ev_state, 0));
+  if (DL.stream != s) T8_HIP_TRY(hipStreamWaitEvent(DL.stream, S->ev_state, 0));
+
+  struct StageArgs {
+    int k;
+    V   pv, sv, ov;
+    T*  stage_speed;
+  };
+  auto stage_args = [=](int g) {
+    StageArgs a;
+    a.k          = g % 3;
+    const int pr = (g / 3) % 2 == 0 ? prev : next, nx = (g / 3) % 2 == 0 ? next : prev;
+    const int src = a.k == 0 ? pr : a.k, dst = a.k == 2 ? nx : a.k + 1;   // Step1 = 1, Step2 = 2 (solver.h:24-31)
+    a.pv = step_vars<V>(planes, stride, pr);
+    a.sv = step_vars<V>(planes, stride, src);
+    a.ov = step_vars<V>(planes, stride, dst);
+    a.stage_speed = a.k == 2 ? speed : nullptr;   // (speed estimates once per step: see iterate())
+    return a;
+  };
+  auto launch = [=](Stepper::Lane& L, const T8gpuPlainPlan* plan, const StageArgs& a, int b, int n, bool sample) -> int {
+    if (n <= 0) return 0;
+    HostTimer ht(0);
+    if (sample) T8_TRY(lane_tick(S, L));
+    if constexpr (sizeof(T) == 4) {
+      if (S->subgrid)
+        T8_TRY(t8gpu_hip_subgrid_fused_stage_f32(kind, a.k + 1, &S->splan, b, n, a.pv, a.sv, a.ov, vol, dt, L.stream));
+      else
+        T8_TRY(t8gpu_hip_plain_fused_stage_f32(kind, a.k + 1, plan, b, n, a.pv, a.sv, a.ov, vol, dt, a.stage_speed, L.stream));
+    } else {
+      if (S->subgrid)
+        T8_TRY(t8gpu_hip_subgrid_fused_stage_f64(kind, a.k + 1, &S->splan, b, n, a.pv, a.sv, a.ov, vol, dt, L.stream));
+      else
+        T8_TRY(t8gpu_hip_plain_fused_stage_f64(kind, a.k + 1, plan, b, n, a.pv, a.sv, a.ov, vol, dt, a.stage_speed, L.stream));
+    }
+    if (sample) T8_TRY(lane_tick(S, L));
+    return 0;
+  };
+  // (S->sample is read by lane_tick: both threads sample the same steps, so it is set once here, "on", and the per-stage
+  //  decision is the `sample` argument)
+  S->sample = true;
+
+  // ---- comm lane, stage g: RCCL_g -> A_g -> [C_(g-1)] -> B_g --------------------------------------------------------------
+  auto comm_stage = [=, &DL, &XL](int g) -> int {
+    const T8gpuHalo& h      = S->halo;
+    const int        cells  = h.cells_per_element < 1 ? 1 : h.cells_per_element;
+    const StageArgs  a      = stage_args(g);
+    const bool       sample = timing > 0 && (g / 3) % timing == 0;
+    if (!S->zero_copy || g == 0) {   // (ghost window: the A tiles of stage g-1 have filled the send buffer)
+      HostTimer ht(0);
+      if constexpr (sizeof(T) == 4)
+        T8_TRY(t8gpu_hip_halo_pack_f32(h.n_send, cells, h.send_idx, a.sv, static_cast<T*>(h.sendbuf), XL.stream));
+      else
+        T8_TRY(t8gpu_hip_halo_pack_f64(h.n_send, cells, h.send_idx, a.sv, static_cast<T*>(h.sendbuf), XL.stream));
+    }
+    T8_TRY(exchange_wire<T>(h, S->peers.data(), S->send_off.data(), S->recv_off.data(), XL.stream));
+    if (!S->zero_copy) {
+      HostTimer ht(0);
+      if constexpr (sizeof(T) == 4)
+        T8_TRY(t8gpu_hip_halo_unpack_f32(h.num_ghosts, h.num_elements, cells, static_cast<const T*>(h.recvbuf), a.sv, XL.stream));
+      else
+        T8_TRY(t8gpu_hip_halo_unpack_f64(h.num_ghosts, h.num_elements, cells, static_cast<const T*>(h.recvbuf), a.sv, XL.stream));
+    }
+    auto wait_deep = [&]() -> int {   // the deep lane's stage g-1
+      if (g == 0 || nd == 0) return 0;
+      if (!lane_wait_recorded(S, DL, g - 1)) return 0;
+      HostTimer ht(3);
+      T8_HIP_TRY(hipStreamWaitEvent(XL.stream, DL.ring[(g - 1) % Stepper::kRing], 0));
+      return 0;
+    };
+    if (nd == ni) T8_TRY(wait_deep());                                                   // A_g <- interior_(g-1)
+    T8_TRY(launch(XL, S->zero_copy ? &S->plan_a : &S->plan, a, ni, nt - ni, sample));   // A_g
+    if (nd < ni) {
+      T8_TRY(wait_deep());                                                               // B_g <- C_(g-1)
+      T8_TRY(launch(XL, &S->plan, a, nd, ni - nd, sample));                              // B_g
+    }
+    {
+      HostTimer ht(2);
+      T8_HIP_TRY(hipEventRecord(XL.ring[g % Stepper::kRing], XL.stream));
+    }
+    XL.recorded.store(g + 1, std::memory_order_release);
+    return 0;
+  };
+  // ---- deep lane, stage g: [B_(g-1)] -> C_g --------------------------------------------------------------------------------
+  auto deep_stage = [=, &DL, &XL](int g) -> int {
+    const StageArgs a      = stage_args(g);
+    const bool      sample = timing > 0 && (g / 3) % timing == 0;
+    if (nd > 0) {
+      if (g > 0) {
+        if (!lane_wait_recorded(S, XL, g - 1)) return 0;
+        HostTimer ht(3);
+        T8_HIP_TRY(hipStreamWaitEvent(DL.stream, XL.ring[(g - 1) % Stepper::kRing], 0));
+      }
+      T8_TRY(launch(DL, &S->plan, a, 0, nd, sample));                                    // C_g
+      HostTimer ht(2);
+      T8_HIP_TRY(hipEventRecord(DL.ring[g % Stepper::kRing], DL.stream));
+    }
+    DL.recorded.store(g + 1, std::memory_order_release);
+    return 0;
+  };
+  // (a lane that fails must not leave the other one's host thread waiting for its records)
+  auto run_lane = [S, G](const std::function<int(int)>& stage) -> int {
+    for (int g = 0; g < G; g++) {
+      const int rc = stage(g);
+      if (rc != 0) {
+        S->lane_abort.store(true, std::memory_order_relaxed);
+        return rc;
+      }
+      if (S->lane_abort.load(std::memory_order_relaxed)) return 0;
+    }
+    return 0;
+  };
+
+  int rc_comm = 0, rc_deep = 0;
+  if (S->threads) {
+    if (!S->worker.joinable()) {
+      (void)hipGetDevice(&S->device);
+      S->worker = std::thread(worker_main, S);
+    }
+    {
+      std::lock_guard<std::mutex> lk(S->mu);
+      S->job = [&]() { return run_lane(comm_stage); };
+      S->job_state.store(1, std::memory_order_release);
+    }
+    S->cv.notify_one();
+    rc_deep = run_lane(deep_stage);
+    while (S->job_state.load(std::memory_order_acquire) != 2) cpu_relax();
+    {
+      std::lock_guard<std::mutex> lk(S->mu);
+      rc_comm = S->job_rc;
+      S->job_state.store(0, std::memory_order_release);
+    }
+  } else {
+    // one host thread: stage by stage, the deep lane first (every wait for a record is then satisfied when it is reached)
+    for (int g = 0; g < G && rc_deep == 0 && rc_comm == 0; g++) {
+      rc_deep = deep_stage(g);
+      if (rc_deep == 0) rc_comm = comm_stage(g);
+    }
+  }
+  // exit: everything is ordered on s again
+  T8_HIP_TRY(hipStreamWaitEvent(s, XL.ring[(G - 1) % Stepper::kRing], 0));
+  if (DL.stream != s && nd > 0) T8_HIP_TRY(hipStreamWaitEvent(s, DL.ring[(G - 1) % Stepper::kRing], 0));
+  S->host_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - host_t0).count();
+  S->host_steps += n_steps;
+  return rc_deep != 0 ? rc_deep : rc_comm;
+}
+
 // n_steps SSP-RK3 steps; (prev, next) are the roles of the FIRST step, they swap from step to step
 // (solver.cu:76). Multi-rank pipeline, per stage g (tile classes of tile_plan.cpp: C = deep interior,
 // B = interior tiles that read an element owned by an A tile, A = tiles that read ghost slots):
@@ -179,6 +510,11 @@ int iterate(Stepper* S, int kind, T* planes, size_t stride, const T* vol, int pr
   const int  ndeep = S->subgrid ? S->splan.n_deep_blocks : S->plan.n_deep_tiles;
   const int  nd = (ndeep > 0 && ndeep <= ni) ? ndeep : 0;
   const bool comm = S->has_halo && S->halo.n_peers > 0;
+  // several ranks, direct enqueue: the two-lane driver above. This function keeps the single-rank loop, and the three-stream
+  // pipeline for a hipGraph capture (whose fork / join shape the capture rules of this stack dictate) and for A/B
+  // measurements (T8GPU_STEPPER=legacy).
+  static const bool legacy = std::getenv("T8GPU_STEPPER") && std::strcmp(std::getenv("T8GPU_STEPPER"), "legacy") == 0;
+  if (comm && !S->capturing && !legacy) return iterate_lanes<T, V>(S, kind, planes, stride, vol, prev, next, dt, speed, n_steps, s);
   t8gpu_hip::Range whole(comm ? "t8gpu.iterate_steps (exchange + 3 tile classes)" : "t8gpu.iterate_steps");
   static const char* const stage_name[3] = {"t8gpu.rk_stage1", "t8gpu.rk_stage2", "t8gpu.rk_stage3"};
   hipEvent_t last_ghost = nullptr, last_interior = nullptr;
@@ -196,6 +532,7 @@ int iterate(Stepper* S, int kind, T* planes, size_t stride, const T* vol, int pr
     T* const stage_speed = k == 2 ? speed : nullptr;
     auto launch = [&](int b, int n, hipStream_t on) -> int {
       if (n <= 0) return 0;
+      HostTimer ht(0);
       T8_TRY(tick(S, on));
       if constexpr (sizeof(T) == 4) {
         if (S->subgrid)
@@ -257,18 +594,19 @@ int iterate(Stepper* S, int kind, T* planes, size_t stride, const T* vol, int pr
       T8_HIP_TRY(hipStreamWaitEvent(S->near_stream, join, 0));
       T8_HIP_TRY(hipStreamWaitEvent(S->comm_stream, join, 0));
     } else if (g > 0) {
+      HostTimer ht(3);
       T8_HIP_TRY(hipStreamWaitEvent(sb, deep_p, 0));                       // B_g <- C_(g-1)
       T8_HIP_TRY(hipStreamWaitEvent(sb, ghost_p, 0));                      // B_g <- A_(g-1)
       T8_HIP_TRY(hipStreamWaitEvent(sc, inter_p, 0));                      // C_g <- B_(g-1)
     }
     T8_TRY(launch(0, nd, sc));                                             // C_g
-    T8_HIP_TRY(hipEventRecord(deep_c, sc));
+    { HostTimer ht(2); T8_HIP_TRY(hipEventRecord(deep_c, sc)); }
     T8_TRY((exchange<T, V>(S->halo, S->peers.data(), S->send_off.data(), S->recv_off.data(), sv, sx)));
-    if (g > 0 && !S->capturing) T8_HIP_TRY(hipStreamWaitEvent(sx, inter_p, 0));               // A_g <- B_(g-1)
+    if (g > 0 && !S->capturing) { HostTimer ht(3); T8_HIP_TRY(hipStreamWaitEvent(sx, inter_p, 0)); }               // A_g <- B_(g-1)
     T8_TRY(launch(ni, nt - ni, sx));                                       // A_g
-    T8_HIP_TRY(hipEventRecord(ghost_c, sx));
+    { HostTimer ht(2); T8_HIP_TRY(hipEventRecord(ghost_c, sx)); }
     T8_TRY(launch(nd, ni - nd, sb));                                       // B_g
-    T8_HIP_TRY(hipEventRecord(inter_c, sb));
+    { HostTimer ht(2); T8_HIP_TRY(hipEventRecord(inter_c, sb)); }
     last_ghost    = swap ? deep_c : ghost_c;   // (what the exit below joins: the two streams that are not s)
     last_interior = inter_c;
   }
@@ -288,10 +626,12 @@ template <class T, class V>
 int iterate_graph(Stepper* S, int kind, T* planes, size_t stride, const T* vol, int prev, int next, T dt, T* speed, int n_steps,
                   hipStream_t s) {
   if (!S->graph_mode || S->timing > 0 || n_steps <= 0) return iterate<T, V>(S, kind, planes, stride, vol, prev, next, dt, speed, n_steps, s);
-  // Multi-rank stages have an RCCL group in the middle. It is captured with the rest (on the capture's origin stream: see
-  // iterate()); T8GPU_GRAPH_RCCL=0 keeps the direct enqueue for steppers with a halo.
-  static const bool no_rccl_capture = std::getenv("T8GPU_GRAPH_RCCL") && std::getenv("T8GPU_GRAPH_RCCL")[0] == '0';
-  if (S->has_halo && S->halo.n_peers > 0 && no_rccl_capture) return iterate<T, V>(S, kind, planes, stride, vol, prev, next, dt, speed, n_steps, s);
+  // Multi-rank stages have an RCCL group in the middle. Capturing it is OPT-IN (T8GPU_GRAPH_RCCL=1): a replayed RCCL group
+  // has only ever run on one GPU exchanging with itself (tests/test_gpu_graph.py), never across xGMI, the capture has to
+  // route every dependency through the origin stream (see iterate()), and hipGraphLaunch costs this stack more host time
+  // than the two-lane direct enqueue (profiles/r04_halo_overhead.md). By default a stepper with peers enqueues directly.
+  static const bool rccl_capture = std::getenv("T8GPU_GRAPH_RCCL") && std::getenv("T8GPU_GRAPH_RCCL")[0] == '1';
+  if (S->has_halo && S->halo.n_peers > 0 && !rccl_capture) return iterate<T, V>(S, kind, planes, stride, vol, prev, next, dt, speed, n_steps, s);
   struct Key {
     int kind, prev, next, n_steps, tsize, subgrid;
     const void *planes, *vol, *speed;
@@ -395,6 +735,15 @@ int t8gpu_hip_comm_unique_id(char* id128) {
 }
 
 int t8gpu_hip_comm_create(const char* id128, int rank, int nranks, void** comm) {
+  {   // header / runtime skew (t8gpu_hip_runtime_versions): same major version, at least 2.7
+    int v[4];
+    (void)t8gpu_hip_runtime_versions(v);
+    if (v[1] < 20700 || v[1] / 10000 != NCCL_VERSION_CODE / 10000 || v[3] / 10000000 != HIP_VERSION / 10000000) {
+      std::fprintf(stderr, "[t8gpu] RCCL %d / HIP %d at run time do not match the headers this library was built with (RCCL %d, HIP %d)\n",
+                   v[1], v[3], v[0], v[2]);
+      return static_cast<int>(hipErrorNotSupported);
+    }
+  }
   ncclUniqueId id;
   std::memcpy(&id, id128, 128);
   ncclComm_t c = nullptr;
@@ -445,7 +794,72 @@ static int stepper_halo_setup(Stepper* S, const T8gpuHalo* halo) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_interior, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_deep, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&S->near_stream, hipStreamNonBlocking);
+    for (int i = 0; i < Stepper::kRing && e == hipSuccess; i++) {
+      e = hipEventCreateWithFlags(&S->deep_lane.ring[i], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&S->comm_lane.ring[i], hipEventDisableTiming);
+    }
     if (e != hipSuccess) return static_cast<int>(e);
+    const char* th = std::getenv("T8GPU_STEPPER_THREADS");
+    S->threads     = !(th && th[0] == '0');
+    // T8GPU_COMM_CUS=n (measurements): the deep tiles run on a stream of their own whose CU mask leaves n compute units to
+    // the comm lane (the RCCL kernel is a few workgroups that crawl when they share their CU with tile waves)
+    if (const char* cus = std::getenv("T8GPU_COMM_CUS")) {
+      const int       n = std::atoi(cus);
+      int             dev = 0;
+      hipDeviceProp_t prop;
+      if (n > 0 && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && n < prop.multiProcessorCount) {
+        const int             total = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((total + 31) / 32, 0u);
+        for (int c = 0; c < total - n; c++) mask[c / 32] |= 1u << (c % 32);
+        e = hipExtStreamCreateWithCUMask(&S->deep_stream, static_cast<uint32_t>(mask.size()), mask.data());
+        if (e != hipSuccess) return static_cast<int>(e);
+      }
+    }
+    // the ghost window (t8gpu_hip.h): plain elements through the tile / 2D patch kernels
+    const char* gw = std::getenv("T8GPU_GHOST_WINDOW");
+    if (!S->subgrid && halo->cells_per_element <= 1 && S->plan.patch_dim != 3 && halo->n_send > 0 && halo->num_elements > 0 &&
+        halo->sendbuf && halo->recvbuf && !(gw && gw[0] == '0')) {
+      // send slots per owned element, from the rank's send list: -1 none, t >= 0 one slot, -(2 + i) a run of send_list
+      const int            N = halo->num_elements, ns = halo->n_send;
+      std::vector<int32_t> idx(ns), map(N, -1), cnt(N, 0), list;
+      e = hipMemcpy(idx.data(), halo->send_idx, sizeof(int32_t) * ns, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) return static_cast<int>(e);
+      for (int t = 0; t < ns; t++) {
+        if (idx[t] < 0 || idx[t] >= N) return static_cast<int>(hipErrorInvalidValue);
+        cnt[idx[t]]++;
+      }
+      std::vector<int32_t> first(N, -1);
+      for (int t = 0; t < ns; t++) {
+        const int el = idx[t];
+        if (cnt[el] == 1) {
+          map[el] = t;
+        } else {
+          if (first[el] < 0) {   // reserve the element's run
+            first[el] = static_cast<int32_t>(list.size());
+            list.resize(list.size() + cnt[el], -1);
+            map[el] = -(2 + first[el]);
+          }
+          int32_t* run = list.data() + first[el];
+          int      k   = 0;
+          while (run[k] != -1) k++;
+          run[k] = (k == cnt[el] - 1) ? static_cast<int32_t>(static_cast<uint32_t>(t) | 0x80000000u) : t;
+        }
+      }
+      e = hipMalloc(&S->d_send_map, sizeof(int32_t) * N);
+      if (e == hipSuccess) e = hipMemcpy(S->d_send_map, map.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice);
+      if (e == hipSuccess && !list.empty()) {
+        e = hipMalloc(&S->d_send_list, sizeof(int32_t) * list.size());
+        if (e == hipSuccess) e = hipMemcpy(S->d_send_list, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice);
+      }
+      if (e != hipSuccess) return static_cast<int>(e);
+      S->plan_a           = S->plan;
+      S->plan_a.ghost_buf = halo->recvbuf;
+      S->plan_a.send_map  = static_cast<const int32_t*>(S->d_send_map);
+      S->plan_a.send_list = static_cast<const int32_t*>(S->d_send_list);
+      S->plan_a.send_buf  = halo->sendbuf;
+      S->plan_a.n_owned   = N;
+      S->zero_copy        = true;
+    }
   }
   return 0;
 }
@@ -483,6 +897,22 @@ int t8gpu_hip_subgrid_stepper_create(const T8gpuSubgridPlan* plan, const T8gpuHa
 int t8gpu_hip_plain_stepper_destroy(void* h) {
   Stepper* S = static_cast<Stepper*>(h);
   if (!S) return 0;
+  if (S->worker.joinable()) {
+    {
+      std::lock_guard<std::mutex> lk(S->mu);
+      S->worker_exit = true;
+    }
+    S->cv.notify_one();
+    S->worker.join();
+  }
+  for (Stepper::Lane* L : {&S->deep_lane, &S->comm_lane}) {
+    for (hipEvent_t e : L->pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : L->ring)
+      if (e) (void)hipEventDestroy(e);
+  }
+  if (S->deep_stream) (void)hipStreamDestroy(S->deep_stream);
+  if (S->d_send_map) (void)hipFree(S->d_send_map);
+  if (S->d_send_list) (void)hipFree(S->d_send_list);
   for (hipEvent_t e : S->pool) (void)hipEventDestroy(e);
   if (S->ev_state) (void)hipEventDestroy(S->ev_state);
   if (S->ev_ghost) (void)hipEventDestroy(S->ev_ghost);
@@ -552,12 +982,58 @@ int t8gpu_hip_plain_stepper_graph(void* h, int enable, int* counts) {
   return 0;
 }
 
+// Diagnostics (T8GPU_STEPPER_PROFILE=1 in the environment, else all zeros): host time the step drivers of this process spent
+// in {kernel launches, RCCL groups, event records, stream waits} since the last reset. ns4 / calls4 may be NULL.
+int t8gpu_hip_stepper_host_profile(int reset, double* ns4, long long* calls4) {
+  for (int c = 0; c < 4; c++) {
+    if (ns4) ns4[c] = host_profile().ns[c];
+    if (calls4) calls4[c] = host_profile().calls[c];
+    if (reset) {
+      host_profile().ns[c]    = 0;
+      host_profile().calls[c] = 0;
+    }
+  }
+  return host_profile().on ? 1 : 0;
+}
+
+// Host time the step driver spent enqueueing (wall time of the multi-rank iterate calls; both host threads of the two-lane
+// driver overlap inside it) and the steps that covers, since the stepper was created or last reset. 0 / 0 for single-rank
+// steppers (their enqueue is a handful of launches).
+int t8gpu_hip_plain_stepper_host_time(void* h, int reset, double* total_ms, long long* steps) {
+  Stepper* S = static_cast<Stepper*>(h);
+  if (!S) return static_cast<int>(hipErrorInvalidValue);
+  if (total_ms) *total_ms = S->host_ns * 1e-6;
+  if (steps) *steps = S->host_steps;
+  if (reset) {
+    S->host_ns    = 0;
+    S->host_steps = 0;
+  }
+  return 0;
+}
+
+// {RCCL version this library was compiled against (NCCL_VERSION_CODE), RCCL version of the library the process bound,
+//  HIP version compiled against (HIP_VERSION), HIP runtime version}. The process may bind another build than the headers
+// came from (here: the torch wheel's librccl / libamdhip64 against /opt/rocm's headers): the entry points this library
+// uses -- ncclGetUniqueId, ncclCommInitRank, ncclGroupStart / End, ncclSend, ncclRecv, ncclCommDestroy / Abort, all with
+// their NCCL 2.7 signatures, no ncclConfig_t -- exist unchanged in every 2.x since 2.7. t8gpu_hip_comm_create refuses a
+// runtime with another major version or older than 2.7 (hipErrorNotSupported).
+int t8gpu_hip_runtime_versions(int out4[4]) {
+  if (!out4) return static_cast<int>(hipErrorInvalidValue);
+  int nv = 0, hv = 0;
+  out4[0] = NCCL_VERSION_CODE;
+  out4[1] = ncclGetVersion(&nv) == ncclSuccess ? nv : -1;
+  out4[2] = HIP_VERSION;
+  out4[3] = hipRuntimeGetVersion(&hv) == hipSuccess ? hv : -1;
+  return 0;
+}
+
 int t8gpu_hip_plain_stepper_timing(void* h, int enable) {
   Stepper* S = static_cast<Stepper*>(h);
   if (!S) return static_cast<int>(hipErrorInvalidValue);
   S->timing = enable < 0 ? 0 : enable;
   S->stages_timed = 0;
   S->used   = 0;
+  S->deep_lane.used = S->comm_lane.used = 0;
   return 0;
 }
 
@@ -566,13 +1042,21 @@ int t8gpu_hip_plain_stepper_elapsed(void* h, double* total_ms, int* launches) {
   Stepper* S = static_cast<Stepper*>(h);
   if (!S || !total_ms || !launches) return static_cast<int>(hipErrorInvalidValue);
   double sum = 0;
-  for (size_t i = 0; i + 1 < S->used; i += 2) {
-    float ms = 0;
-    T8_HIP_TRY(hipEventElapsedTime(&ms, S->pool[i], S->pool[i + 1]));
-    sum += ms;
-  }
+  int    n   = 0;
+  auto   add = [&](const std::vector<hipEvent_t>& pool, size_t used) -> int {
+    for (size_t i = 0; i + 1 < used; i += 2) {
+      float ms = 0;
+      T8_HIP_TRY(hipEventElapsedTime(&ms, pool[i], pool[i + 1]));
+      sum += ms;
+      n++;
+    }
+    return 0;
+  };
+  T8_TRY(add(S->pool, S->used));
+  T8_TRY(add(S->deep_lane.pool, S->deep_lane.used));   // (the two-lane driver's launches)
+  T8_TRY(add(S->comm_lane.pool, S->comm_lane.used));
   *total_ms = sum;
-  *launches = static_cast<int>(S->used / 2);
+  *launches = n;
   return 0;
 }
 

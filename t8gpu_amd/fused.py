@@ -14,7 +14,10 @@ class T8gpuPlainPlan(C.Structure):
         ("max_faces", C.c_int32), ("ell_width", C.c_int32), ("ell", C.c_void_p), ("geo_idx", C.c_void_p),
         ("geo_table", C.c_void_p), ("n_geo", C.c_int32), ("max_slots", C.c_int32), ("n_deep_tiles", C.c_int32),
         ("n_slots_addressed", C.c_int32), ("tile_desc", C.c_void_p), ("n_patch_tiles", C.c_int32 * 3), ("patch_dim", C.c_int32),
-                ("n_irregular_tiles", C.c_int32 * 3)]
+                ("n_irregular_tiles", C.c_int32 * 3),
+        # ABI 7: the ghost window, attached by the multi-rank step driver only (stepper.hip); NULL / 0 here
+        ("ghost_buf", C.c_void_p), ("send_map", C.c_void_p), ("send_list", C.c_void_p), ("send_buf", C.c_void_p),
+        ("n_owned", C.c_int32), ("reserved7", C.c_int32)]
 
 
 class PlainPlan:

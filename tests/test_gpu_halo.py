@@ -92,6 +92,87 @@ def k_way_plain(mesh, world, mode, dtype, small_tiles):
         assert np.array_equal(full, ref.state().cpu().numpy())
 
 
+def send_map_of(send_idx, n_owned):
+    """T8gpuPlainPlan.send_map / send_list (include/t8gpu_hip.h, "ghost window") from a rank's send list."""
+    smap = np.full(max(1, n_owned), -1, np.int32)
+    slots = {}
+    for t, e in enumerate(send_idx.tolist()):
+        slots.setdefault(e, []).append(t)
+    lst = []
+    for e, ts in slots.items():
+        if len(ts) == 1:
+            smap[e] = ts[0]
+        else:
+            smap[e] = -(2 + len(lst))
+            lst += ts[:-1] + [ts[-1] - 2 ** 31]
+    return smap, np.asarray(lst if lst else [0], np.int64).astype(np.int32)
+
+
+@pytest.mark.parametrize("world", [2, 5, 7])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("tiles", ["small", "patches", "generic"])
+def test_ghost_window_k_way_partition_equals_single_rank(world, dtype, tiles):
+    """The ghost window of the fused kernels (T8gpuPlainPlan.ghost_buf / send_map: what the multi-rank step driver
+    attaches to the launches of its ghost-reading tiles): the A tiles read their ghosts from the receive buffer in the wire
+    format and write the elements a peer mirrors into the send buffer in their RK epilogue -- no pack kernel after the first
+    stage, no unpack kernel, the mirror slots of the planes stay NaN throughout. All ranks of a k-way partition on one GPU,
+    the transport a loopback copy; bitwise the single-rank run. 5 and 7 ranks: elements with several send slots (send_list)."""
+    import ctypes as C
+    from t8gpu_amd import fused, hip
+    mesh = SynthMesh(2, 4, 7, band=0.06) if tiles == "small" else SynthMesh(2, 5, 9, band=0.08)
+    whole = mesh.partition()
+    st = perturbed_state(whole, 78)
+    ref = PlainSolver(whole, dtype, mode="fused", state=st)
+    parts = [mesh.partition(r, world) for r in range(world)]
+    solvers, halos, windows, keep = [], [], [], []
+    multi = 0
+    for part in parts:
+        gidx = np.concatenate([part.first_global + np.arange(part.N), part.ghost_global])
+        local = st[:, gidx].copy()
+        local[:, part.N:] = np.nan                              # the mirror slots are never filled: nobody may read them
+        opts = dict(tmax=32, fcap=80) if tiles == "small" else (dict(compressed=False) if tiles == "generic" else {})
+        s = PlainSolver(part, dtype, mode="fused", state=local, plan_options=opts)
+        h = HaloExchange(part, dtype, dist=None, overlap=False)
+        smap, slist = send_map_of(part.send_idx, part.N)
+        multi += int((smap < -1).sum())
+        dm, dl = torch.from_numpy(smap).cuda(), torch.from_numpy(slist).cuda()
+        w = fused.T8gpuPlainPlan()
+        C.pointer(w)[0] = s.plan.c                              # a copy of the plan ...
+        w.ghost_buf, w.send_map, w.send_list, w.send_buf, w.n_owned = (h.recvbuf.data_ptr(), dm.data_ptr(), dl.data_ptr(),
+                                                                      h.sendbuf.data_ptr(), part.N)   # ... with the window
+        solvers.append(s); halos.append(h); windows.append(w); keep.append((dm, dl))
+    if tiles == "patches" and world > 2:
+        assert sum(s.plan.host.n_patch_class[2] for s in solvers) > 0      # patch tiles among the ghost-reading ones
+    if world > 2:
+        assert multi > 0                                                    # elements with more than one send slot
+    dt = 0.1 * 2.0 ** -mesh.finest_level
+    mirrors = [s.planes[:20, p.N:p.N + p.G].clone() for s, p in zip(solvers, parts)]
+    for step in range(3):
+        ref.iterate(dt)
+        for s in solvers:
+            s.begin_step()
+        for k in range(3):
+            if step == 0 and k == 0:                                        # the state came from outside: pack once
+                for s, h in zip(solvers, halos):
+                    h._pack(s.step_planes(s.stage_steps(k)[0]))
+            loopback(halos)                                                 # (reads every send buffer before anyone rewrites it)
+            torch.cuda.synchronize()
+            for s, w in zip(solvers, windows):
+                src, dst = s.stage_steps(k)
+                ni, nt = s.plan.host.n_interior, s.plan.host.ntiles
+                args = (s.get_own_variables(s.prev), s.get_own_variables(src), s.get_own_variables(dst), hip.ptr(s.planes[25]),
+                        hip.fscalar(dtype, dt), hip.ptr(s.speed) if k == 2 else None, hip.stream_ptr())
+                hip.call("t8gpu_hip_plain_fused_stage", dtype, s.kind, k + 1, C.byref(s.plan.c), 0, ni, *args)
+                hip.call("t8gpu_hip_plain_fused_stage", dtype, s.kind, k + 1, C.byref(w), ni, nt - ni, *args)
+            torch.cuda.synchronize()
+    full = torch.cat([s.state() for s in solvers], dim=1).cpu().numpy()
+    assert not np.isnan(full).any()
+    assert np.array_equal(full, ref.state().cpu().numpy())
+    for s, part, m in zip(solvers, parts, mirrors):                         # the mirror slots were never written
+        assert torch.allclose(s.planes[:20, part.N:part.N + part.G], m, rtol=0, atol=0, equal_nan=True)
+    assert torch.equal(torch.cat([s.speed[:p.F] for s, p in zip(solvers, parts) if p.F]).isfinite().all(), torch.tensor(True, device="cuda"))
+
+
 def test_pack_unpack_kernels_match_numpy():
     mesh = SynthMesh(2, 4, 6, band=0.06)
     part = mesh.partition(1, 3)
@@ -189,15 +270,22 @@ def test_native_stepper_with_rccl_self_exchange_on_a_symmetric_problem(dtype, ca
     gidx = np.concatenate([np.arange(half.N), half.ghost_global])
     local = st[:, gidx].copy()
     local[:, half.N:] = np.nan                                            # ghosts must arrive through RCCL
-    g = PlainSolver(half, dtype, mode="fused", state=local, plan_options=dict(tmax=min(caps[0], 256), fcap=caps[1]))
+    g = PlainSolver(half, dtype, mode="fused", state=local, plan_options=dict(tmax=min(caps[0], 256), fcap=caps[1]),
+                    capacity=half.N + half.G + 3)                        # (three extra ghost slots: see `fake` below)
     if caps[0] == 4000:                                                   # no class information: the driver must cope
         g.plan.c.n_deep_tiles = 0
     hp = g.plan.host
     print("tiles C / B / A:", hp.n_deep, hp.n_interior - hp.n_deep, hp.ntiles - hp.n_interior)
     comm = native.NativeComm(0, 1, lambda b, src: b)
-    fake = types.SimpleNamespace(N=half.N, G=half.G, cells_per_element=1, peers=np.zeros(1, np.int32), send_off=half.send_off,
-                                 recv_off=half.recv_off, send_idx=half.send_idx)
-    g.use_native_stepper(native.NativeHalo(fake, dtype, comm))
+    # a second message to the same "peer": the first three send elements once more, received into three extra ghost slots
+    # nobody reads -- two messages per peer inside one RCCL group, and elements with two send slots (the driver's send_list)
+    extra = 3
+    fake = types.SimpleNamespace(N=half.N, G=half.G + extra, cells_per_element=1, peers=np.zeros(2, np.int32),
+                                 send_off=np.append(half.send_off, half.send_off[-1] + extra).astype(np.int32),
+                                 recv_off=np.append(half.recv_off, half.recv_off[-1] + extra).astype(np.int32),
+                                 send_idx=np.append(half.send_idx, half.send_idx[:extra]).astype(np.int32))
+    nh = native.NativeHalo(fake, dtype, comm)
+    g.use_native_stepper(nh)
     dt = 0.1 * 2.0 ** -mesh.finest_level
     if caps == (64, 160):
         assert 0 < hp.n_deep < hp.n_interior < hp.ntiles                  # all three tile classes are populated
@@ -211,6 +299,11 @@ def test_native_stepper_with_rccl_self_exchange_on_a_symmetric_problem(dtype, ca
     want, got = ref.state().cpu().numpy(), g.state().cpu().numpy()
     assert np.isfinite(got).all()
     assert rel_err(got, want[:, : half.N]) < (1e-12 if dtype == torch.float64 else 1e-5)
+    # both send slots of the doubled elements carry the same values, and they are the elements' final state
+    sb = nh.sendbuf.view(-1, 5).cpu().numpy()
+    n0 = half.send_idx.size
+    assert np.array_equal(sb[n0:n0 + extra], sb[:extra])
+    assert np.array_equal(sb[:extra], got[:, half.send_idx[:extra]].T)
     g.stepper = None
     comm.destroy()
 
