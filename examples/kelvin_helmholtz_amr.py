@@ -36,9 +36,6 @@ def main():
     ap.add_argument("--vtk", default=None, help="prefix of the .vtu / .pvtu files written at the end (density, energy, momentum)")
     args = ap.parse_args()
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
-    hostmem.keep_heap()      # host arrays of an adapt cycle are reused by the next one (t8gpu_amd/hostmem.py)
-    if os.environ.get("T8GPU_REHEARSAL", "0") != "1":
-        hostmem.use_pinned_uploads()   # ... and uploaded through one pinned staging buffer
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     rehearsal = os.environ.get("T8GPU_REHEARSAL", "0") == "1"
     dist = None
@@ -46,6 +43,10 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(0 if rehearsal else int(os.environ.get("LOCAL_RANK", 0)))
         dist.init_process_group("gloo" if rehearsal else "nccl")
+    # (after set_device: pinned memory creates a context on the current device -- every rank's own GPU, not GPU 0)
+    hostmem.keep_heap()      # host arrays of an adapt cycle are reused by the next one (t8gpu_amd/hostmem.py)
+    if not rehearsal:
+        hostmem.use_pinned_uploads()   # ... and uploaded through one pinned staging buffer
     say = print if rank == 0 else (lambda *a, **k: None)
 
     def adapt(s):

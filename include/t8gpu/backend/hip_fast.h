@@ -140,10 +140,12 @@ namespace t8gpu::hip {
     /// them) and the communicator; iterate_fused then exchanges the ghost layer per stage (csrc/hip/stepper.hip).
     explicit PlainFusedPlan(HostMeshArrays const& m, int ndim = 3, int tmax = 256, int fcap = 512, HostHaloArrays const* halo = nullptr,
                             Communicator const* comm = nullptr) {
-      // (flags 3 | 8: structured patches -- 16 x 16 quadrilateral / 8 x 8 x 4 hexahedral blocks, the irregular 3D ones included -- are cut out of the tiling and run through the patch kernels)
+      // (flags 3 | 8: structured patches -- 16 x 16 quadrilateral / 8 x 8 x 4 hexahedral blocks, the irregular 3D ones included -- are cut out of the tiling and run through the patch kernels.
+      //  The patch kernels address a plane by a 32-bit byte offset: a mesh whose planes reach 4 GiB is planned without patches, every element through the tile kernels -- the launchers refuse patch tiles on such planes)
+      const bool  wide  = (static_cast<unsigned long long>(m.num_local_elements) + static_cast<unsigned long long>(m.num_ghost_elements)) * sizeof(ft) >= (1ull << 32);
       void* h = t8gpu_plan_plain_create_ex(m.num_local_elements, m.num_ghost_elements, m.num_local_faces,
                                            m.num_local_boundary_faces, ndim, m.face_neighbors.data(), m.face_normals.data(),
-                                           m.face_surfaces.data(), tmax, fcap, 3 | 8);
+                                           m.face_surfaces.data(), tmax, fcap, wide ? 0 : (3 | 8));
       if (!h) T8GPU_ABORT("t8gpu_plan_plain_create_ex failed");
       int64_t sz[16];
       t8gpu_plan_plain_sizes(h, sz);

@@ -216,6 +216,10 @@ int t8gpu_hip_plain_fused_stage_f64(int flux_kind, int stage, const T8gpuPlainPl
  * own test, for host code that picks tile caps (t8gpu_amd/fused.py). Only the plan's integer fields and the NULL-ness of
  * tile_desc / ell / geo_idx / geo_table are looked at; no GPU is needed. */
 int t8gpu_hip_plain_persistent_accepts(const T8gpuPlainPlan* plan, int flux_kind, int float_size, int tile_count);
+/* 1 if a launch of this plan's generic tiles reads csr_off / csr_ent (the generic kernel), 0 if it runs the pipelined kernels
+ * (ELL rows + tile descriptors), whose callers need not upload the CSR lists: the launcher's own test, from the plan's
+ * integer fields and the NULL-ness of ell / tile_desc alone; no GPU is needed. */
+int t8gpu_hip_plain_needs_csr(const T8gpuPlainPlan* plan);
 
 /* ---- ghost-layer exchange (device side) ----------------------------------------------------------
  * Replaces the reference's cross-rank pointer sharing (cudaIpc*, t8gpu/memory/shared_device_vector.inl:

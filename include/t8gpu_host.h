@@ -91,7 +91,7 @@ int32_t t8gpu_plan_plain_patch_dim(const void* plan);
  * have bit for bit one volume carries it in its descriptor (flag 0x400; words 1 and 3 then hold the double instead of
  * the implied counts 256 and 64 | 256) and the patch kernels skip the per-element volume load. Returns their number. */
 int32_t t8gpu_plan_plain_patch_volumes(void* plan, const double* volumes);
-/* sizes[16] (12 = max over the generic tiles of own + halo elements, 13 = number of deep-interior tiles, 14 = number of patch tiles, 15 reserved = 0; the maxima 4-6 are over the generic tiles) = {ntiles, n_halo, n_faces, n_csr, max_elems, max_halo, max_faces, n_interior_tiles, N, F,
+/* sizes[16] (12 = max over the generic tiles of own + halo elements, 13 = number of deep-interior tiles, 14 = number of patch tiles, 15 = number of ELL rows (the elements of generic tiles: ell holds sizes[15] * ell_width entries, a tile's first row is word 6 of its tile_desc record); the maxima 4-6 are over the generic tiles) = {ntiles, n_halo, n_faces, n_csr, max_elems, max_halo, max_faces, n_interior_tiles, N, F,
  *              ell_width, n_geo} */
 void t8gpu_plan_plain_sizes(const void* plan, int64_t* sizes);
 void t8gpu_plan_plain_arrays(const void* plan, int32_t* elem_off, int32_t* halo_off, int32_t* face_off,

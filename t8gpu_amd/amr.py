@@ -26,6 +26,9 @@ def _inherited_plan_options(solver):
         opts["fcap_elements"] = getattr(plan, "auto_fcap_elements", None)     # (the mesh size the cap was chosen for)
     if getattr(plan, "auto_irregular", None) is not None:
         opts["irregular"] = plan.auto_irregular
+        # (like the cap, the patch form is decided again once the mesh size has changed by more than a factor two since it was
+        #  chosen: fused.PlainPlan drops both under that rule)
+        opts["fcap_elements"] = getattr(plan, "auto_fcap_elements", None)
     return opts or None
 
 

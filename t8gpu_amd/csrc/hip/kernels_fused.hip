@@ -144,6 +144,15 @@ __global__ __launch_bounds__(256) void k_plain_fused(T8gpuPlainPlan P, int tile_
 namespace t8gpu_hip {
 
 
+// Do the generic tiles of this plan run the pipelined one-tile kernels (ELL rows + tile descriptors: no CSR lists read), or the
+// generic kernel, which walks csr_off / csr_ent? One definition for the launcher below and for t8gpu_hip_plain_needs_csr,
+// which the host asks before it decides what to upload (t8gpu_amd/fused.py used to repeat a part of this test).
+inline bool plain_tiles_pipelined(const T8gpuPlainPlan* plan) {
+  const int slots = plan->max_slots > 0 ? plan->max_slots : plan->max_elems + plan->max_halo;
+  return plan->ell && plan->tile_desc && plan->ell_width >= 8 && plan->ell_width % 8 == 0 && plan->max_elems <= 256 && slots <= 512 &&
+         plan->max_faces <= 1024;
+}
+
 // tiles [tile_begin, tile_begin + tile_count) of tile_order, none of them a patch tile. whole_plan: the caller's launch
 // covers the whole plan (what the persistent kernel is for).
 template <class T, class V>
@@ -154,8 +163,7 @@ int plain_generic_stage(int kind, int stage, const T8gpuPlainPlan* plan, int til
   hipStream_t s  = static_cast<hipStream_t>(stream);
   const dim3  grid(tile_count), block(256);
   const int   slots = plan->max_slots > 0 ? plan->max_slots : plan->max_elems + plan->max_halo;
-  const bool  pipelined = plan->ell && plan->tile_desc && plan->ell_width >= 8 && plan->ell_width % 8 == 0 && plan->max_elems <= 256 &&
-                         slots <= 512 && plan->max_faces <= 1024;
+  const bool  pipelined = plain_tiles_pipelined(plan);
   const bool  four = plan->max_faces > 512;
   // (the generic kernel walks the CSR lists; callers that know their plan stays inside the pipelined kernels' limits need not
   //  upload them -- t8gpu_amd/fused.py does not)
@@ -317,6 +325,7 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
 }  // namespace t8gpu_hip
 
 extern "C" {
+int t8gpu_hip_plain_needs_csr(const T8gpuPlainPlan* plan) { return plan && t8gpu_hip::plain_tiles_pipelined(plan) ? 0 : 1; }
 int t8gpu_hip_plain_fused_stage_f32(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count,
                                     T8gpuVars_f32 prev, T8gpuVars_f32 mid, T8gpuVars_f32 out, const float* volume,
                                     float dt, float* speed, void* stream) {

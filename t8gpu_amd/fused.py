@@ -45,9 +45,10 @@ class PlainPlan:
         # An inherited face cap (amr._inherited_plan_options) was chosen for a mesh of `fcap_elements` elements: which kernel a
         # plan gets depends on its tile count, so a mesh that has since grown or shrunk by more than a factor two decides again
         # (a run that starts from a coarse mesh would otherwise keep the small mesh's 768-face one-tile plan for good).
-        if fcap is not None and fcap_elements and not (fcap_elements // 2 <= part.N <= 2 * fcap_elements):
+        if fcap_elements and not (fcap_elements // 2 <= part.N <= 2 * fcap_elements):
             fcap = None
-        self.auto_fcap_elements = fcap_elements if fcap is not None and fcap_elements else part.N
+            irregular = None          # (an inherited patch form was decided on that mesh too: ADVICE r3)
+        self.auto_fcap_elements = fcap_elements if (fcap is not None or irregular is not None) and fcap_elements else part.N
         if patches is None:
             patches = compressed and os.environ.get("T8GPU_PATCH", "1") != "0"
         self.patches = patches if compressed else False          # True / False, or 2 / 3 for one kind only
@@ -148,7 +149,7 @@ class PlainPlan:
         # (the launcher's own condition, kernels_fused.hip: plain_generic_stage) never runs it: 2 + 4 bytes per incidence
         # less to upload (50 MB at 3 M elements in 3D)
         h = self.host
-        skip_csr = compressed and h.max_elems <= 256 and h.max_slots <= 512 and h.max_faces <= 1024 and h.ell_width % 8 == 0
+        skip_csr = compressed and not self._needs_csr(h)
         for name in HostPlainPlan.FIELDS:
             a = getattr(self.host, name)
             if skip_csr and name in ("csr_off", "csr_ent"):
@@ -185,6 +186,18 @@ class PlainPlan:
         c.patch_dim = self.host.patch_dim
         c.n_slots_addressed = part.N + part.G
         self.c = c
+
+    @staticmethod
+    def _needs_csr(h):
+        """Would the generic tiles of the compressed form of host plan `h` run the generic kernel, which walks the CSR lists?
+        (t8gpu_hip_plain_needs_csr: the launcher's own test.)"""
+        c = T8gpuPlainPlan()
+        one = C.c_void_p(1)                                     # "present": never dereferenced by the query
+        c.tile_desc, c.ell = one, one
+        c.ell_width, c.max_elems, c.max_halo, c.max_faces, c.max_slots = h.ell_width, h.max_elems, h.max_halo, h.max_faces, h.max_slots
+        fn = hip.lib().t8gpu_hip_plain_needs_csr
+        fn.restype = C.c_int
+        return bool(fn(C.byref(c)))
 
     @staticmethod
     def _persistent_accepts(h, dtype, flux_kind=None, n_generic=None):

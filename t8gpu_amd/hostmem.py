@@ -39,9 +39,15 @@ class PinnedUploader:
     def __init__(self, megabytes=256, chunk_megabytes=32):
         import torch
         from . import synth
-        self.cap, self.chunk = int(megabytes) << 20, int(chunk_megabytes) << 20
+        self.cap = int(megabytes) << 20
+        if self.cap <= 0:
+            raise ValueError("PinnedUploader needs a staging buffer of at least 1 MB")
+        # a chunk is staged whole: never larger than the buffer (a 16 MB buffer with the default 32 MB chunk would let
+        # t8gpu_host_parallel_copy write past its end), and rounded like the offsets
+        self.chunk = max(256, min(int(chunk_megabytes) << 20, self.cap) & ~255)
         self.buf = torch.empty(self.cap, dtype=torch.uint8, pin_memory=True)
         self.off = 0
+        self._in_flight = []      # (event) per staged region since the last wrap: a copy may have been queued on ANY stream
         self._copy = synth.lib().t8gpu_host_parallel_copy
         self._copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
         self._copy.restype = None
@@ -63,10 +69,16 @@ class PinnedUploader:
         while done < n:
             take = min(self.chunk, n - done)
             if self.off + take > self.cap:     # the DMA engine may still read what is staged: drain it, start over
-                torch.cuda.current_stream().synchronize()
+                for ev in self._in_flight:     # (every copy since the last wrap, whichever stream it was queued on)
+                    ev.synchronize()
+                self._in_flight = []
                 self.off = 0
+            assert take <= self.cap - self.off
             self._copy(self.buf.data_ptr() + self.off, src + done, take)
             dst[done:done + take].copy_(self.buf[self.off:self.off + take], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()                        # on the stream the copy was queued on
+            self._in_flight.append(ev)
             self.off += (take + 255) & ~255
             done += take
         return out
@@ -75,11 +87,12 @@ class PinnedUploader:
 _uploader = None
 
 
-def use_pinned_uploads(megabytes=256):
-    """From now on solver / plan uploads of this process go through a PinnedUploader (uploader() returns it)."""
+def use_pinned_uploads(megabytes=256, chunk_megabytes=32):
+    """From now on solver / plan uploads of this process go through a PinnedUploader (uploader() returns it). Allocates pinned
+    memory, i.e. creates a context on the CURRENT device: call it after torch.cuda.set_device(LOCAL_RANK)."""
     global _uploader
     if _uploader is None:
-        _uploader = PinnedUploader(megabytes)
+        _uploader = PinnedUploader(megabytes, chunk_megabytes)
     return _uploader
 
 

@@ -27,6 +27,28 @@ def test_pinned_uploader_moves_every_byte():
     assert abs(s - 2.0 * a.sum()) < 1e-6 * a.size
 
 
+def test_pinned_uploader_chunk_never_exceeds_the_buffer_and_wraps_wait_for_every_stream():
+    """A staging buffer smaller than the default chunk (the chunk was not clipped and the staging copy wrote
+    past the pinned buffer), uploads queued on two streams in turn: a wrap waits for the copies of both."""
+    up = hostmem.PinnedUploader(megabytes=1, chunk_megabytes=32)
+    assert up.chunk <= up.cap
+    with pytest.raises(ValueError):
+        hostmem.PinnedUploader(megabytes=0)
+    rng = np.random.default_rng(4)
+    cases = [rng.random(700_000), rng.integers(0, 1 << 30, 1_300_001, dtype=np.int32), rng.random(400_000).astype(np.float32)]
+    side = torch.cuda.Stream()
+    outs = []
+    for i, a in enumerate(cases * 3):
+        if i % 2:
+            with torch.cuda.stream(side):
+                outs.append((a, up.upload(a)))
+        else:
+            outs.append((a, up.upload(a)))
+    torch.cuda.synchronize()
+    for a, t in outs:
+        assert np.array_equal(t.cpu().numpy(), a)
+
+
 def test_solver_through_the_pinned_uploader_matches_the_default_path():
     from _gpu import perturbed_state
     from t8gpu_amd.solver import PlainSolver
