@@ -247,6 +247,10 @@ def main():
             el = float(tt.item())
         rep_s.append(el)
     elapsed = float(np.median(rep_s))
+    host_enqueue = None
+    if stepper is not None and world > 1:
+        hms, hsteps = stepper.host_time()
+        host_enqueue = round(hms / hsteps, 4) if hsteps else None   # (pre-warm, warm-up and timed steps alike)
     if stepper is not None:
         kernel_ms, kernel_launches = stepper.elapsed()
     else:
@@ -302,7 +306,7 @@ def main():
         if stale:
             roof["profile_stale"] = stale
         if kernel_launches != 3 * steps_timed:
-            roof["note"] = ("stage kernel split into deep-interior / near-boundary / ghost-reading tile ranges; avg_launch_ms is "
+            roof["note"] = ("stage kernel split into interior / ghost-reading tile ranges; avg_launch_ms is "
                             "their sum per stage")
         if stride > 1:
             roof["note"] = (roof.get("note", "") + f"; kernel events on {stages_timed} of {3 * args.steps} stages of the timed region").lstrip("; ")
@@ -330,6 +334,18 @@ def main():
             "algorithmic_frac_whole_step": round(value * 1e6 * per_update / world / (HBM_PEAK_GBS * 1e9), 4),
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if world > 1:
+            # what the N > 1 line needs to be read on its own: how the step was driven, what the host paid per
+            # step for it, and which RCCL / HIP builds the process bound against which headers the library was compiled with
+            from t8gpu_amd import native as _native
+            ver = _native.runtime_versions()
+            out["multi_gpu"] = {"driver": ("two lanes (interior tiles || RCCL -> ghost-reading tiles), two host threads, ghost window"
+                                           if stepper is not None else "python-driven stages"),
+                                "host_enqueue_ms_per_step": host_enqueue,
+                                "rccl_version": {"compiled": ver["rccl"][0], "runtime": ver["rccl"][1]},
+                                "hip_version": {"compiled": ver["hip"][0], "runtime": ver["hip"][1]},
+                                "tiles_rank0": {"interior": int(solver.plan.host.n_interior), "ghost_reading": int(solver.plan.host.ntiles - solver.plan.host.n_interior)}
+                                if mode == "fused" and w["kind"] == "plain" else None}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

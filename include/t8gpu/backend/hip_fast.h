@@ -145,7 +145,8 @@ namespace t8gpu::hip {
       const bool  wide  = (static_cast<unsigned long long>(m.num_local_elements) + static_cast<unsigned long long>(m.num_ghost_elements)) * sizeof(ft) >= (1ull << 32);
       void* h = t8gpu_plan_plain_create_ex(m.num_local_elements, m.num_ghost_elements, m.num_local_faces,
                                            m.num_local_boundary_faces, ndim, m.face_neighbors.data(), m.face_normals.data(),
-                                           m.face_surfaces.data(), tmax, fcap, wide ? 0 : (3 | 8));
+                                           m.face_surfaces.data(), tmax, fcap, (wide ? 0 : (3 | 8)) | ((halo && comm && !halo->peers.empty()) ? 32 : 0));
+      // (flag 32, several ranks: interior tiles in one class -- the step driver launches them as one persistent grid per stage)
       if (!h) T8GPU_ABORT("t8gpu_plan_plain_create_ex failed");
       int64_t sz[16];
       t8gpu_plan_plain_sizes(h, sz);

@@ -275,9 +275,13 @@ int t8gpu_hip_halo_exchange_f64(const T8gpuHalo* halo, T8gpuVars_f64 state, void
 /* CompressibleEulerSolver::iterate (solver.cu:75-175) as one call: `planes` is the MemoryManager
  * allocation (26 planes of `stride`, plane = step*5+var, volume = plane 25; memory_manager.h:460), prev /
  * next the step ids AFTER the caller's std::swap (solver.cu:76). Enqueues, per stage, the exchange and the
- * ghost-reading tiles on an internal second stream beside the interior tiles on `stream` (the dependency
- * scheme is described in csrc/hip/stepper.hip) and returns; no host sync. Work queued on `stream` before
- * the call is seen by it, work queued after the call sees its result.
+ * ghost-reading tiles on an internal second stream beside the interior tiles on `stream` (two lanes, each waiting
+ * only for the other lane's PREVIOUS stage; the comm lane is enqueued by a host thread of the stepper's own --
+ * T8GPU_STEPPER_THREADS=0: by the caller's thread; csrc/hip/stepper.hip) and returns; no host sync. Work queued on
+ * `stream` before the call is seen by it, work queued after the call sees its result. For plain 2D / tile plans
+ * the ghost-reading tiles read the receive buffer and fill the send buffer themselves (T8gpuPlainPlan "ghost
+ * window"): the ghost mirror slots [N, N+G) of the planes are then NOT refreshed by this driver -- code that reads
+ * them between steps calls t8gpu_hip_halo_exchange_* (T8GPU_GHOST_WINDOW=0: pack / unpack kernels, slots refreshed).
  * iterate_steps: n_steps consecutive steps in one call, prev / next given for the FIRST step and swapped
  * from step to step (after an odd n_steps the caller's roles are swapped once more); the two streams then
  * meet only at the entry and the exit of the call instead of once per step. */
@@ -299,10 +303,11 @@ int t8gpu_hip_plain_stepper_iterate_steps_f64(void* stepper, int flux_kind, doub
  * hipGraphLaunch afterwards; enable = 0 -> direct enqueue (default); enable < 0 -> query only. counts (may be NULL)
  * receives {captures, replays}. A capture the runtime refuses returns its error code. delta_t is part of the argument set
  * (a CFL-adaptive step size re-captures per value: use the direct enqueue there).
- * With a halo the RCCL groups are captured too, on the ORIGIN stream of the capture (the deep tiles fork off instead): an
- * RCCL group on a forked stream of a capture crashes hipStreamEndCapture on this stack (HIP 7.0.51831 / RCCL 2.26.6 of the
- * torch wheel). Exercised on one GPU with a one-rank communicator exchanging with itself
- * (tests/test_gpu_graph.py), never yet across xGMI. T8GPU_GRAPH_RCCL=0 keeps the direct enqueue for steppers with a halo. */
+ * A stepper WITH a halo enqueues directly whatever this switch says, unless T8GPU_GRAPH_RCCL=1 is in the environment
+ * (opt-in): the RCCL groups are then captured too, on the ORIGIN stream of the capture (the deep tiles fork off instead; an
+ * RCCL group on a forked stream of a capture crashes hipStreamEndCapture on this stack, HIP 7.0.51831 / RCCL 2.26.6 of the
+ * torch wheel). That has only ever run on one GPU with a one-rank communicator exchanging with itself
+ * (tests/test_gpu_graph.py), never across xGMI, and costs more host time than the two-lane direct enqueue. */
 int t8gpu_hip_plain_stepper_graph(void* stepper, int enable, int* counts);
 int t8gpu_hip_plain_stepper_timing(void* stepper, int enable);
 /* Diagnostics (scripts/halo_overhead.py): with T8GPU_STEPPER_PROFILE=1 in the environment the step drivers time their own

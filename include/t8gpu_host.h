@@ -69,7 +69,10 @@ void* t8gpu_plan_plain_create(int32_t N, int32_t G, int32_t F, int32_t B, int32_
  * 0x100 | flags, area (double)}, halo_ids the 64 elements across its sides ([-x | +x | -y | +y] x 16). Inside every
  * class of tile_order the patch tiles come first (t8gpu_plan_plain_patch_counts).
  * flags bit 2: the caller does not read `face_geo` when the plan has a geometry dictionary (sizes[11] > 0): the array is
- * then left empty (32 bytes per tile face less to build and copy). */
+ * then left empty (32 bytes per tile face less to build and copy).
+ * flags bit 5 (32): no deep / near-boundary split of the interior tiles -- tile_order = [interior | ghost-reading],
+ * sizes[13] (deep tiles) = sizes[7] (interior tiles), no patch tiles reported for class 1: a launch over [0, n_interior)
+ * is then ONE kernel launch, which is what the two-lane step driver of the multi-rank path wants (csrc/hip/stepper.hip). */
 void* t8gpu_plan_plain_create_ex(int32_t N, int32_t G, int32_t F, int32_t B, int32_t ndim, const int32_t* face_neighbors,
                                  const double* normals, const double* areas, int32_t tmax, int32_t fcap, int32_t flags);
 void  t8gpu_plan_plain_destroy(void* plan);

@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
 export T8GPU_HALO_ONLY=c
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -- python3 "$ROOT/scripts/halo_overhead.py" 8 3 60 > "$OUT/trace.log" 2>&1 || { tail -20 "$OUT/trace.log"; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -- python3 "$ROOT/scripts/halo_overhead.py" ${HALO_ARGS:-8 3 60} > "$OUT/trace.log" 2>&1 || { tail -20 "$OUT/trace.log"; exit 1; }
 grep -v "amdgpu.ids" "$OUT/trace.log" | tail -8
 python3 "$ROOT/scripts/trace_timeline.py" "$OUT/trace" 48 8 > "$OUT/timeline.md" 2>&1
 cat "$OUT/timeline.md"

@@ -251,7 +251,14 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
   if (tile_count == 0) return 0;
   if ((plan->ghost_buf || plan->send_map) && (plan->n_owned <= 0 || (plan->send_map && !plan->send_buf))) return static_cast<int>(hipErrorInvalidValue);
   stage_kernel_note_reset();
-  const bool whole = tile_begin == 0 && tile_count == plan->ntiles;
+  // The interior launch of a multi-rank stage -- exactly [0, n_interior) -- is a persistent grid like a whole-plan launch. In
+  // the three-stream pipeline of rounds 1-3 resident workgroups that never leave kept the exchange kernels from starting
+  // (profiles/r03_halo_overhead.md); the two-lane driver queues the RCCL kernel and the ghost-reading tiles a stage ahead of
+  // their deadline and they slip in at the drain between two interior launches: rank 3 of the 8-way c4 split 0.168 -> 0.153
+  // ms/step (profiles/r04_halo_overhead.md). T8GPU_INTERIOR_PERSISTENT=0: one tile per workgroup (measurements).
+  static const bool interior_persistent = !(std::getenv("T8GPU_INTERIOR_PERSISTENT") && std::getenv("T8GPU_INTERIOR_PERSISTENT")[0] == '0');
+  const bool whole = (tile_begin == 0 && tile_count == plan->ntiles) ||
+                     (interior_persistent && tile_begin == 0 && tile_count == plan->n_interior_tiles && tile_count < plan->ntiles);
   const int  np_total = plan->n_patch_tiles[0] + plan->n_patch_tiles[1] + plan->n_patch_tiles[2];
   if (np_total == 0) return plain_generic_stage<T, V>(kind, stage, plan, tile_begin, tile_count, prev, mid, out, volume, dt, speed, whole, stream);
   if (!plan->tile_desc) return static_cast<int>(hipErrorInvalidValue);

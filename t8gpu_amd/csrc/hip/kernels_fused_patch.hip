@@ -36,8 +36,11 @@
 namespace t8gpu_hip {
 
 // workgroup `wg` of the `nwg` that share the patch tiles [tile_begin, tile_begin + tile_count) of tile_order
+// chunk = 0: persistent walk -- the XCD's workgroups stride through its share together (tiles j, j + n, ...); chunk = c > 0:
+// workgroup j of the XCD takes the c CONSECUTIVE tiles [j c, j c + c) of the share and leaves (a grid of ~count / c
+// workgroups that the hardware hands out as slots free up: what a launch beside other kernels wants, see plain_patch_stage)
 template <class T, int KIND, int STAGE>
-T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_count, int wg, int nwg, const FVars<T>& prev,
+T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_count, int wg, int nwg, int chunk, const FVars<T>& prev,
                              const FVars<T>& src, const FVars<T>& out, const T* __restrict__ vol, T dt, T* __restrict__ speed) {
   constexpr int NW  = KIND == 0 ? kPrimWords : 5;
   constexpr int REC = rec_words<T, NW>();
@@ -54,8 +57,9 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
   const int nxcd = G < 8 ? G : 8, nx = (G - xcd + 7) >> 3;
   const int per = tile_count / nxcd, rem = tile_count % nxcd;
   const int x0   = tile_begin + xcd * per + (xcd < rem ? xcd : rem);
-  const int tend = x0 + per + (xcd < rem ? 1 : 0);
-  int       t    = x0 + jw;
+  int       tend = x0 + per + (xcd < rem ? 1 : 0);
+  int       t    = x0 + (chunk > 0 ? jw * chunk : jw);
+  if (chunk > 0 && t + chunk < tend) tend = t + chunk;
   if (xcd >= nxcd || t >= tend) return;
   if (kTab) {
     lt[tid] = kLogTab[tid];
@@ -123,7 +127,7 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
     return p;
   };
 
-  const int stride = nx;
+  const int stride = chunk > 0 ? 1 : nx;
   Desc      d0 = load_desc(t), d1 = load_desc(t + stride);
   int       hs_a = halo_wave ? P.halo_ids[d0.h0 + hl] : 0, hs_b = halo_wave ? P.halo_ids[d1.h0 + hl] : 0;
   Pre       cur = prefetch(d0, hs_a, true);
@@ -237,10 +241,10 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
 
 // (second launch bound = waves per SIMD the register allocation must allow: 3 workgroups per CU in fp64, 5 in fp32)
 template <class T, int KIND, int STAGE>
-__global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_patch(T8gpuPlainPlan P, int tile_begin, int tile_count, FVars<T> prev,
+__global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_patch(T8gpuPlainPlan P, int tile_begin, int tile_count, int chunk, FVars<T> prev,
                                                                                 FVars<T> src, FVars<T> out, const T* __restrict__ vol, T dt,
                                                                                 T* __restrict__ speed) {
-  plain_patch_body<T, KIND, STAGE>(P, tile_begin, tile_count, blockIdx.x, gridDim.x, prev, src, out, vol, dt, speed);
+  plain_patch_body<T, KIND, STAGE>(P, tile_begin, tile_count, blockIdx.x, gridDim.x, chunk, prev, src, out, vol, dt, speed);
 }
 
 // ONE launch per stage for a range of tile_order that holds patch tiles AND generic tiles: the first `patch_wgs`
@@ -248,13 +252,13 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_patch(T8g
 // the generic tiles of the benchmark mesh -- 3 % of its elements -- cost 9 % of the stage: a launch of their own, started
 // when the patch launch has drained. Here they start as the persistent patch workgroups finish and fill the ragged end.
 template <class T, int KIND, int STAGE>
-__global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_stage(T8gpuPlainPlan P, int patch_begin, int patch_count, int patch_wgs,
+__global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_stage(T8gpuPlainPlan P, int patch_begin, int patch_count, int patch_wgs, int chunk,
                                                                                 int tile_begin, int tile_count, FVars<T> prev, FVars<T> src,
                                                                                 FVars<T> out, const T* __restrict__ vol, T dt,
                                                                                 T* __restrict__ speed) {
   const int b = blockIdx.x;
   if (b < patch_wgs) {
-    plain_patch_body<T, KIND, STAGE>(P, patch_begin, patch_count, b, patch_wgs, prev, src, out, vol, dt, speed);
+    plain_patch_body<T, KIND, STAGE>(P, patch_begin, patch_count, b, patch_wgs, chunk, prev, src, out, vol, dt, speed);
   } else {
 #ifdef T8GPU_EXP_TILEMOD
     const int pos = tile_begin + xcd_position(b - patch_wgs, tile_count) % T8GPU_EXP_TILEMOD;
@@ -273,6 +277,8 @@ template <class T>
 int plain_patch_stage(int kind, int stage, const T8gpuPlainPlan* plan, int patch_begin, int patch_count, int tile_begin, int tile_count,
                       FVars<T> prev, FVars<T> mid, FVars<T> out, const T* volume, T dt, T* speed, bool persistent, hipStream_t stream) {
   if (patch_count <= 0) return tile_count > 0 ? -1 : 0;
+  // (does this launch run beside another lane's kernels? a plan with ghost-reading tiles, launched in part)
+  const bool shared_gpu = plan->n_interior_tiles < plan->ntiles && patch_count + (tile_count > 0 ? tile_count : 0) < plan->ntiles;
   if (!plan->tile_desc) return static_cast<int>(hipErrorInvalidValue);
   // (the kernel addresses a plane by a 32-bit byte offset, patch_common.hpp: at32)
   if (plan->n_slots_addressed <= 0 || static_cast<unsigned long long>(plan->n_slots_addressed) * sizeof(T) >= (1ull << 32))
@@ -316,17 +322,33 @@ int plain_patch_stage(int kind, int stage, const T8gpuPlainPlan* plan, int patch
   if (plan->ghost_buf || plan->send_map) persistent = false;
   const int  per_cu    = per_cu_env > 0 ? per_cu_env : (sizeof(T) == 8 ? 3 : 5);
   const int  resident  = cus * per_cu;
-  const int  patch_wgs = (!persistent || patch_count < resident) ? patch_count : resident;
+  // A persistent launch that shares the GPU with the other lane's kernels (the interior launch of a multi-rank stage: the plan
+  // has ghost-reading tiles and the range is not the whole plan) must not count on all its workgroups being resident from
+  // the start: whatever slots the RCCL kernel and the ghost-reading tiles hold when it is dispatched, that many of its
+  // workgroups start when the FIRST of the others retire and then walk their whole share -- the launch takes up to twice
+  // as long (rank 0 of the 2-way c4 split: interior kernel 180 instead of 150 us, profiles/r04_halo_overhead.md). Such
+  // launches hand out CHUNKS instead: workgroup j takes `chunk` consecutive patches, with the software pipeline inside the
+  // chunk, and the hardware dispatches the chunks as slots free up.
+  static const int chunk_env = std::getenv("T8GPU_PATCH_CHUNK") ? std::atoi(std::getenv("T8GPU_PATCH_CHUNK")) : -1;
+  int chunk = 0;
+  // (measured, rank of the c4 mesh split 2 / 4 / 8 ways with a self-exchange, ms per step: persistent walk 0.549 / 0.313 / 0.151,
+  //  chunks of 2: 0.497 / 0.280 / 0.153, of 3: 0.483 / 0.268 / 0.151, of 4: 0.481 / 0.264 / 0.156, of 6: 0.469 / 0.288 / 0.157)
+  if (persistent && shared_gpu && patch_count >= resident) chunk = chunk_env >= 0 ? chunk_env : 3;
+  int patch_wgs = (!persistent || patch_count < resident) ? patch_count : resident;
+  if (chunk > 0) {   // 8 XCD shares of ceil(count / 8) patches, ceil(share / chunk) workgroups each
+    const int share = (patch_count + 7) / 8;
+    patch_wgs       = 8 * ((share + chunk - 1) / chunk);
+  }
   const dim3 grid(patch_wgs + (tile_count > 0 ? tile_count : 0)), block(256);
   note_stage_kernel(patch_count + (tile_count > 0 ? tile_count : 0), tile_count > 0 ? "k_plain_stage<T, K, S>" : "k_plain_patch<T, K, S>",
                     static_cast<int>(sizeof(T)), kind, stage);
 #define T8_PA(K, S)                                                                                                               \
   do {                                                                                                                            \
     if (tile_count > 0)                                                                                                           \
-      hipLaunchKernelGGL((k_plain_stage<T, K, S>), grid, block, lds, stream, *plan, patch_begin, patch_count, patch_wgs, tile_begin, \
+      hipLaunchKernelGGL((k_plain_stage<T, K, S>), grid, block, lds, stream, *plan, patch_begin, patch_count, patch_wgs, chunk, tile_begin, \
                          tile_count, prev, mid, out, volume, dt, speed);                                                          \
     else                                                                                                                          \
-      hipLaunchKernelGGL((k_plain_patch<T, K, S>), grid, block, lds, stream, *plan, patch_begin, patch_count, prev, mid, out, volume, dt, \
+      hipLaunchKernelGGL((k_plain_patch<T, K, S>), grid, block, lds, stream, *plan, patch_begin, patch_count, chunk, prev, mid, out, volume, dt, \
                          speed);                                                                                                  \
   } while (0)
 #define T8_PAS(K)          \

@@ -237,8 +237,8 @@ int tick(Stepper* S, hipStream_t s) {
 //     The RCCL kernel needs 264 VGPRs per lane (rcclGenericKernel<1, false> of RCCL 2.26.6 for gfx950): beside tile kernels
 //     that hold 3 x 160 of a SIMD's 512 it is not dispatched before the tile launch has handed out its last workgroup.
 //     Here it is queued a whole stage ahead of its deadline and slips in at the drain between two interior launches.
-//     (T8GPU_STEPPER_CLASSES=3 keeps the deep / near-boundary split: C_g on the deep lane behind [B_(g-1)], B_g on the comm
-//     lane behind A_g and [C_(g-1)].)
+//     (A plan WITH a deep / near-boundary split of its interior tiles -- Subgrid plans, plain plans built without flag 32 -- runs
+//     C_g on the deep lane behind [B_(g-1)] and B_g on the comm lane behind A_g and [C_(g-1)].)
 //   * The comm lane is enqueued by a HOST THREAD of its own while the caller's thread enqueues the deep lane; the threads
 //     meet through two counters (a wait on stage g's event may only be issued once the other thread has recorded it).
 // Plans the ghost window does not cover (Subgrid blocks, 3D patch tiles) run the same two lanes with the pack / unpack
@@ -322,10 +322,11 @@ int iterate_lanes(Stepper* S, int kind, T* planes, size_t stride, const T* vol, 
   const int  nt = S->subgrid ? S->splan.num_elements : S->plan.ntiles;
   const int  ni = S->subgrid ? S->splan.n_interior_blocks : S->plan.n_interior_tiles;
   const int  ndeep = S->subgrid ? S->splan.n_deep_blocks : S->plan.n_deep_tiles;
-  // T8GPU_STEPPER_CLASSES=3 (measurements): the deep / near-boundary split of the interior tiles, B_g behind A_g on the comm
-  // lane. Default: the interior tiles [0, ni) are ONE launch per stage on the deep lane.
-  static const bool three = std::getenv("T8GPU_STEPPER_CLASSES") && std::getenv("T8GPU_STEPPER_CLASSES")[0] == '3';
-  const int  nd = three ? ((ndeep > 0 && ndeep <= ni) ? ndeep : 0) : ni;
+  // The plan decides: one interior class (n_deep = n_interior; t8gpu_plan_plain_create_ex flag 32, what partitioned meshes get)
+  // -> the interior tiles are ONE launch per stage on the deep lane; a deep / near-boundary split in the plan (Subgrid plans,
+  // plain plans built without the flag) -> C_g on the deep lane, B_g behind A_g on the comm lane. n_deep = 0 ("unknown"):
+  // every interior tile counts as near-boundary.
+  const int  nd = (ndeep > 0 && ndeep <= ni) ? ndeep : 0;
   const int  G  = 3 * n_steps;
   t8gpu_hip::Range whole("t8gpu.iterate_steps (exchange -> ghost-reading tiles || interior tiles, two lanes)");
   Stepper::Lane& DL = S->deep_lane;
@@ -794,9 +795,13 @@ static int stepper_halo_setup(Stepper* S, const T8gpuHalo* halo) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_interior, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_deep, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&S->near_stream, hipStreamNonBlocking);
+    // the lanes' events order two queues of ONE device: a device-scope release is all they need (the default is a
+    // system-scope fence per record). T8GPU_EVENT_SCOPE=system keeps the default (measurements).
+    const char*    scope = std::getenv("T8GPU_EVENT_SCOPE");
+    const unsigned flags = hipEventDisableTiming | ((scope && scope[0] == 's') ? 0u : static_cast<unsigned>(hipEventReleaseToDevice));
     for (int i = 0; i < Stepper::kRing && e == hipSuccess; i++) {
-      e = hipEventCreateWithFlags(&S->deep_lane.ring[i], hipEventDisableTiming);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&S->comm_lane.ring[i], hipEventDisableTiming);
+      e = hipEventCreateWithFlags(&S->deep_lane.ring[i], flags);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&S->comm_lane.ring[i], flags);
     }
     if (e != hipSuccess) return static_cast<int>(e);
     const char* th = std::getenv("T8GPU_STEPPER_THREADS");

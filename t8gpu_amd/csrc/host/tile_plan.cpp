@@ -93,6 +93,7 @@ struct TilePlan {
   // structured patches (see find_patches): tiles the patch kernel evaluates without face records
   int32_t want_patches = 0;
   bool    skip_face_geo = false;                       // leave face_geo empty when the plan has a geometry dictionary
+  bool    two_classes = false;                         // no deep / near-boundary split of the interior tiles (flag 32)
   std::vector<Patch>   patches;                        // in element order
   std::vector<int32_t> tile_patch;                     // [ntiles] index into patches, or -1 (generic tile)
   int32_t n_patch_class[3] = {0, 0, 0};                // leading patch tiles of the deep / near / ghost-reading class
@@ -846,7 +847,7 @@ void build(TilePlan& P, const int32_t* fn, const double* normals, const double* 
     for (int pass = 0; pass < 3; pass++) {
       const int32_t before = static_cast<int32_t>(P.tile_order.size());
       for (int32_t t = 0; t < ntiles; t++) {
-        const int c    = reads_ghost[t] ? 2 : (near_boundary[t] ? 1 : 0);
+        const int c    = reads_ghost[t] ? 2 : ((near_boundary[t] && !P.two_classes) ? 1 : 0);
         const int kind = P.tile_patch[t] < 0 ? 2 : (P.patches[P.tile_patch[t]].info.empty() ? 0 : 1);
         if (c == cls && kind == pass) P.tile_order.push_back(t);
       }
@@ -903,6 +904,8 @@ void* t8gpu_plan_plain_create_ex(int32_t N, int32_t G, int32_t F, int32_t B, int
   P->N = N; P->G = G; P->F = F; P->B = B; P->ndim = ndim; P->tmax = tmax; P->fcap = fcap;
   P->want_patches  = flags & 27;   // bit 0: 2D patches (16 x 16), bit 1: 3D patches (8 x 8 x 4), bit 3: irregular 3D patches too, bit 4: no regular 3D ones
   P->skip_face_geo = (flags & 4) != 0;   // bit 2: no face_geo rows if the plan has a geometry dictionary
+  P->two_classes   = (flags & 32) != 0;  // bit 5: interior tiles in ONE class (n_deep_tiles = n_interior_tiles): a launch over
+                                         // [0, n_interior) is then one kernel launch (the two-lane step driver, stepper.hip)
   build(*P, fn, normals, areas);
   if (P->max_elems + P->max_halo >= 0xFFFF || P->max_faces > 0x7FFE) {
     delete P;

@@ -22,12 +22,12 @@ class T8gpuPlainPlan(C.Structure):
 
 class PlainPlan:
     def __init__(self, part, dtype, tmax=None, fcap=None, compressed=True, dictionary=True, patches=None, flux_kind=None,
-                 irregular=None, fcap_elements=None):
+                 irregular=None, fcap_elements=None, two_classes=None):
         """compressed=False: generic kernel (CSR lists, full geometry). dictionary=False: pipelined kernel
         with per-face geometry rows even where the mesh has few distinct ones (what curved meshes get anyway).
         patches: cut structured 16 x 16 patches out of the tiling for the patch kernel (default: yes for the compressed
         plan; T8GPU_PATCH=0 switches it off -- same results bit for bit, every element through the tile kernels)."""
-        skip_geo = self._plan_on_host(part, dtype, tmax, fcap, compressed, dictionary, patches, flux_kind, irregular, fcap_elements)
+        skip_geo = self._plan_on_host(part, dtype, tmax, fcap, compressed, dictionary, patches, flux_kind, irregular, fcap_elements, two_classes)
         self._upload(dtype, compressed, dictionary, skip_geo, part)
 
     @classmethod
@@ -35,12 +35,14 @@ class PlainPlan:
         """The host half alone (no GPU): the tile plan and the caps / patch forms the rules below settle on (`host`, `auto_fcap`,
         `irregular`, `auto_irregular`). Tests pin the rules through this."""
         self = object.__new__(cls)
-        args = dict(tmax=None, fcap=None, compressed=True, dictionary=True, patches=None, flux_kind=None, irregular=None, fcap_elements=None)
+        args = dict(tmax=None, fcap=None, compressed=True, dictionary=True, patches=None, flux_kind=None, irregular=None, fcap_elements=None,
+                    two_classes=None)
         args.update(kw)
         self._plan_on_host(part, dtype, **args)
         return self
 
-    def _plan_on_host(self, part, dtype, tmax, fcap, compressed, dictionary, patches, flux_kind, irregular, fcap_elements=None):
+    def _plan_on_host(self, part, dtype, tmax, fcap, compressed, dictionary, patches, flux_kind, irregular, fcap_elements=None,
+                      two_classes=None):
         import os
         # An inherited face cap (amr._inherited_plan_options) was chosen for a mesh of `fcap_elements` elements: which kernel a
         # plan gets depends on its tile count, so a mesh that has since grown or shrunk by more than a factor two decides again
@@ -74,6 +76,12 @@ class PlainPlan:
         # the face cap chosen by the heuristics below, or handed down from the plan of the mesh this one was adapted from
         # (amr._inherited_plan_options); None: the default
         self.auto_fcap = given_fcap
+        # Partitioned meshes: interior tiles in ONE class (tile_order = interior | ghost-reading) -- the two-lane step driver
+        # (stepper.hip) launches [0, n_interior) as one kernel per stage. two_classes=False / T8GPU_PLAN_CLASSES=3 keeps the
+        # deep / near-boundary split (what the three-stream pipeline of rounds 1-3 wants: T8GPU_STEPPER=legacy).
+        if two_classes is None:
+            two_classes = getattr(part, "nranks", 1) > 1 and os.environ.get("T8GPU_PLAN_CLASSES", "2") != "3"
+        self.two_classes = bool(two_classes)
         retry_768 = given_fcap in (384, 480) and dtype == torch.float64      # an inherited cap still has to fit the persistent kernel
         if (fcap is None and "T8GPU_FCAP" not in os.environ and not small and dtype == torch.float64 and
                 getattr(part.mesh, "dim", 2) == 3):
@@ -95,7 +103,7 @@ class PlainPlan:
                     self.auto_fcap = 480
         fcap = int(os.environ.get("T8GPU_FCAP", 512)) if fcap is None else fcap
         # the per-face geometry rows are only read by the kernels without a dictionary (generic kernel, dictionary=False)
-        self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary), patches=self.patches, irregular=self.irregular)
+        self.host = HostPlainPlan.from_partition(part, two_classes=self.two_classes, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary), patches=self.patches, irregular=self.irregular)
         if retry_768:
             # 480-face tiles only pay if the persistent kernel takes the plan: the LAUNCHER'S OWN test is asked (C-ABI query;
             # it covers the LDS margin, the tile-count gate for mid-size meshes, the flux kind and T8GPU_PERSISTENT=0 --
@@ -103,7 +111,7 @@ class PlainPlan:
             # better on 768-face tiles.
             if not (compressed and dictionary and self._persistent_accepts(self.host, dtype, flux_kind)):
                 fcap = self.auto_fcap = 768
-                self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary), patches=self.patches, irregular=self.irregular)
+                self.host = HostPlainPlan.from_partition(part, two_classes=self.two_classes, tmax=tmax, fcap=fcap, want_face_geo=not (compressed and dictionary), patches=self.patches, irregular=self.irregular)
         if (given_fcap is None and "T8GPU_FCAP" not in os.environ and compressed and dictionary and fcap in (480, 512)
                 and getattr(part.mesh, "dim", 2) == 3 and self.host.n_patches * 256 > part.N // 2
                 and self.host.n_patches < self.host.ntiles):
@@ -112,7 +120,7 @@ class PlainPlan:
             # 512-face cap 140 + 4. Measured on c5, fp64 (scripts/fcap_scan.sh): 256: 5 340, 300: 5 640, 360-400: 5 720-5 760,
             # 440: 5 540, 480: 5 420 M/s; fp32: 512: 9 310, 384: 9 950 (a plan without patches prefers 480: 4 550 against
             # 4 130 at 380).
-            trial = HostPlainPlan.from_partition(part, tmax=tmax, fcap=384, want_face_geo=False, patches=self.patches, irregular=self.irregular)
+            trial = HostPlainPlan.from_partition(part, two_classes=self.two_classes, tmax=tmax, fcap=384, want_face_geo=False, patches=self.patches, irregular=self.irregular)
             # (fp64: only if the persistent kernel still takes the plan -- the one-tile kernel wants 768; fp32 runs either kernel well)
             if dtype == torch.float32 or self._persistent_accepts(trial, dtype, flux_kind):
                 fcap = self.auto_fcap = 384
@@ -125,7 +133,7 @@ class PlainPlan:
         if (dtype == torch.float32 and self.irregular is True and irregular_auto and n_irr and compressed and dictionary
                 and self._persistent_accepts(self.host, dtype, flux_kind, n_generic=self.host.ntiles - self.host.n_patches + 2 * n_irr)):
             self.irregular = False
-            self.host = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=False, patches=self.patches, irregular=False)
+            self.host = HostPlainPlan.from_partition(part, two_classes=self.two_classes, tmax=tmax, fcap=fcap, want_face_geo=False, patches=self.patches, irregular=False)
         h = self.host
         # What an ADAPTED mesh's plan inherits (amr._inherited_plan_options): where nearly every patch is an irregular one -- thin
         # refined sheets: c5a has 5 944 irregular and 8 regular patches -- the irregular form buys nothing (it runs at the speed of
@@ -137,7 +145,7 @@ class PlainPlan:
         skip_geo = (compressed and dictionary and h.geo_table.shape[0] > 0 and h.max_elems <= 256 and h.max_slots <= 512
                     and h.max_faces <= 1024)
         if not skip_geo and h.face_geo.shape[0] == 0 and h.face_lr.size:     # the kernels this plan gets do read the rows
-            self.host = h = HostPlainPlan.from_partition(part, tmax=tmax, fcap=fcap, want_face_geo=True, patches=self.patches, irregular=self.irregular)
+            self.host = h = HostPlainPlan.from_partition(part, two_classes=self.two_classes, tmax=tmax, fcap=fcap, want_face_geo=True, patches=self.patches, irregular=self.irregular)
         return skip_geo
 
     def _upload(self, dtype, compressed, dictionary, skip_geo, part):

@@ -130,6 +130,13 @@ class NativeStepper:
     def timing(self, enable):
         hip.check(hip.lib().t8gpu_hip_plain_stepper_timing(self.handle, int(enable)))
 
+    def host_time(self, reset=False):
+        """(milliseconds, steps): host time the multi-rank driver spent enqueueing and the steps that covers (0, 0 for a
+        single-rank stepper)."""
+        ms, n = C.c_double(), C.c_longlong()
+        hip.check(hip.lib().t8gpu_hip_plain_stepper_host_time(self.handle, int(bool(reset)), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def timed_stages(self):
         return int(hip.lib().t8gpu_hip_plain_stepper_timed_stages(self.handle))
 
@@ -156,6 +163,13 @@ class NativeSubgridStepper(NativeStepper):
         hip.call("t8gpu_hip_subgrid_stepper_iterate_steps", solver.dtype, self.handle, solver.kind, hip.ptr(solver.planes),
                  C.c_size_t(solver.stride), hip.ptr(solver.volumes), prev, next, hip.fscalar(solver.dtype, delta_t),
                  C.c_int(n_steps), hip.stream_ptr(stream))
+
+
+def runtime_versions():
+    """{"rccl": (compiled against, bound at run time), "hip": (...)}: t8gpu_hip_runtime_versions (include/t8gpu_hip.h)."""
+    v = (C.c_int * 4)()
+    hip.check(hip.lib().t8gpu_hip_runtime_versions(v))
+    return {"rccl": (v[0], v[1]), "hip": (v[2], v[3])}
 
 
 def stream_wait(stream, timeout_s):

@@ -39,7 +39,7 @@ class HostPlainPlan:
               "csr_ent", "tile_order")
 
     def __init__(self, N, G, F, B, ndim, face_neighbors, normals, areas, tmax=256, fcap=512, want_face_geo=True,
-                 patches=False, volumes=None, irregular=True):
+                 patches=False, volumes=None, irregular=True, two_classes=False):
         """patches=True: structured 16 x 16 patches are cut out of the tiling (tile_plan.cpp: find_patches); they are
         tiles without face records (`tile_patch[t]` = 1), first inside every class of `tile_order` (`n_patch_class`).
         want_face_geo=False: leave `face_geo` (32 bytes per tile face, only read by the kernels that have no geometry
@@ -56,6 +56,8 @@ class HostPlainPlan:
             pflags |= 8       # 3D blocks next to a periodic wrap / wall / coarser - side neighbour become (irregular) patches too
             if irregular == "all":
                 pflags |= 16  # ... and the regular blocks take the irregular form as well (one kernel, one launch per stage)
+        if two_classes:
+            pflags |= 32      # interior tiles in one class (no deep / near-boundary split): one launch per stage for [0, n_interior)
         h = lib.t8gpu_plan_plain_create_ex(N, G, F, B, ndim, p(fn), p(nr), p(ar), tmax, fcap, pflags)
         if not h:
             raise ValueError("tile plan exceeds the packed index format (use smaller tmax / fcap)")

@@ -83,7 +83,7 @@ print("direct enqueue done", flush=True)
 replayed, counts = run(True)
 print("graph counts", counts, flush=True)
 mode = os.environ["T8GPU_TEST_GRAPH_CHILD"]
-if mode == "rccl_capture_off":                # T8GPU_GRAPH_RCCL=0: a stepper with a halo keeps the direct enqueue
+if mode == "rccl_capture_off":                # no T8GPU_GRAPH_RCCL=1: a stepper with a halo keeps the direct enqueue
     assert counts == (0, 0), counts
     assert torch.equal(direct, replayed)
     print("HALO: DIRECT ENQUEUE IN GRAPH MODE OK", flush=True)
@@ -115,14 +115,15 @@ def test_graph_replay_of_the_multi_rank_pipeline_with_rccl_self_exchange(tmp_pat
     The exchange chain is captured on the ORIGIN stream of the capture and the deep tiles fork off (stepper.hip) -- with
     the RCCL group on a forked stream hipStreamEndCapture crashes on this stack (the opt-in diagnostic below). Runs in a
     child process all the same: a runtime crash must not take the test session down."""
-    res, out = _child(tmp_path, "rccl", {}, "graph_child_rccl.log")
+    res, out = _child(tmp_path, "rccl", dict(T8GPU_GRAPH_RCCL="1"), "graph_child_rccl.log")
     assert res.returncode == 0 and "GRAPH WITH RCCL OK" in res.stdout, out[-3000:]
 
 
-def test_graph_mode_can_be_kept_off_for_steppers_with_a_halo(tmp_path):
-    """T8GPU_GRAPH_RCCL=0: a stepper with a halo enqueues directly whatever the graph switch says (zero captures, zero
-    replays, same bits) -- the fallback if a stack refuses RCCL inside a capture altogether."""
-    res, out = _child(tmp_path, "rccl_capture_off", dict(T8GPU_GRAPH_RCCL="0"), "graph_child_halo_direct.log")
+def test_graph_mode_is_off_by_default_for_steppers_with_a_halo(tmp_path):
+    """Capturing RCCL groups is opt-in (T8GPU_GRAPH_RCCL=1; ADVICE r3: a replayed RCCL group has never run across xGMI): by
+    default a stepper with a halo enqueues directly -- the two-lane driver -- whatever the graph switch says (zero captures,
+    zero replays, same bits)."""
+    res, out = _child(tmp_path, "rccl_capture_off", {}, "graph_child_halo_direct.log")
     assert res.returncode == 0 and "HALO: DIRECT ENQUEUE IN GRAPH MODE OK" in res.stdout, out[-3000:]
 
 
@@ -136,7 +137,7 @@ def test_graph_capture_of_the_three_stream_pipeline_without_the_rccl_group(tmp_p
     lib = build.NO_RCCL_LIB
     if not os.path.exists(lib):
         pytest.skip("diagnostic build missing: python -c 'from t8gpu_amd import build; build.build_diagnostic_variants()'")
-    res, out = _child(tmp_path, "no_rccl", dict(T8GPU_HIP_LIB=lib), "graph_child_no_rccl.log")
+    res, out = _child(tmp_path, "no_rccl", dict(T8GPU_HIP_LIB=lib, T8GPU_GRAPH_RCCL="1"), "graph_child_no_rccl.log")
     assert res.returncode == 0 and "GRAPH WITHOUT RCCL CAPTURED AND REPLAYED" in res.stdout, out[-3000:]
 
 
@@ -150,7 +151,7 @@ def test_rccl_group_on_a_forked_stream_of_a_capture_opt_in(tmp_path):
     usable stack). Kept to re-check newer stacks."""
     shim = tmp_path / "segv_backtrace.so"
     subprocess.run(["gcc", "-O1", "-g", "-shared", "-fPIC", "-o", str(shim), os.path.join(ROOT, "scripts", "segv_backtrace.c")], check=True)
-    res, out = _child(tmp_path, "rccl", dict(T8GPU_GRAPH_VARIANT="5", T8GPU_TEST_SEGV_SHIM=str(shim)), "graph_child_rccl_forked.log")
+    res, out = _child(tmp_path, "rccl", dict(T8GPU_GRAPH_VARIANT="5", T8GPU_GRAPH_RCCL="1", T8GPU_TEST_SEGV_SHIM=str(shim)), "graph_child_rccl_forked.log")
     assert "direct enqueue done" in res.stdout, out[-3000:]
     if res.returncode != 0:
         pytest.xfail("RCCL group on a forked stream of a capture: " + out[-1500:].replace("\n", " | "))

@@ -243,16 +243,19 @@ def k_way_subgrid(mesh, world, mode, dim, both_classes):
         assert np.array_equal(full, ref.state().cpu().numpy())      # same sums in the same order on every rank
 
 
-@pytest.mark.parametrize("dtype,caps", [(torch.float64, (64, 160)), (torch.float32, (64, 160)), (torch.float64, (8, 30)),
-                                        (torch.float64, (256, 512)), (torch.float64, (4000, 512))])
-def test_native_stepper_with_rccl_self_exchange_on_a_symmetric_problem(dtype, caps):
+@pytest.mark.parametrize("dtype,caps,classes", [(torch.float64, (64, 160), 3), (torch.float64, (64, 160), 2), (torch.float32, (64, 160), 2),
+                                                (torch.float64, (8, 30), 2), (torch.float32, (8, 30), 3), (torch.float64, (256, 512), 2),
+                                                (torch.float64, (256, 512), 3), (torch.float64, (4000, 512), 3)])
+def test_native_stepper_with_rccl_self_exchange_on_a_symmetric_problem(dtype, caps, classes):
     """The C++ step driver with its RCCL exchange and two-stream pipeline, with REAL data dependencies, on one
     GPU: the mesh and the state are invariant under y -> y + 1/2, which maps the lower half of the Morton
     curve (rank 0 of 2) onto the upper half (rank 1) in order. What rank 1 would send to rank 0 is then
     exactly what rank 0 sends to rank 1, so rank 0 can exchange with ITSELF through a one-rank RCCL
     communicator and must reproduce the single-rank run on its half. (Not bitwise: the single-rank run
     lists the faces at y = 1/2 and at the periodic seam with opposite orientations, so it is symmetric only up
-    to rounding; a ghost that is one stage stale would be off by O(dt) ~ 1e-4, far above the tolerance.)"""
+    to rounding; a ghost that is one stage stale would be off by O(dt) ~ 1e-4, far above the tolerance.)
+    classes = 2: the plan a partitioned mesh gets by default (interior | ghost-reading tiles; the two-lane driver launches the
+    interior as one persistent grid); 3: with the deep / near-boundary split (B tiles on the comm lane)."""
     import types
     from t8gpu_amd import fused, native
     mesh = SynthMesh(2, 5, 8, band=0.05)
@@ -270,7 +273,7 @@ def test_native_stepper_with_rccl_self_exchange_on_a_symmetric_problem(dtype, ca
     gidx = np.concatenate([np.arange(half.N), half.ghost_global])
     local = st[:, gidx].copy()
     local[:, half.N:] = np.nan                                            # ghosts must arrive through RCCL
-    g = PlainSolver(half, dtype, mode="fused", state=local, plan_options=dict(tmax=min(caps[0], 256), fcap=caps[1]),
+    g = PlainSolver(half, dtype, mode="fused", state=local, plan_options=dict(tmax=min(caps[0], 256), fcap=caps[1], two_classes=classes == 2),
                     capacity=half.N + half.G + 3)                        # (three extra ghost slots: see `fake` below)
     if caps[0] == 4000:                                                   # no class information: the driver must cope
         g.plan.c.n_deep_tiles = 0
@@ -287,8 +290,10 @@ def test_native_stepper_with_rccl_self_exchange_on_a_symmetric_problem(dtype, ca
     nh = native.NativeHalo(fake, dtype, comm)
     g.use_native_stepper(nh)
     dt = 0.1 * 2.0 ** -mesh.finest_level
-    if caps == (64, 160):
+    if caps == (64, 160) and classes == 3:
         assert 0 < hp.n_deep < hp.n_interior < hp.ntiles                  # all three tile classes are populated
+    if classes == 2:
+        assert 0 < hp.n_deep == hp.n_interior < hp.ntiles
     for _ in range(6 + 13):
         ref.iterate(dt)
     g.iterate(dt)                                                         # one step per call ...
