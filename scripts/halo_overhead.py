@@ -2,11 +2,13 @@
 """One-GPU estimate of what the halo machinery costs a rank of the 8-way strong-scaled c4 run.
 
 Takes rank 3's share of the c4 mesh split 8 ways (1.24 M elements, ~3 k ghosts) and times the native C++
-stepper (a) without any exchange and (b) with the full per-stage sequence -- event, pack kernel, RCCL
-grouped send/recv, unpack kernel, event, interior tiles || exchange, ghost-reading tiles -- where every
-peer is mapped onto this rank itself (RCCL self send/recv, message sizes made symmetric). The payload does
-not cross xGMI, so (b) - (a) is the launch / synchronisation overhead of the overlap scheme, not link time;
-the ghost VALUES are meaningless here and the result of (b) is not checked.
+stepper (a) without any exchange and (b) with the full per-stage sequence of the multi-rank driver
+(csrc/hip/stepper.hip: RCCL grouped send/recv -> ghost-reading tiles on the comm lane beside the interior
+tiles on the deep lane; T8GPU_STEPPER=legacy T8GPU_PLAN_CLASSES=3: the three-stream pipeline of rounds 1-3
+with its pack / unpack kernels) -- where every peer is mapped onto this rank itself (RCCL self send/recv,
+message sizes made symmetric). The payload does not cross xGMI, so (b) - (a) is the launch / synchronisation
+overhead of the overlap scheme, not link time; the ghost VALUES are meaningless here and the result of (b) is
+not checked. T8GPU_STEPPER_PROFILE=1 adds the host cost of (c) by call category.
 usage: halo_overhead.py [world=8] [rank=3] [steps=200] [one_gpu_ms_per_step=0.92]"""
 import sys
 import time
@@ -96,21 +98,24 @@ def main():
         del a, b
         comm.destroy()
         return
-    # (d) the same call through a hipGraph: captured once (RCCL groups included, on the capture's origin stream), then ONE
-    # hipGraphLaunch per call -- the host cost of a step drops to the replay's
-    b.stepper.graph(True)
-    b.iterate_steps(steps, dt)                       # capture
-    torch.cuda.synchronize()
-    td = timed(b, many=True)
-    print(f"(d) same through a hipGraph replay: {td:.4f} ms/step; the host needs {timed.host_ms:.4f} ms per step; "
-          f"captures / replays = {b.stepper.graph()}", flush=True)
-    b.stepper.graph(False)
+    # (d) the same call through a hipGraph (opt-in: T8GPU_GRAPH_RCCL=1 -- by default a stepper with a halo enqueues directly):
+    # captured once (RCCL groups included, on the capture's origin stream), then ONE hipGraphLaunch per call
+    td = float("nan")
+    if __import__("os").environ.get("T8GPU_GRAPH_RCCL") == "1":
+        b.stepper.graph(True)
+        b.iterate_steps(steps, dt)                       # capture
+        torch.cuda.synchronize()
+        td = timed(b, many=True)
+        print(f"(d) same through a hipGraph replay: {td:.4f} ms/step; the host needs {timed.host_ms:.4f} ms per step; "
+              f"captures / replays = {b.stepper.graph()}", flush=True)
+        b.stepper.graph(False)
     print(f"overhead of the overlap scheme: {tb - ta:+.4f} ms/step = {(tb - ta) / 3 * 1e3:+.1f} us/stage; "
           f"8-way ideal would be {1.0:.2f}x of (a), this is {tb / ta:.3f}x", flush=True)
     one = float(sys.argv[4]) if len(sys.argv) > 4 else 0.92   # ms/step of the whole mesh on one GPU (bench.py c4, round 3)
     print(f"projected strong-scaling speedup at {world} ranks if every rank behaves like this one: "
-          f"{one / tb:.2f}x direct enqueue per step, {one / tc:.2f}x all steps in one call, {one / td:.2f}x graph replay "
-          f"(no exchange: {one / ta:.2f}x) -- a PROJECTION from one GPU: no byte crosses xGMI here", flush=True)
+          f"{one / tb:.2f}x direct enqueue per step, {one / tc:.2f}x all steps in one call"
+          + (f", {one / td:.2f}x graph replay" if td == td else "") +
+          f" (no exchange: {one / ta:.2f}x) against {one} ms/step on one GPU -- a PROJECTION from one GPU: no byte crosses xGMI here", flush=True)
     del a, b                                        # (T8GPU_STEPPER_PROFILE=1: the steppers print their host-cost profile here)
     import gc
     gc.collect()

@@ -109,7 +109,6 @@ struct Stepper {
     size_t             used = 0;
   };
   Lane            deep_lane, comm_lane;     // C tiles | RCCL, A tiles, B tiles
-  hipStream_t     deep_stream = nullptr;    // own stream of the C tiles (only with a CU mask: T8GPU_COMM_CUS), else the caller's
   bool            zero_copy = false;        // ghost window: A tiles read the receive buffer and fill the send buffer themselves
   T8gpuPlainPlan  plan_a{};                 // `plan` + the ghost window (launches of the A class)
   void*           d_send_map = nullptr;
@@ -331,7 +330,7 @@ int iterate_lanes(Stepper* S, int kind, T* planes, size_t stride, const T* vol, 
   t8gpu_hip::Range whole("t8gpu.iterate_steps (exchange -> ghost-reading tiles || interior tiles, two lanes)");
   Stepper::Lane& DL = S->deep_lane;
   Stepper::Lane& XL = S->comm_lane;
-  DL.stream = S->deep_stream ? S->deep_stream : s;
+  DL.stream = s;
   XL.stream = S->comm_stream;
   DL.recorded.store(0, std::memory_order_relaxed);
   XL.recorded.store(0, std::memory_order_relaxed);
@@ -789,6 +788,8 @@ static int stepper_halo_setup(Stepper* S, const T8gpuHalo* halo) {
     // Normal priority on purpose: a high-priority comm stream was measured (rocprofv3 kernel trace, one rank
     // of the 8-way c4 split) to make everything slower -- tile kernels 49 -> 90-150 us, the 5 us pack / unpack
     // kernels up to 90 us, 50 us gaps -- the queue preempts the running tile waves instead of waiting for a slot.
+    // (round 4, two-lane driver: the highest stream priority for the comm lane changes nothing -- 0.1521 / 0.1522 ms per step on
+    //  rank 3 of the 8-way c4 split)
     hipError_t e = hipStreamCreateWithFlags(&S->comm_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_state, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_ghost, hipEventDisableTiming);
@@ -806,20 +807,9 @@ static int stepper_halo_setup(Stepper* S, const T8gpuHalo* halo) {
     if (e != hipSuccess) return static_cast<int>(e);
     const char* th = std::getenv("T8GPU_STEPPER_THREADS");
     S->threads     = !(th && th[0] == '0');
-    // T8GPU_COMM_CUS=n (measurements): the deep tiles run on a stream of their own whose CU mask leaves n compute units to
-    // the comm lane (the RCCL kernel is a few workgroups that crawl when they share their CU with tile waves)
-    if (const char* cus = std::getenv("T8GPU_COMM_CUS")) {
-      const int       n = std::atoi(cus);
-      int             dev = 0;
-      hipDeviceProp_t prop;
-      if (n > 0 && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && n < prop.multiProcessorCount) {
-        const int             total = prop.multiProcessorCount;
-        std::vector<uint32_t> mask((total + 31) / 32, 0u);
-        for (int c = 0; c < total - n; c++) mask[c / 32] |= 1u << (c % 32);
-        e = hipExtStreamCreateWithCUMask(&S->deep_stream, static_cast<uint32_t>(mask.size()), mask.data());
-        if (e != hipSuccess) return static_cast<int>(e);
-      }
-    }
+    // (Measured and dropped: the interior tiles on a stream whose CU mask leaves 8 or 16 compute units to the comm lane
+    //  (hipExtStreamCreateWithCUMask) -- 0.200 instead of 0.168 ms per step with the three-class lanes; such a stream is also a
+    //  blocking one, which serialises it with the legacy default stream most callers use.)
     // the ghost window (t8gpu_hip.h): plain elements through the tile / 2D patch kernels
     const char* gw = std::getenv("T8GPU_GHOST_WINDOW");
     if (!S->subgrid && halo->cells_per_element <= 1 && S->plan.patch_dim != 3 && halo->n_send > 0 && halo->num_elements > 0 &&
@@ -915,7 +905,6 @@ int t8gpu_hip_plain_stepper_destroy(void* h) {
     for (hipEvent_t e : L->ring)
       if (e) (void)hipEventDestroy(e);
   }
-  if (S->deep_stream) (void)hipStreamDestroy(S->deep_stream);
   if (S->d_send_map) (void)hipFree(S->d_send_map);
   if (S->d_send_list) (void)hipFree(S->d_send_list);
   for (hipEvent_t e : S->pool) (void)hipEventDestroy(e);
