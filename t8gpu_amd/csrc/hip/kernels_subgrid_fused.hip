@@ -630,7 +630,17 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_subgrid_family(
     // (the far cell's primitives only now: five state words instead of nine primitives live during the + passes)
     const CellData<T, KIND> there = cell_from_state<T, KIND>(xst);
     T g[5];
-    cell_flux<T, KIND>(there, here, x_wall, xd, !x_wall, area_of(xrow.z, xrow.w, T(0)) / T(16), g);
+    // A pooled round is 64 consecutive slots = the four faces of ONE axis (slot = (d * 4 + j) * 16 + sub-face, wave w takes
+    // slots 64 (w - 3) ...): the axis is wave-uniform, w - 3. Said so, the flux is evaluated with a compile-time axis behind a
+    // scalar branch instead of per-lane component selects (round 4; ~40 selects less per - wavefront, c3 within +-0.3 %).
+    const T   xarea = area_of(xrow.z, xrow.w, T(0)) / T(16);
+    const int xdu   = w - 3;
+    if (xdu == 0)
+      cell_flux<T, KIND>(there, here, x_wall, 0, !x_wall, xarea, g);
+    else if (xdu == 1)
+      cell_flux<T, KIND>(there, here, x_wall, 1, !x_wall, xarea, g);
+    else
+      cell_flux<T, KIND>(there, here, x_wall, 2, !x_wall, xarea, g);
     const T sgn = x_wall ? T(-1) : T(1);
     block_sync<true>();   // (this wavefront's last reads of its exchange slice are behind it)
 #pragma unroll
@@ -661,6 +671,16 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_subgrid_family(
 #pragma unroll
   for (int k = 0; k < 5; k++) at<WIDE>(out.p[k], o) = rk_stage_update<T, STAGE>(pv[k], s0[k], scale, acc[k]);
 }
+
+// (Round 4, measured and dropped: a PERSISTENT form of this kernel -- a resident grid of 2 (fp64) / 3 (fp32) workgroups per CU
+// walking the cubes of their XCD's share, the next cube's record rows as scalar loads at the top of an iteration, its own state,
+// pooled far cells and previous-step state requested after the - round, behind this cube's previous-step loads. Bitwise the
+// kernel above (it ran through test_family_kernel_and_block_kernel_agree_bitwise on grids of 3, 21 and 512 workgroups), and
+// much slower: c3 fp64 7 910 -> 4 610, fp32 17 200 -> 13 030 M subcell-updates/s. The loop-carried state -- lane constants
+// of the pooled rounds, the next cube's rows, its 10 + 10 (+ 10) state words -- does not fit beside the 126 / 72 VGPRs of the
+// flux passes: 128 / 80 VGPRs with 80 / 50 dwords of scratch spill and 100 SGPRs with ~160 lane spills, and the reloads sit
+// in the in-order vmcnt queue behind the prefetch. Fetching the own state a second time for the RK update (ten registers
+// less through the passes) did not remove a single spill. The block kernel's persistent form of round 2 failed the same way.)
 
 // ---------------------------------------------------------------------------------------------------------------
 // Family kernel, RANK 2: one wavefront = a 2x2 square of consecutive same-level Subgrid<4,4> blocks (lanes 16 w .. 16 w + 15
