@@ -78,10 +78,7 @@ namespace t8gpu::hip {
                    volume, delta_t, stream);
   }
 
-  /// What the halo exchange needs besides HostMeshArrays (peers ascending; offsets have n_peers + 1 entries).
-  struct HostHaloArrays {
-    std::vector<int32_t> peers, recv_off, send_off, send_idx;
-  };
+  using t8gpu::HostHaloArrays;   // (t8gpu/mesh/mesh_manager.h: what the halo exchange needs besides HostMeshArrays)
 
   /// the connectivity of one rank from forest-query callbacks (csrc/host/connectivity.cpp): the
   /// arrays a MeshManager's compute_connectivity_information hands to this backend.

@@ -20,6 +20,7 @@
 #ifndef T8GPU_HIP_MESH_MESH_MANAGER_H
 #define T8GPU_HIP_MESH_MESH_MANAGER_H
 
+#include <t8gpu/backend/transport.h>
 #include <t8gpu/memory/memory_manager.h>
 
 #include <t8gpu_hip.h>
@@ -124,6 +125,12 @@ namespace t8gpu {
     std::vector<int32_t> levels;          // [N]
   };
 
+  /// What the ghost layer needs besides HostMeshArrays (peers ascending; offsets have n_peers + 1 entries; send_idx = owned
+  /// elements mirrored on a peer; the ghosts of peer j are the mirror slots N + [recv_off[j], recv_off[j + 1])).
+  struct HostHaloArrays {
+    std::vector<int32_t> peers, recv_off, send_off, send_idx;
+  };
+
   /// T8_VTK_SCALAR / T8_VTK_VECTOR of t8code's t8_vtk_data_field_t: values per cell
   enum : int { T8GPU_VTK_SCALAR = 1, T8GPU_VTK_VECTOR = 3 };
 
@@ -160,8 +167,7 @@ namespace t8gpu {
     /// From host arrays in the reference's formats (one rank's share; ghosts resolved to mirror slots).
     explicit MeshManager(HostMeshArrays const& m, sc_MPI_Comm comm = sc_MPI_COMM_WORLD)
         : MemoryManager<VariableType, StepType>(static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements, comm) {
-      int comm_rank = 0;
-      detail::comm_layout(comm, comm_rank, m_nb_ranks);
+      detail::comm_layout(comm, m_comm_rank, m_nb_ranks);
       rebuild_connectivity(m);
       this->set_volume(std::vector<float_type>(m.volumes.begin(), m.volumes.end()));
     }
@@ -169,13 +175,19 @@ namespace t8gpu {
     /// MeshManager(comm, scheme, cmesh, forest) (mesh_manager.inl:3-44). The connectivity comes through the
     /// forest-query adapter (csrc/host/connectivity.cpp), i.e. the way a t8code build would provide it.
     /// `lowest_level` / `highest_level` bound adapt() (the class constants min_level / max_level by default).
+    /// On several ranks (comm.size > 1) every rank passes ITS OWN handle of the same forest (the description is replicated,
+    /// as in t8gpu_amd/amr.py) and owns the contiguous share [n r / size, n (r + 1) / size) of the space-filling curve;
+    /// set_transport() must follow before adapt() / partition() / refresh_ghost_layer() are called.
     explicit MeshManager(void* synth_mesh, int lowest_level = min_level, int highest_level = max_level,
                          sc_MPI_Comm comm = sc_MPI_COMM_WORLD)
-        : MeshManager(arrays_of(synth_mesh), comm) {
+        : MeshManager(arrays_of(synth_mesh, comm_rank_of(comm), comm_size_of(comm), nullptr), comm) {
       m_forest    = synth_mesh;
       m_min_level = lowest_level;
       m_max_level = highest_level;
+      if (m_nb_ranks > 1) rebuild_connectivity(arrays_of(m_forest, m_comm_rank, m_nb_ranks, &m_halo_host));   // (+ the halo lists)
     }
+    /// The channel adapt() / partition() / refresh_ghost_layer() use on several ranks (not owned). See backend/transport.h.
+    void set_transport(Transport* transport) { m_transport = transport; }
 
     /// mesh_manager.inl:76-122: `func(accessor, forest, tree_idx, element, e_idx)` fills the variables of element
     /// e_idx in a HOST accessor; all 26 planes are zeroed, Step 0 and the volume uploaded. With the synthetic provider
@@ -216,19 +228,91 @@ namespace t8gpu {
       adapt(std::vector<float_type>(refinement_criteria.begin(), refinement_criteria.end()), step);
     }
 
-    /// mesh_manager.inl:626-723. One process drives one GPU and, in this header-level API, one rank's share that was
-    /// partitioned when the arrays were made. On a single rank t8_forest_partition is the identity. On several ranks it
-    /// is the identity as well HERE: this class can only adapt a mesh it holds a forest of (single rank, see adapt()), so
-    /// a multi-rank mesh still is the balanced SFC split it was constructed with and there is nothing to move -- the call
-    /// keeps `step` and returns, as the reference's does when no element changes owner. (Adapt + SFC repartition of a
-    /// multi-rank run over RCCL exists above the C-ABI in t8gpu_amd/amr.py: PartitionedAdapt; INTEGRATION.md section 5
-    /// states the limitation. Round 2 aborted here, which killed reference-style main loops at N > 1: ADVICE r2.)
-    void partition(step_index_type /*step*/) {}
+    /// mesh_manager.inl:626-723. After adapt() the elements a rank holds are no longer its equal share of the curve;
+    /// partition() ships every run of adapted elements to its owner in the new equal split (t8gpu_hip_repartition_*: the
+    /// old owner sends, where the reference's new owner pulls through CUDA-IPC pointers, partition_data<<<>>> :626-643),
+    /// installs the new forest and rebuilds the connectivity. Only `step` and the volume are valid afterwards, as in the
+    /// reference. On one rank, or when no adapt() is pending, it is the identity (t8_forest_partition moves nothing).
+    void partition(step_index_type step) {
+      if (!m_pending.forest) return;
+      if (!m_transport) {
+        std::fprintf(stderr, "t8gpu: partition() on %d ranks needs a transport (MeshManager::set_transport)\n", m_nb_ranks);
+        std::abort();
+      }
+      const int     R = m_nb_ranks, r = m_comm_rank;
+      const int64_t n_new = t8gpu_synth_mesh_num_elements(m_pending.forest);
+      auto off = [&](int q) { return n_new * q / R; };                                   // the equal split of the NEW curve
+      const int64_t a = m_pending.have_off[r], b = m_pending.have_off[r + 1], lo = off(r), hi = off(r + 1);
+      std::vector<int32_t> sp, sf, sc, rp, rf, rc;
+      for (int q = 0; q < R; q++) {
+        const int64_t s0 = std::max(a, off(q)), s1 = std::min(b, off(q + 1));
+        if (s1 > s0) { sp.push_back(q); sf.push_back(static_cast<int32_t>(s0 - a)); sc.push_back(static_cast<int32_t>(s1 - s0)); }
+        const int64_t r0 = std::max(m_pending.have_off[q], lo), r1 = std::min(m_pending.have_off[q + 1], hi);
+        if (r1 > r0) { rp.push_back(q); rf.push_back(static_cast<int32_t>(r0 - lo)); rc.push_back(static_cast<int32_t>(r1 - r0)); }
+      }
+      // the new share's connectivity first: it says how many ghost slots the planes need
+      HostHaloArrays halo;
+      HostMeshArrays m = arrays_of(m_pending.forest, r, R, &halo);
+      this->resize(static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements);
+      const int32_t   nh = static_cast<int32_t>(b - a);
+      float_type*     t  = m_pending.tmp;
+      auto vars = [](float_type* const p[5]) {
+        if constexpr (std::is_same_v<float_type, double>) { T8gpuVars_f64 v; for (int k = 0; k < 5; k++) v.p[k] = p[k]; return v; }
+        else { T8gpuVars_f32 v; for (int k = 0; k < 5; k++) v.p[k] = p[k]; return v; }
+      };
+      float_type* src[5];
+      float_type* dst[5];
+      for (int k = 0; k < 5; k++) {
+        src[k] = t + static_cast<size_t>(k) * std::max(nh, 1);
+        dst[k] = this->get_own_variable(step, static_cast<variable_index_type>(k));
+      }
+      m_transport->repartition(static_cast<int>(sp.size()), sp.data(), sf.data(), sc.data(), static_cast<int>(rp.size()), rp.data(), rf.data(),
+                               rc.data(), vars(src), t + 5 * static_cast<size_t>(std::max(nh, 1)), vars(dst), this->get_own_volume(), 1);
+      (void)hipFree(m_pending.tmp);
+      t8gpu_synth_mesh_destroy(m_forest);
+      m_forest  = m_pending.forest;
+      m_pending = Pending{};
+      m_halo_host = std::move(halo);
+      rebuild_connectivity(m);
+      // the volumes of the ghost slots come with the connectivity (the owned ones arrived with the elements)
+      if (m.num_ghost_elements > 0) {
+        std::vector<float_type> gv(m.volumes.begin() + m.num_local_elements, m.volumes.end());
+        T8GPU_CUDA_CHECK_ERROR(hipMemcpy(this->get_own_volume() + m.num_local_elements, gv.data(), sizeof(float_type) * gv.size(), hipMemcpyHostToDevice));
+      }
+    }
+
+    /// Refresh the ghost mirror slots [N, N + G) of the five planes of `step` from their owners (several ranks only; a
+    /// no-op on one). The reference needs no such call: a ghost is read through the owner's CUDA-IPC pointer
+    /// (kernels.cu:164-168). Kernels that read ghost values outside iterate() -- estimate_gradient of the adapt criterion,
+    /// solver.cu:245-263 -- call it first; the step drivers refresh what they read themselves.
+    void refresh_ghost_layer(step_index_type step) {
+      if (m_nb_ranks <= 1 || m_halo_host.peers.empty()) return;
+      if (!m_transport) {
+        std::fprintf(stderr, "t8gpu: refresh_ghost_layer() on %d ranks needs a transport (MeshManager::set_transport)\n", m_nb_ranks);
+        std::abort();
+      }
+      T8gpuHalo h{};
+      h.num_elements = m_num_local_elements; h.num_ghosts = m_num_ghost_elements;
+      h.n_peers = static_cast<int32_t>(m_halo_host.peers.size()); h.n_send = static_cast<int32_t>(m_halo_host.send_idx.size());
+      h.cells_per_element = 1;
+      h.peers = m_halo_host.peers.data(); h.send_off = m_halo_host.send_off.data(); h.recv_off = m_halo_host.recv_off.data();
+      h.send_idx = m_d_send_idx; h.sendbuf = m_d_sendbuf; h.recvbuf = m_d_recvbuf;
+      if constexpr (std::is_same_v<float_type, double>) {
+        T8gpuVars_f64 v; for (int k = 0; k < 5; k++) v.p[k] = this->get_own_variable(step, static_cast<variable_index_type>(k));
+        m_transport->halo_exchange(h, v);
+      } else {
+        T8gpuVars_f32 v; for (int k = 0; k < 5; k++) v.p[k] = this->get_own_variable(step, static_cast<variable_index_type>(k));
+        m_transport->halo_exchange(h, v);
+      }
+    }
+    [[nodiscard]] HostHaloArrays const& host_halo() const { return m_halo_host; }
+    [[nodiscard]] int comm_rank() const { return m_comm_rank; }
+    [[nodiscard]] int comm_size() const { return m_nb_ranks; }
 
     /// mesh_manager.inl:333-481: face lists, normals, areas, ghost slots of the current forest -> device arrays.
     /// adapt() already leaves them current; calling this again is harmless (the reference requires the call).
     void compute_connectivity_information() {
-      if (m_forest) rebuild_connectivity(arrays_of(m_forest));
+      if (m_forest) rebuild_connectivity(arrays_of(m_forest, m_comm_rank, m_nb_ranks, m_nb_ranks > 1 ? &m_halo_host : nullptr));
     }
 
     /// MeshManager::adapt (mesh_manager.inl:196-330), single rank: the reference's adapt callback on the criteria
@@ -239,6 +323,10 @@ namespace t8gpu {
       if (!m_forest) {
         std::fprintf(stderr, "t8gpu: adapt() needs a manager constructed from a forest\n");
         std::abort();
+      }
+      if (m_nb_ranks > 1) {
+        adapt_partitioned(refinement_criteria, step, threshold);
+        return;
       }
       const int32_t n_old = m_num_local_elements;
       std::vector<double> crit(refinement_criteria.begin(), refinement_criteria.end());
@@ -285,13 +373,92 @@ namespace t8gpu {
       (void)hipFree(d_tmp);
       t8gpu_synth_mesh_destroy(m_forest);
       m_forest = new_forest;
-      rebuild_connectivity(arrays_of(m_forest));
+      rebuild_connectivity(arrays_of(m_forest, 0, 1, nullptr));
     }
+
+   private:
+    /// adapt() on several ranks (t8gpu_amd/amr.py: PartitionedAdapt, the same scheme in C++): the forest description is
+    /// replicated, so the criteria of all ranks are gathered, every rank evaluates the reference's adapt callback on the whole
+    /// array (families cut by a rank boundary are not coarsened: their members' data live on two ranks), adapts the forest,
+    /// and transfers ITS OWN elements on the device (adapt_variables_and_volume) into temporary planes. The result is what the
+    /// reference holds after its adapt(): adapted elements on their old owners. partition() then ships them.
+    void adapt_partitioned(std::vector<float_type> const& refinement_criteria, step_index_type step, double threshold) {
+      if (!m_transport) {
+        std::fprintf(stderr, "t8gpu: adapt() on %d ranks needs a transport (MeshManager::set_transport)\n", m_nb_ranks);
+        std::abort();
+      }
+      if (m_pending.forest) {   // adapt() twice without partition(): drop the first
+        t8gpu_synth_mesh_destroy(m_pending.forest);
+        (void)hipFree(m_pending.tmp);
+        m_pending = Pending{};
+      }
+      const int     R = m_nb_ranks, r = m_comm_rank;
+      const int64_t n_glob = t8gpu_synth_mesh_num_elements(m_forest);
+      std::vector<int64_t> old_off(static_cast<size_t>(R) + 1);
+      for (int q = 0; q <= R; q++) old_off[q] = n_glob * q / R;
+      const int64_t n_mine = old_off[r + 1] - old_off[r];
+      if (static_cast<int64_t>(refinement_criteria.size()) < n_mine) std::abort();
+      // 1. all criteria on every rank
+      std::vector<double> mine(refinement_criteria.begin(), refinement_criteria.begin() + n_mine), all(static_cast<size_t>(n_glob));
+      double *d_mine = nullptr, *d_all = nullptr;
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&d_mine, sizeof(double) * std::max<int64_t>(n_mine, 1)));
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&d_all, sizeof(double) * std::max<int64_t>(n_glob, 1)));
+      T8GPU_CUDA_CHECK_ERROR(hipMemcpy(d_mine, mine.data(), sizeof(double) * n_mine, hipMemcpyHostToDevice));
+      m_transport->allgatherv(d_mine, d_all, old_off.data());
+      T8GPU_CUDA_CHECK_ERROR(hipMemcpy(all.data(), d_all, sizeof(double) * n_glob, hipMemcpyDeviceToHost));
+      (void)hipFree(d_mine);
+      (void)hipFree(d_all);
+      // 2. the adapt callback on the whole forest, families split by a rank boundary left alone; the new forest
+      std::vector<int8_t> marks(static_cast<size_t>(n_glob));
+      t8gpu_synth_mesh_marks(m_forest, all.data(), threshold, m_min_level, m_max_level, 4, marks.data());
+      t8gpu_synth_mesh_unmark_split_families(m_forest, marks.data(), old_off.data() + 1, R - 1);
+      void* new_forest = t8gpu_synth_mesh_adapt(m_forest, marks.data());
+      if (!new_forest) {
+        std::fprintf(stderr, "t8gpu: forest adaptation failed\n");
+        std::abort();
+      }
+      const int64_t        n_new = t8gpu_synth_mesh_num_elements(new_forest);
+      std::vector<int32_t> adapt_data(static_cast<size_t>(n_new) + 1);
+      if (t8gpu_synth_mesh_adapt_data(m_forest, new_forest, adapt_data.data()) != 0) std::abort();
+      // new elements made from rank q's old elements: [have_off[q], have_off[q + 1])
+      m_pending.have_off.assign(static_cast<size_t>(R) + 1, n_new);
+      for (int q = 0; q < R; q++)
+        m_pending.have_off[q] = std::lower_bound(adapt_data.begin(), adapt_data.begin() + n_new, static_cast<int32_t>(old_off[q])) - adapt_data.begin();
+      const int64_t a = m_pending.have_off[r], b = m_pending.have_off[r + 1];
+      const int32_t nh = static_cast<int32_t>(b - a);
+      // 3. this rank's elements through the data-transfer kernel into 5 + 1 temporary planes of nh values
+      std::vector<int32_t> local(static_cast<size_t>(nh) + 1);
+      for (int32_t i = 0; i <= nh; i++) local[i] = adapt_data[a + i] - static_cast<int32_t>(old_off[r]);
+      int32_t* d_ad = nullptr;
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&d_ad, sizeof(int32_t) * local.size()));
+      T8GPU_CUDA_CHECK_ERROR(hipMemcpy(d_ad, local.data(), sizeof(int32_t) * local.size(), hipMemcpyHostToDevice));
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_pending.tmp, sizeof(float_type) * 6 * static_cast<size_t>(std::max(nh, 1))));
+      auto old_vars = this->get_own_variables(step);
+      if (nh > 0) {
+        float_type* t = m_pending.tmp;
+        if constexpr (std::is_same_v<float_type, double>) {
+          T8gpuVars_f64 o, n;
+          for (int k = 0; k < 5; k++) { o.p[k] = old_vars.get(k); n.p[k] = t + static_cast<size_t>(k) * nh; }
+          T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_adapt_variables_and_volume_f64(nh, static_cast<int>(m_mesh_dim), d_ad, o, n, this->get_own_volume(), t + 5 * static_cast<size_t>(nh), nullptr)));
+        } else {
+          T8gpuVars_f32 o, n;
+          for (int k = 0; k < 5; k++) { o.p[k] = old_vars.get(k); n.p[k] = t + static_cast<size_t>(k) * nh; }
+          T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(t8gpu_hip_adapt_variables_and_volume_f32(nh, static_cast<int>(m_mesh_dim), d_ad, o, n, this->get_own_volume(), t + 5 * static_cast<size_t>(nh), nullptr)));
+        }
+      }
+      T8GPU_CUDA_CHECK_ERROR(hipDeviceSynchronize());
+      (void)hipFree(d_ad);
+      m_pending.forest = new_forest;
+    }
+
+   public:
     [[nodiscard]] void const* forest() const { return m_forest; }
     [[nodiscard]] HostMeshArrays const& host_arrays() const { return m_host; }
 
     ~MeshManager() {
       if (m_forest) t8gpu_synth_mesh_destroy(m_forest);
+      if (m_pending.forest) t8gpu_synth_mesh_destroy(m_pending.forest);
+      (void)hipFree(m_pending.tmp);
       free_connectivity();
       (void)hipFree(m_staging);
     }
@@ -376,8 +543,20 @@ namespace t8gpu {
 
     /// HostMeshArrays of a synthetic forest on one rank: connectivity through the forest-query adapter, plus the
     /// leaf geometry the VTK members need
-    static HostMeshArrays arrays_of(void* forest) {
-      T8gpuForestQuery* q = t8gpu_synth_query_create(forest, 0, 1);
+    static int comm_rank_of(sc_MPI_Comm comm) {
+      int r = 0, n = 1;
+      detail::comm_layout(comm, r, n);
+      return r;
+    }
+    static int comm_size_of(sc_MPI_Comm comm) {
+      int r = 0, n = 1;
+      detail::comm_layout(comm, r, n);
+      return n;
+    }
+    /// rank `rank` of `nranks`' share of the forest in the reference's array formats, through the forest-query adapter
+    /// (csrc/host/connectivity.cpp) -- the way a t8code build would provide it; `halo` (nullable) receives the ghost lists
+    static HostMeshArrays arrays_of(void* forest, int rank, int nranks, HostHaloArrays* halo) {
+      T8gpuForestQuery* q = t8gpu_synth_query_create(forest, rank, nranks);
       void*             h = q ? t8gpu_host_connectivity_create(q) : nullptr;
       if (!h) {
         std::fprintf(stderr, "t8gpu: connectivity of the synthetic forest could not be built\n");
@@ -388,12 +567,16 @@ namespace t8gpu {
       HostMeshArrays m;
       m.num_local_elements = static_cast<int32_t>(c[0]); m.num_ghost_elements = static_cast<int32_t>(c[1]);
       m.num_local_faces = static_cast<int32_t>(c[2]); m.num_local_boundary_faces = static_cast<int32_t>(c[3]);
+      m.rank = rank;
       m.face_neighbors.resize(2 * c[2] + c[3]);
       m.face_normals.resize(3 * (c[2] + c[3]));
       m.face_surfaces.resize(c[2] + c[3]);
       m.volumes.resize(c[0] + c[1]);
-      t8gpu_host_connectivity_arrays(h, m.face_neighbors.data(), m.face_normals.data(), m.face_surfaces.data(), m.volumes.data(), nullptr,
-                                     nullptr, nullptr, nullptr);
+      HostHaloArrays hh;
+      hh.peers.resize(c[4]); hh.recv_off.resize(c[4] + 1); hh.send_off.resize(c[4] + 1); hh.send_idx.resize(c[5]);
+      t8gpu_host_connectivity_arrays(h, m.face_neighbors.data(), m.face_normals.data(), m.face_surfaces.data(), m.volumes.data(),
+                                     hh.peers.data(), hh.recv_off.data(), hh.send_off.data(), hh.send_idx.data());
+      if (halo) *halo = std::move(hh);
       t8gpu_host_connectivity_destroy(h);
       t8gpu_synth_query_destroy(q);
       if constexpr (dim != 3) {   // the adapter hands out xyz; MeshConnectivityAccessor<ft, dim> strides by `dim`
@@ -404,15 +587,23 @@ namespace t8gpu {
           for (size_t k = 0; k < dim; k++) nd[dim * i + k] = m.face_normals[3 * i + k];
         m.face_normals.swap(nd);
       }
-      void* part = t8gpu_synth_part_create(forest, 0, 1, 0, 3);
+      void* part = t8gpu_synth_part_create(forest, rank, nranks, 0, 3);
       m.mesh_dim = t8gpu_synth_mesh_dim(forest);
+      m.first_global_element = t8gpu_synth_mesh_num_elements(forest) * rank / nranks;
+      m.levels.resize(c[0] + c[1]);           // (the provider lists owned + ghost elements; the manager keeps the owned ones)
+      m.centres.resize(3 * (c[0] + c[1]));
+      t8gpu_synth_part_elements(part, m.levels.data(), nullptr, m.centres.data());
       m.levels.resize(c[0]);
       m.centres.resize(3 * c[0]);
-      t8gpu_synth_part_elements(part, m.levels.data(), nullptr, m.centres.data());
       t8gpu_synth_part_destroy(part);
       return m;
     }
     void free_connectivity() {
+      (void)hipFree(m_d_send_idx);
+      (void)hipFree(m_d_sendbuf);
+      (void)hipFree(m_d_recvbuf);
+      m_d_send_idx = nullptr;
+      m_d_sendbuf = m_d_recvbuf = nullptr;
       (void)hipFree(m_ranks);
       (void)hipFree(m_indices);
       (void)hipFree(m_face_neighbors);
@@ -440,8 +631,25 @@ namespace t8gpu {
       upload(m_face_neighbors, m.face_neighbors);
       upload(m_face_normals, std::vector<float_type>(m.face_normals.begin(), m.face_normals.end()));
       upload(m_face_surfaces, std::vector<float_type>(m.face_surfaces.begin(), m.face_surfaces.end()));
+      if (m_nb_ranks > 1 && !m_halo_host.peers.empty()) {   // device side of refresh_ghost_layer()
+        upload(m_d_send_idx, m_halo_host.send_idx);
+        T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_d_sendbuf, sizeof(float_type) * (5 * m_halo_host.send_idx.size() + 1)));
+        T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_d_recvbuf, sizeof(float_type) * (5 * static_cast<size_t>(m.num_ghost_elements) + 1)));
+      }
     }
 
+    // several ranks: the channel, the ghost lists of the current share, and what adapt() leaves for partition()
+    Transport*     m_transport = nullptr;
+    int            m_comm_rank = 0;
+    HostHaloArrays m_halo_host;
+    int32_t*       m_d_send_idx = nullptr;
+    float_type*    m_d_sendbuf  = nullptr;
+    float_type*    m_d_recvbuf  = nullptr;
+    struct Pending {
+      void*                forest = nullptr;   // the adapted forest (replicated)
+      float_type*          tmp    = nullptr;   // 5 + 1 planes of (have_off[r + 1] - have_off[r]) adapted elements of this rank
+      std::vector<int64_t> have_off;           // new elements made from rank q's old ones: [have_off[q], have_off[q + 1])
+    } m_pending;
     int                  m_rank = 0, m_mesh_dim = 2;
     int64_t              m_first_global = 0;
     std::vector<double>  m_centres;

@@ -418,6 +418,29 @@ int t8gpu_hip_gather_elements_f64(int n, int first, T8gpuVars_f64 variables, con
 int t8gpu_hip_scatter_elements_f32(int n, int first, const float* in, T8gpuVars_f32 variables, float* volume, void* stream);
 int t8gpu_hip_scatter_elements_f64(int n, int first, const double* in, T8gpuVars_f64 variables, double* volume, void* stream);
 
+/* MeshManager::partition / SubgridMeshManager::partition, device half, over RCCL (mesh_manager.inl:626-723,
+ * subgrid_mesh_manager.inl:1217-1369): the reference's new owner PULLS an element's variables through CUDA-IPC pointers
+ * (partition_data<<<>>>), here the old owner SENDS. Elements move in contiguous runs of the space-filling curve; run j of the
+ * send list = elements [send_first[j], + send_count[j]) of the five `src` planes and of `src_volume` (cells_per_element
+ * values per element and variable, one volume per element) to rank send_peer[j]; the receive list likewise into `dst` /
+ * `dst_volume`. Six messages per run straight between the planes, one RCCL group per call; runs whose peer is `my_rank` are
+ * device copies (the i-th such send pairs with the i-th such receive) and `comm` may be NULL if there are no others.
+ * All index arrays on the HOST. Collective over the ranks that exchange runs. */
+int t8gpu_hip_repartition_f32(void* comm, int my_rank, int n_send, const int32_t* send_peer, const int32_t* send_first,
+                              const int32_t* send_count, int n_recv, const int32_t* recv_peer, const int32_t* recv_first,
+                              const int32_t* recv_count, T8gpuVars_f32 src, const float* src_volume, T8gpuVars_f32 dst,
+                              float* dst_volume, int cells_per_element, void* stream);
+int t8gpu_hip_repartition_f64(void* comm, int my_rank, int n_send, const int32_t* send_peer, const int32_t* send_first,
+                              const int32_t* send_count, int n_recv, const int32_t* recv_peer, const int32_t* recv_first,
+                              const int32_t* recv_count, T8gpuVars_f64 src, const double* src_volume, T8gpuVars_f64 dst,
+                              double* dst_volume, int cells_per_element, void* stream);
+/* every rank's chunk mine[offsets[rank + 1] - offsets[rank]] of a distributed array of doubles to every rank's
+ * all[offsets[nranks]] (device pointers, offsets on the host): how the refinement criteria of a partitioned adapt travel
+ * (the reference's adapt callback reads per-element criteria of its own rank; with a replicated forest description every
+ * rank evaluates it on the whole array). Collective. */
+int t8gpu_hip_comm_allgatherv_f64(void* comm, int rank, int nranks, const double* mine, double* all, const int64_t* offsets,
+                                  void* stream);
+
 /* ---- AMR indicator and data transfer for Subgrid<4,4> / Subgrid<4,4,4> blocks -------------
  * compute_refinement_criteria<Subgrid><<<>>>: examples/subgrid/kernels.inl:1110-1168 (discrete H1 seminorm of the
  * density inside a block / block volume). */

@@ -709,6 +709,56 @@ int iterate_graph(Stepper* S, int kind, T* planes, size_t stride, const T* vol, 
   return 0;
 }
 
+
+// ---- MeshManager::partition over RCCL ------------------------------------------------------------------------
+// The device half of the reference's partition() (t8gpu/mesh/mesh_manager.inl:626-723, subgrid_mesh_manager.inl:1217-1369):
+// there the new owner of an element PULLS its variables through CUDA-IPC pointers into the old owner's memory
+// (partition_data<<<>>>); here the old owner SENDS. Elements move in contiguous runs of the space-filling curve, and a run is
+// contiguous in every variable plane and in the volume array, so a run is six messages straight from the source planes into
+// the destination planes -- no gather kernel, no staging buffer. One RCCL group for all runs of a call; a run whose peer is
+// this rank is a device copy.
+template <class T, class V>
+int repartition(void* comm, int my_rank, int n_send, const int32_t* send_peer, const int32_t* send_first, const int32_t* send_count,
+                int n_recv, const int32_t* recv_peer, const int32_t* recv_first, const int32_t* recv_count, V src, const T* src_vol, V dst,
+                T* dst_vol, int cells, hipStream_t s) {
+  if (cells < 1 || n_send < 0 || n_recv < 0) return static_cast<int>(hipErrorInvalidValue);
+  const size_t w = static_cast<size_t>(cells);
+  // runs that stay on this rank: the i-th local send pairs with the i-th local receive (both lists are in curve order)
+  int js = 0;
+  for (int jr = 0; jr < n_recv; jr++) {
+    if (recv_peer[jr] != my_rank) continue;
+    while (js < n_send && send_peer[js] != my_rank) js++;
+    if (js >= n_send || send_count[js] != recv_count[jr]) return static_cast<int>(hipErrorInvalidValue);
+    const size_t n = static_cast<size_t>(recv_count[jr]);
+    for (int k = 0; k < 5; k++)
+      T8_HIP_TRY(hipMemcpyAsync(dst.p[k] + w * recv_first[jr], src.p[k] + w * send_first[js], sizeof(T) * w * n, hipMemcpyDeviceToDevice, s));
+    T8_HIP_TRY(hipMemcpyAsync(dst_vol + recv_first[jr], src_vol + send_first[js], sizeof(T) * n, hipMemcpyDeviceToDevice, s));
+    js++;
+  }
+  bool remote = false;
+  for (int j = 0; j < n_send; j++) remote = remote || send_peer[j] != my_rank;
+  for (int j = 0; j < n_recv; j++) remote = remote || recv_peer[j] != my_rank;
+  if (!remote) return 0;
+  if (!comm) return static_cast<int>(hipErrorInvalidValue);
+#ifndef T8GPU_EXP_NO_RCCL
+  ncclComm_t c = static_cast<ncclComm_t>(comm);
+  T8_TRY(nccl_code(ncclGroupStart()));
+  for (int j = 0; j < n_recv; j++) {
+    if (recv_peer[j] == my_rank || recv_count[j] <= 0) continue;
+    const size_t n = static_cast<size_t>(recv_count[j]);
+    for (int k = 0; k < 5; k++) T8_TRY(nccl_code(ncclRecv(dst.p[k] + w * recv_first[j], w * n, nccl_type<T>(), recv_peer[j], c, s)));
+    T8_TRY(nccl_code(ncclRecv(dst_vol + recv_first[j], n, nccl_type<T>(), recv_peer[j], c, s)));
+  }
+  for (int j = 0; j < n_send; j++) {
+    if (send_peer[j] == my_rank || send_count[j] <= 0) continue;
+    const size_t n = static_cast<size_t>(send_count[j]);
+    for (int k = 0; k < 5; k++) T8_TRY(nccl_code(ncclSend(src.p[k] + w * send_first[j], w * n, nccl_type<T>(), send_peer[j], c, s)));
+    T8_TRY(nccl_code(ncclSend(src_vol + send_first[j], n, nccl_type<T>(), send_peer[j], c, s)));
+  }
+  T8_TRY(nccl_code(ncclGroupEnd()));
+#endif
+  return 0;
+}
 }  // namespace
 
 extern "C" {
@@ -763,6 +813,45 @@ int t8gpu_hip_halo_exchange_f32(const T8gpuHalo* h, T8gpuVars_f32 state, void* s
 int t8gpu_hip_halo_exchange_f64(const T8gpuHalo* h, T8gpuVars_f64 state, void* stream) {
   if (!h) return static_cast<int>(hipErrorInvalidValue);
   return exchange<double, T8gpuVars_f64>(*h, h->peers, h->send_off, h->recv_off, state, static_cast<hipStream_t>(stream));
+}
+
+int t8gpu_hip_repartition_f32(void* comm, int my_rank, int n_send, const int32_t* send_peer, const int32_t* send_first,
+                              const int32_t* send_count, int n_recv, const int32_t* recv_peer, const int32_t* recv_first,
+                              const int32_t* recv_count, T8gpuVars_f32 src, const float* src_volume, T8gpuVars_f32 dst, float* dst_volume,
+                              int cells_per_element, void* stream) {
+  return repartition<float, T8gpuVars_f32>(comm, my_rank, n_send, send_peer, send_first, send_count, n_recv, recv_peer, recv_first, recv_count,
+                                           src, src_volume, dst, dst_volume, cells_per_element, static_cast<hipStream_t>(stream));
+}
+int t8gpu_hip_repartition_f64(void* comm, int my_rank, int n_send, const int32_t* send_peer, const int32_t* send_first,
+                              const int32_t* send_count, int n_recv, const int32_t* recv_peer, const int32_t* recv_first,
+                              const int32_t* recv_count, T8gpuVars_f64 src, const double* src_volume, T8gpuVars_f64 dst, double* dst_volume,
+                              int cells_per_element, void* stream) {
+  return repartition<double, T8gpuVars_f64>(comm, my_rank, n_send, send_peer, send_first, send_count, n_recv, recv_peer, recv_first, recv_count,
+                                            src, src_volume, dst, dst_volume, cells_per_element, static_cast<hipStream_t>(stream));
+}
+
+// Every rank's chunk of a distributed double array to every rank: mine[offsets[rank + 1] - offsets[rank]] -> all[offsets[nranks]]
+// (device pointers; offsets on the host). The refinement criteria of a partitioned adapt travel this way (the forest is
+// replicated, so every rank evaluates the adapt callback on the whole array).
+int t8gpu_hip_comm_allgatherv_f64(void* comm, int rank, int nranks, const double* mine, double* all, const int64_t* offsets, void* stream) {
+  if (!mine || !all || !offsets || rank < 0 || rank >= nranks) return static_cast<int>(hipErrorInvalidValue);
+  hipStream_t  s = static_cast<hipStream_t>(stream);
+  const size_t n = static_cast<size_t>(offsets[rank + 1] - offsets[rank]);
+  if (n) T8_HIP_TRY(hipMemcpyAsync(all + offsets[rank], mine, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+  if (nranks == 1) return 0;
+  if (!comm) return static_cast<int>(hipErrorInvalidValue);
+#ifndef T8GPU_EXP_NO_RCCL
+  ncclComm_t c = static_cast<ncclComm_t>(comm);
+  T8_TRY(nccl_code(ncclGroupStart()));
+  for (int q = 0; q < nranks; q++) {
+    if (q == rank) continue;
+    const size_t m = static_cast<size_t>(offsets[q + 1] - offsets[q]);
+    if (m) T8_TRY(nccl_code(ncclRecv(all + offsets[q], m, ncclDouble, q, c, s)));
+    if (n) T8_TRY(nccl_code(ncclSend(mine, n, ncclDouble, q, c, s)));
+  }
+  T8_TRY(nccl_code(ncclGroupEnd()));
+#endif
+  return 0;
 }
 
 // Polls a stream until it is idle or `timeout_s` elapsed (1 = timed out). Lets a caller bound the

@@ -38,6 +38,10 @@ def test_adapt_example_compiles():
     compile_example("adapt_example.hip", "adapt_example")
 
 
+def test_partition_example_compiles():
+    compile_example("partition_example.hip", "partition_example")
+
+
 def test_subgrid_api_compiles():
     compile_example("subgrid_api.hip", "subgrid_api")
 
@@ -97,6 +101,17 @@ def test_subgrid_api_runs(tmp_path):
     assert f["n_cells"] == v["n_cells"] and np.array_equal(f["arrays"]["density"], v["arrays"]["variables"])
     assert f["arrays"]["momentum"].shape == (f["n_cells"], 3)
     assert set(np.unique(f["arrays"]["momentum"][:, 0])) <= {-0.5, 0.5}
+
+
+@pytest.mark.gpu
+def test_partition_example_runs():
+    """MeshManager::adapt -> partition -> compute_connectivity_information on 2 and 3 ranks (host threads of one process, loopback
+    transport: tests/compat/loopback_transport.h) with fused steps in between: bitwise the single-rank run, shares balanced to one
+    element (t8gpu/mesh/mesh_manager.inl:196-330, 626-723). The product's transport is t8gpu::RcclTransport over the same interface
+    (t8gpu_hip_repartition_*, t8gpu_hip_comm_allgatherv_f64, t8gpu_hip_halo_exchange_*)."""
+    exe = compile_example("partition_example.hip", "partition_example")
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0 and "partition_example OK" in res.stdout, res.stdout + res.stderr
 
 
 @pytest.mark.gpu
