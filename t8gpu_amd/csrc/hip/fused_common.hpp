@@ -163,6 +163,11 @@ template <class T>
 int plain_patch3_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count, FVars<T> prev, FVars<T> mid,
                        FVars<T> out, const T* volume, T dt, T* speed, bool persistent, bool irregular, hipStream_t stream);
 
+// regular + irregular 3D patches of one class in one persistent launch (-1: launch them one after the other)
+template <class T>
+int plain_patch3_both_stage(int kind, int stage, const T8gpuPlainPlan* plan, int reg_begin, int reg_count, int irr_begin, int irr_count,
+                            FVars<T> prev, FVars<T> mid, FVars<T> out, const T* volume, T dt, T* speed, hipStream_t stream);
+
 }  // namespace t8gpu_hip
 
 #endif  // T8GPU_HIP_FUSED_COMMON_HPP

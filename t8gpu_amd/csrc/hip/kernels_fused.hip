@@ -293,6 +293,14 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
       if (ni < 0 || ni > plan->n_patch_tiles[c]) return static_cast<int>(hipErrorInvalidValue);
       const int i0 = p1 - ni;   // first irregular patch of the class
       const int rb = pb, re = pe < i0 ? pe : i0, ib = pb > i0 ? pb : i0, ie = pe;
+      int both = -1;
+      if (re > rb && ie > ib && (whole || persistent_always))   // both kinds in one launch (kernels_fused_patch3.hip)
+        both = plain_patch3_both_stage<T>(kind, stage, plan, rb, re - rb, ib, ie - ib, fmk<T>(prev), fmk<T>(mid), fmk<T>(out), volume, dt, speed,
+                                          static_cast<hipStream_t>(stream));
+      if (both > 0) return both;
+      if (both == 0) {
+        // done
+      } else {
       if (re > rb)
         if (int rc = plain_patch3_stage<T>(kind, stage, plan, rb, re - rb, fmk<T>(prev), fmk<T>(mid), fmk<T>(out), volume, dt, speed,
                                            whole || persistent_always, false, static_cast<hipStream_t>(stream)))
@@ -301,6 +309,7 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
         if (int rc = plain_patch3_stage<T>(kind, stage, plan, ib, ie - ib, fmk<T>(prev), fmk<T>(mid), fmk<T>(out), volume, dt, speed,
                                            whole || persistent_always, true, static_cast<hipStream_t>(stream)))
           return rc;
+      }
     } else if (pe > pb) {
       if (int rc = flush()) return rc;
       // patches and generic tiles of the class in ONE launch where the patches carry most of it (the generic tiles then

@@ -72,15 +72,14 @@ T8_DEV int patch3_fresh(int v) {
   return v;
 }
 
-// (second launch bound = wavefronts per SIMD the register allocation must allow: two 8-wave workgroups per CU in fp64 --
-//  77 KB of LDS each --, three in fp32)
 // IRR: the launch covers IRREGULAR patches (descriptor flag 0x800, csrc/host/tile_plan.cpp) -- the same block, with every side
 // face evaluated in the orientation its per-cell words give and the six fluxes of a cell added in the listed order. A separate
 // instantiation: the regular one keeps its register budget.
+// workgroup `wg` of the `nwg` that share the patch tiles [tile_begin, tile_begin + tile_count) of tile_order (nwg a multiple of 8
+// or < 8: wg & 7 must be the workgroup's XCD)
 template <class T, int KIND, int STAGE, bool IRR>
-__global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8gpuPlainPlan P, int tile_begin, int tile_count, FVars<T> prev,
-                                                                                 FVars<T> src, FVars<T> out, const T* __restrict__ vol, T dt,
-                                                                                 T* __restrict__ speed) {
+T8_DEV void plain_patch3_body(const T8gpuPlainPlan& P, int tile_begin, int tile_count, int wg, int nwg, const FVars<T>& prev,
+                              const FVars<T>& src, const FVars<T>& out, const T* __restrict__ vol, T dt, T* __restrict__ speed) {
   constexpr int NW  = KIND == 0 ? kPrimWords : 5;
   constexpr int REC = rec_words<T, NW>();
   extern __shared__ __attribute__((aligned(16))) double lds_raw[];
@@ -90,7 +89,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
   double* const lt = reinterpret_cast<double*>(pe + REC * 512);
   const int tid = threadIdx.x;
 
-  const int G = gridDim.x, xcd = blockIdx.x & 7, jw = blockIdx.x >> 3;
+  const int G = nwg, xcd = wg & 7, jw = wg >> 3;
   const int nxcd = G < 8 ? G : 8, nx = (G - xcd + 7) >> 3;
   const int per = tile_count / nxcd, rem = tile_count % nxcd;
   const int x0   = tile_begin + xcd * per + (xcd < rem ? xcd : rem);
@@ -343,6 +342,32 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
   }
 }
 
+// (second launch bound = wavefronts per SIMD the register allocation must allow: two 8-wave workgroups per CU in fp64 --
+//  77 KB of LDS each --, three in fp32)
+template <class T, int KIND, int STAGE, bool IRR>
+__global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8gpuPlainPlan P, int tile_begin, int tile_count, FVars<T> prev,
+                                                                                 FVars<T> src, FVars<T> out, const T* __restrict__ vol, T dt,
+                                                                                 T* __restrict__ speed) {
+  plain_patch3_body<T, KIND, STAGE, IRR>(P, tile_begin, tile_count, blockIdx.x, gridDim.x, prev, src, out, vol, dt, speed);
+}
+
+// REGULAR and IRREGULAR patches of one class in ONE launch (round 4): the first `reg_wgs` workgroups (a multiple of 8) walk the
+// regular patches, the others the irregular ones -- two bodies behind a workgroup-uniform branch, each with its own registers
+// (the regular body's 114, the irregular one's 128: nothing is live across the branch, so neither spills; both forms behind a
+// per-PATCH branch inside one loop cost 13-30 spills, round 3). As two launches the second one starts when the first has
+// drained: one tail and one launch gap per stage less.
+template <class T, int KIND, int STAGE>
+__global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3_both(T8gpuPlainPlan P, int reg_begin, int reg_count, int reg_wgs,
+                                                                                      int irr_begin, int irr_count, FVars<T> prev, FVars<T> src,
+                                                                                      FVars<T> out, const T* __restrict__ vol, T dt,
+                                                                                      T* __restrict__ speed) {
+  const int b = blockIdx.x;
+  if (b < reg_wgs)
+    plain_patch3_body<T, KIND, STAGE, false>(P, reg_begin, reg_count, b, reg_wgs, prev, src, out, vol, dt, speed);
+  else
+    plain_patch3_body<T, KIND, STAGE, true>(P, irr_begin, irr_count, b - reg_wgs, static_cast<int>(gridDim.x) - reg_wgs, prev, src, out, vol, dt, speed);
+}
+
 // tiles [tile_begin, tile_begin + tile_count) of tile_order must all be 3D patch tiles. persistent = false: one patch per
 // workgroup (class-split multi-rank launches).
 template <class T>
@@ -411,6 +436,72 @@ int plain_patch3_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile
 #undef T8_P3I
   return static_cast<int>(hipGetLastError());
 }
+
+// Regular patches [reg_begin, +reg_count) and irregular patches [irr_begin, +irr_count) in one persistent launch. Returns -1 where
+// that is not worth it or not possible (a class launch of a multi-rank stage, fewer patches than resident workgroups): the
+// caller launches the two kinds one after the other.
+template <class T>
+int plain_patch3_both_stage(int kind, int stage, const T8gpuPlainPlan* plan, int reg_begin, int reg_count, int irr_begin, int irr_count,
+                            FVars<T> prev, FVars<T> mid, FVars<T> out, const T* volume, T dt, T* speed, hipStream_t stream) {
+  static const bool off = std::getenv("T8GPU_PATCH3_BOTH") && std::getenv("T8GPU_PATCH3_BOTH")[0] == '0';   // (measurements)
+  if (off || reg_count <= 0 || irr_count <= 0) return -1;
+  if (!plan->face_lr || !plan->face_orig || !plan->tile_desc) return static_cast<int>(hipErrorInvalidValue);
+  if (plan->n_slots_addressed <= 0 || static_cast<unsigned long long>(plan->n_slots_addressed) * sizeof(T) >= (1ull << 32))
+    return static_cast<int>(hipErrorInvalidValue);
+  int             dev = 0;
+  static int      cus = 0;
+  if (cus == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return static_cast<int>(hipErrorInvalidDevice);
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int resident = cus * (sizeof(T) == 8 ? 2 : 3);
+  if (reg_count + irr_count < 2 * resident) return -1;
+  // the resident workgroups in proportion to the work (an irregular patch costs ~1.2 regular ones), the regular share a multiple of 8
+  const double w_r = reg_count, w_i = 1.2 * irr_count;
+  int reg_wgs = static_cast<int>(resident * w_r / (w_r + w_i) / 8.0 + 0.5) * 8;
+  if (reg_wgs < 8) reg_wgs = 8;
+  if (reg_wgs > resident - 8) reg_wgs = resident - 8;
+  const int    nw  = kind == 0 ? kPrimWords : 5;
+  const int    rec = sizeof(T) == 8 ? (nw > 5 ? 10 : 6) : 12;
+  const size_t lds = sizeof(T) * (static_cast<size_t>(5) * kP3FF + static_cast<size_t>(rec) * 512) +
+                     ((sizeof(T) == 8 && kind == 0) ? 2 * kLogTabEntries * sizeof(double) : 0);
+  const dim3 grid(resident), block(512);
+  note_stage_kernel(reg_count + irr_count, "k_plain_patch3_both<T, K, S>", static_cast<int>(sizeof(T)), kind, stage);
+#define T8_P3B(K, S)                                                                                                          \
+  do {                                                                                                                       \
+    if (lds > 64 * 1024) {                                                                                                   \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_plain_patch3_both<T, K, S>),                       \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                 \
+      if (e != hipSuccess) return static_cast<int>(e);                                                                       \
+    }                                                                                                                        \
+    hipLaunchKernelGGL((k_plain_patch3_both<T, K, S>), grid, block, lds, stream, *plan, reg_begin, reg_count, reg_wgs, irr_begin, irr_count, \
+                       prev, mid, out, volume, dt, speed);                                                                   \
+  } while (0)
+#define T8_P3BS(K)         \
+  do {                     \
+    if (stage == 1)        \
+      T8_P3B(K, 1);        \
+    else if (stage == 2)   \
+      T8_P3B(K, 2);        \
+    else                   \
+      T8_P3B(K, 3);        \
+  } while (0)
+  if (kind == 0)
+    T8_P3BS(0);
+  else if (kind == 1)
+    T8_P3BS(1);
+  else
+    T8_P3BS(2);
+#undef T8_P3BS
+#undef T8_P3B
+  return static_cast<int>(hipGetLastError());
+}
+
+template int plain_patch3_both_stage<float>(int, int, const T8gpuPlainPlan*, int, int, int, int, FVars<float>, FVars<float>, FVars<float>, const float*,
+                                            float, float*, hipStream_t);
+template int plain_patch3_both_stage<double>(int, int, const T8gpuPlainPlan*, int, int, int, int, FVars<double>, FVars<double>, FVars<double>,
+                                             const double*, double, double*, hipStream_t);
 
 template int plain_patch3_stage<float>(int, int, const T8gpuPlainPlan*, int, int, FVars<float>, FVars<float>, FVars<float>, const float*,
                                        float, float*, bool, bool, hipStream_t);
