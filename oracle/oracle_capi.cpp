@@ -9,6 +9,7 @@
 #include <omp.h>
 #endif
 
+#include <cstddef>
 using namespace oracle;
 
 extern "C" void oracle_set_num_threads(int n) {
@@ -17,6 +18,21 @@ extern "C" void oracle_set_num_threads(int n) {
 #else
   (void)n;
 #endif
+}
+
+// Zero-fills `bytes` bytes from the OpenMP team with the static schedule of the oracle's own loops, so that every page of a
+// state array is FIRST TOUCHED by (a thread on the socket of) the thread that will work on it -- numpy's allocator would leave
+// all pages on the allocating thread's NUMA node (bench.py: cpu_baseline).
+extern "C" void oracle_first_touch(void* p, size_t bytes) {
+  char* c = static_cast<char*>(p);
+  const long n = static_cast<long>(bytes / 4096) + 1;
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(static)
+#endif
+  for (long i = 0; i < n; i++) {
+    const size_t a = static_cast<size_t>(i) * 4096, b = a + 4096 < bytes ? a + 4096 : bytes;
+    for (size_t j = a; j < b; j++) c[j] = 0;
+  }
 }
 
 extern "C" int oracle_num_threads() {

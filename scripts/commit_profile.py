@@ -10,6 +10,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def main():
@@ -25,9 +26,13 @@ def main():
         t = json.load(open(tj))
         path = os.path.join(dst, "traffic.json")
         allt = json.load(open(path)) if os.path.exists(path) else {}
+        from t8gpu_amd.build import kernel_source_hash
+        # (the hash of the kernel sources the profiled library was built from: bench.py reports this record's figures only
+        #  while the sources are the same -- a body change under an unchanged kernel name would otherwise go unnoticed)
         allt[f"{workload}|{dtype}|{flux}|{mode}"] = {"hbm_bytes_per_launch": int(t["avg_hbm_bytes_per_launch"]), "kernels": t["kernels"],
                                                      "source": f"profiles/{tag}.md", "method": t["method"],
-                                                     "valu_busy": t.get("valu_busy"), "lds_conflict_frac": t.get("lds_conflict_frac")}
+                                                     "valu_busy": t.get("valu_busy"), "lds_conflict_frac": t.get("lds_conflict_frac"),
+                                                     "kernel_source_hash": kernel_source_hash()}
         json.dump(allt, open(path, "w"), indent=1)
         print(f"{workload}|{dtype}|{flux}|{mode}: {int(t['avg_hbm_bytes_per_launch'])} B per launch")
 

@@ -94,6 +94,19 @@ def build_hip(force=False, variant=None, defines=(), only=None):
     return target
 
 
+def kernel_source_hash():
+    """sha256[:16] over the kernel sources (csrc/hip/kernels_*.hip and every header beside them; the step driver, which holds
+    no kernel, is left out): what a committed rocprofv3 profile is tied to (profiles/traffic.json, bench.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(CSRC, "hip")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hpp", ".h")) or (f.startswith("kernels_") and f.endswith(".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build_oracle(force=False):
     odir = os.path.join(ROOT, "oracle")
     deps = [os.path.join(odir, "oracle.hpp"), os.path.join(odir, "oracle_capi.cpp")]

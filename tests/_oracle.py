@@ -63,11 +63,17 @@ class PlainCase:
     """Host copy of one rank's plain-element problem in the reference's memory layout:
     planes[26, stride] (plane = step*5 + var, volume = plane 25; memory_manager.h:460)."""
 
-    def __init__(self, part, dtype, capacity=None, state=None):
+    def __init__(self, part, dtype, capacity=None, state=None, first_touch=None):
+        """first_touch: an oracle library whose OpenMP team zero-fills the planes (bench.py's CPU baseline: pages placed where
+        the threads that work on them run)"""
         self.part, self.dtype = part, np.dtype(dtype)
         tot = part.N + part.G
         self.stride = capacity or tot
-        self.planes = np.zeros((26, self.stride), dtype)
+        if first_touch is None:
+            self.planes = np.zeros((26, self.stride), dtype)
+        else:
+            self.planes = np.empty((26, self.stride), dtype)
+            first_touch.oracle_first_touch(p(self.planes), C.c_size_t(self.planes.nbytes))
         ic = part.kh_initial_state() if state is None else state
         self.planes[0:5, :tot] = ic.astype(dtype)          # Step0 = `next` before the first iterate()
         self.planes[25, :tot] = part.volumes.astype(dtype)
@@ -91,13 +97,17 @@ class PlainCase:
 class SubgridCase:
     """planes[25, stride] in SUBCELLS + separate per-block volumes (subgrid_memory_manager.h:553-554)."""
 
-    def __init__(self, part, dtype, state=None):
+    def __init__(self, part, dtype, state=None, first_touch=None):
         self.part, self.dtype = part, np.dtype(dtype)
         self.rank = part.mesh.dim
         self.S = 4 ** self.rank
         tot = part.N + part.G
         self.stride = tot * self.S
-        self.planes = np.zeros((25, self.stride), dtype)
+        if first_touch is None:
+            self.planes = np.zeros((25, self.stride), dtype)
+        else:
+            self.planes = np.empty((25, self.stride), dtype)
+            first_touch.oracle_first_touch(p(self.planes), C.c_size_t(self.planes.nbytes))
         ic = part.kh_initial_state() if state is None else state
         self.planes[0:5] = ic.astype(dtype)
         self.volumes = part.volumes.astype(dtype)
