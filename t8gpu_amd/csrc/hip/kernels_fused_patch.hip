@@ -79,12 +79,23 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
   const int  a_mx = ci > 0 ? patch_morton(ci - 1, cj) : 512 + cj;
   const int  a_my = cj > 0 ? 256 + patch_morton(ci, cj - 1) : 528 + ci;
   const bool yfirst_lane = patch_ctz4(cj) >= patch_ctz4(ci);   // (cell (0, 0): per patch, from the descriptor)
-  const bool halo_wave = tid >= 192;                           // wave 3: the 64 cells across the sides
-  const int  hl        = tid - 192;
-  const bool minus_lane = tid < 32;                            // wave 0, lanes 0-31: the faces of the -x / -y sides
-  const bool minus_y    = tid >= 16;
-  const int  m_l = 256 + (minus_y ? 32 : 0) + (tid & 15);      // left operand: the cell across; right: the patch's cell
-  const int  m_r = minus_y ? patch_morton(tid & 15, 0) : patch_morton(0, tid & 15);
+  // The two extra jobs of a patch -- the 64 cells across the sides (one round of primitives) and the 32 faces of the - sides
+  // (one half-filled flux round) -- ROTATE over the four wavefronts from patch to patch: wavefront w has role (w + it) & 3 at
+  // the workgroup's it-th patch, role 3 takes the side cells, role 0 the - faces. Fixed to wavefronts 3 and 0 (round 3) the
+  // wavefronts of a workgroup carry 730 / 520 / 520 / 620 VALU instructions per patch, and a workgroup's wavefront i runs on
+  // SIMD i of its CU: one SIMD of four does 22 % more than the average while the others wait at the barriers.
+  // Measured (same box, scripts/ab_variants.sh): c4 fp64 11 640 -> 11 727 M/s, fp32 and c2 unchanged -- the dispatcher does not pin
+  // wavefront i to SIMD i as strictly as feared. T8GPU_EXP_FIXED_ROLES: experiment builds keep the fixed assignment.
+  const int  wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
+#ifdef T8GPU_EXP_FIXED_ROLES
+  auto role = [&](int) { return wv == 3 ? 3 : (wv == 0 ? 0 : 1); };
+#else
+  auto role = [&](int it) { return (wv + it) & 3; };
+#endif
+  const int  hl      = ln;                                     // side-cell lane: cell hl of [-x | +x | -y | +y] x 16
+  const bool minus_y = ln >= 16;                               // - face lanes 0-31 of the role-0 wavefront: -x side, then -y side
+  const int  m_l = 256 + (minus_y ? 32 : 0) + (ln & 15);       // left operand: the cell across; right: the patch's cell
+  const int  m_r = minus_y ? patch_morton(ln & 15, 0) : patch_morton(0, ln & 15);
 
   typedef int int8v __attribute__((ext_vector_type(8)));
   struct Desc {
@@ -110,7 +121,7 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
   };
   // first: the prologue's request. A launch with a ghost window (t8gpu_hip.h; the multi-rank driver's ghost-reading class)
   // runs one patch per workgroup -- plain_patch_stage() sees to it -- so only that request can meet a ghost slot.
-  auto prefetch = [&](const Desc& d, int hslot, bool first) {
+  auto prefetch = [&](const Desc& d, int hslot, bool first, bool halo_wave) {
     Pre p;
 #pragma unroll
     for (int k = 0; k < 5; k++) p.s0[k] = at32<T>(src.p[k], static_cast<unsigned>(d.e0 + tid));
@@ -129,17 +140,19 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
 
   const int stride = chunk > 0 ? 1 : nx;
   Desc      d0 = load_desc(t), d1 = load_desc(t + stride);
-  int       hs_a = halo_wave ? P.halo_ids[d0.h0 + hl] : 0, hs_b = halo_wave ? P.halo_ids[d1.h0 + hl] : 0;
-  Pre       cur = prefetch(d0, hs_a, true);
+  int       hs_a = role(0) == 3 ? P.halo_ids[d0.h0 + hl] : 0, hs_b = role(1) == 3 ? P.halo_ids[d1.h0 + hl] : 0;
+  Pre       cur = prefetch(d0, hs_a, true, role(0) == 3);
+  int       it  = 0;
   T         res[5] = {T(0), T(0), T(0), T(0), T(0)};
   int       res_e  = -1;
   __builtin_amdgcn_s_waitcnt(0);   // (see k_plain_persistent: the prologue's loads must not become a wait inside the loop)
 
-  for (; t < tend; t += stride) {
+  for (; t < tend; t += stride, it++) {
+    const bool halo_wave = role(it) == 3, minus_lane = role(it) == 0 && ln < 32;
     const Desc d2   = load_desc(t + 2 * stride);
-    const int  hs_c = halo_wave ? P.halo_ids[d2.h0 + hl] : 0;
+    const int  hs_c = role(it + 2) == 3 ? P.halo_ids[d2.h0 + hl] : 0;
     Pre        nxt;
-    if (t + stride < tend) nxt = prefetch(d1, hs_b, false);
+    if (t + stride < tend) nxt = prefetch(d1, hs_b, false, role(it + 1) == 3);
     const int e = d0.e0 + tid;
     T         pv[5] = {T(0), T(0), T(0), T(0), T(0)};
     if (STAGE > 1) {
@@ -207,7 +220,7 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
       rec_load<T, NW>(pe + m_r * REC, wr);
       patch_face<T, KIND, NW>(minus_y, wl, wr, area, g, sm);
 #pragma unroll
-      for (int k = 0; k < 5; k++) ff[k * kPatchFF + 512 + tid] = g[k];
+      for (int k = 0; k < 5; k++) ff[k * kPatchFF + 512 + ln] = g[k];
     }
     __syncthreads();
 
