@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""The markdown table of profiles/r03_bench_matrix.md from the JSON lines scripts/bench_matrix.sh wrote.
-usage: matrix_md.py gpurun_out/bench_matrix.jsonl > profiles/r03_bench_matrix.md"""
+"""The markdown table of profiles/rNN_bench_matrix.md from the JSON lines scripts/bench_matrix.sh wrote.
+usage: matrix_md.py gpurun_out/bench_matrix.jsonl [round] > profiles/rNN_bench_matrix.md"""
 import json
 import sys
 
 rows = [json.loads(line) for line in open(sys.argv[1]) if line.startswith("{")]
-print("# Round-3 bench matrix (one MI355X box, `scripts/bench_matrix.sh` = `bench.py --steps 50 --reps 3 --no-cpu-baseline`, median "
-      "repetition; end of round 3)\n")
+rnd = sys.argv[2] if len(sys.argv) > 2 else "3"
+print(f"# Round-{rnd} bench matrix (one MI355X box, `scripts/bench_matrix.sh` = `bench.py --steps 50 --reps 3 --no-cpu-baseline`, median "
+      f"repetition; end of round {rnd})\n")
 print("`frac` = algorithmic bytes of the reference's unfused data flow per launch / launch time / 8 TB/s (throughput-equivalent, SURVEY 8d);")
 print("`traffic frac` = PMC HBM bytes of the committed profile of the SAME kernel(s) / this run's launch time / 8 TB/s (null where no profile "
       "of the launched kernel is committed);")
