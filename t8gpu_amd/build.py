@@ -95,15 +95,20 @@ def build_hip(force=False, variant=None, defines=(), only=None):
 
 
 def kernel_source_hash():
-    """sha256[:16] over the kernel sources (csrc/hip/kernels_*.hip and every header beside them; the step driver, which holds
-    no kernel, is left out): what a committed rocprofv3 profile is tied to (profiles/traffic.json, bench.py)."""
+    """sha256[:16] over the CODE of the kernel sources (csrc/hip/kernels_*.hip and every header beside them; the step driver,
+    which holds no kernel, is left out; `//` comments and white space do not count): what a committed rocprofv3 profile is tied
+    to (profiles/traffic.json, bench.py)."""
     import hashlib
+    import re
     h = hashlib.sha256()
     d = os.path.join(CSRC, "hip")
     for f in sorted(os.listdir(d)):
         if f.endswith((".hpp", ".h")) or (f.startswith("kernels_") and f.endswith(".hip")):
+            text = open(os.path.join(d, f), encoding="utf-8", errors="replace").read()
+            text = re.sub(r"//[^\n]*", "", text)            # (no kernel source has `//` inside a string literal)
+            text = re.sub(r"\s+", " ", text)
             h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+            h.update(text.encode())
     return h.hexdigest()[:16]
 
 

@@ -680,7 +680,11 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_subgrid_family(
 // of the pooled rounds, the next cube's rows, its 10 + 10 (+ 10) state words -- does not fit beside the 126 / 72 VGPRs of the
 // flux passes: 128 / 80 VGPRs with 80 / 50 dwords of scratch spill and 100 SGPRs with ~160 lane spills, and the reloads sit
 // in the in-order vmcnt queue behind the prefetch. Fetching the own state a second time for the RK update (ten registers
-// less through the passes) did not remove a single spill. The block kernel's persistent form of round 2 failed the same way.)
+// less through the passes) did not remove a single spill. The block kernel's persistent form of round 2 failed the same way.
+// Also measured and dropped: `chunk` consecutive cubes per workgroup with NOTHING carried between them (lane constants
+// recomputed per cube from an opaque copy of the lane index, which keeps the loop free of spills: 127 / 75 VGPRs) -- chunks of
+// 1 / 2 / 3 / 4 / 8 cubes: c3 fp64 7 470 / 7 300 / 7 180 / 7 360 / 7 260, fp32 15 830 / 15 950 / 15 460 / 15 680 / 15 640 M/s on a
+// box where this kernel runs at ~7 750 / ~17 000: the loop form alone costs the code 4 - 7 %, and fewer dispatches buy nothing.)
 
 // ---------------------------------------------------------------------------------------------------------------
 // Family kernel, RANK 2: one wavefront = a 2x2 square of consecutive same-level Subgrid<4,4> blocks (lanes 16 w .. 16 w + 15
