@@ -147,8 +147,10 @@ def test_graph_capture_of_the_three_stream_pipeline_without_the_rccl_group(tmp_p
 def test_rccl_group_on_a_forked_stream_of_a_capture_opt_in(tmp_path):
     """DIAGNOSTIC, opt-in: T8GPU_GRAPH_VARIANT=5 puts the exchange chain back on a forked stream of the capture -- the
     layout of rounds 1-2, which dies with SIGSEGV in hipStreamEndCapture in relaxed, global and thread-local capture mode
-    alike (round 3: no handler output even with faulthandler and a backtrace handler installed, i.e. the fault leaves no
-    usable stack). Kept to re-check newer stacks."""
+    alike. Round 3 got no handler output (the handlers ran on the faulting thread's own, exhausted stack); round 4's shim runs on an
+    alternate stack and shows the cause: one frame of libamdhip64.so (+0x2d34a8 in the torch wheel's HIP 7.0.51831) repeated through
+    the whole backtrace -- unbounded recursion inside the runtime while hipStreamEndCapture walks the captured graph, a stack
+    overflow. Kept to re-check newer stacks."""
     shim = tmp_path / "segv_backtrace.so"
     subprocess.run(["gcc", "-O1", "-g", "-shared", "-fPIC", "-o", str(shim), os.path.join(ROOT, "scripts", "segv_backtrace.c")], check=True)
     res, out = _child(tmp_path, "rccl", dict(T8GPU_GRAPH_VARIANT="5", T8GPU_GRAPH_RCCL="1", T8GPU_TEST_SEGV_SHIM=str(shim)), "graph_child_rccl_forked.log")
