@@ -113,8 +113,7 @@ namespace t8gpu {
     explicit SubgridMeshManager(HostSubgridMeshArrays const& m, sc_MPI_Comm comm = sc_MPI_COMM_WORLD)
         : SubgridMemoryManager<VariableType, StepType, SubgridType>(static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements, comm),
           m_host{m} {
-      int comm_rank = 0;
-      detail::comm_layout(comm, comm_rank, m_nb_ranks);
+      detail::comm_layout(comm, m_comm_rank, m_nb_ranks);
       rebuild_connectivity(m);
       const size_t            tot = static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements;
       std::vector<float_type> vol(m.volumes.begin(), m.volumes.end());
@@ -122,14 +121,18 @@ namespace t8gpu {
       this->set_volume(vol);
     }
     /// From a synthetic forest (owned afterwards): stands for SubgridMeshManager(comm, scheme, cmesh, forest)
-    /// (subgrid_mesh_manager.inl:3-60); connectivity through the forest-query adapter.
+    /// (subgrid_mesh_manager.inl:3-60); connectivity through the forest-query adapter. On several ranks every rank passes
+    /// its own handle of the same forest and owns an equal share of the curve; set_transport() must follow (see MeshManager).
     explicit SubgridMeshManager(void* synth_mesh, int lowest_level = min_level, int highest_level = max_level,
                                 sc_MPI_Comm comm = sc_MPI_COMM_WORLD)
-        : SubgridMeshManager(arrays_of(synth_mesh), comm) {
+        : SubgridMeshManager(arrays_of(synth_mesh, comm_rank_of(comm), comm_size_of(comm), nullptr), comm) {
       m_forest    = synth_mesh;
       m_min_level = lowest_level;
       m_max_level = highest_level;
+      if (m_nb_ranks > 1) rebuild_connectivity(arrays_of(m_forest, m_comm_rank, m_nb_ranks, &m_halo_host));   // (+ the halo lists)
     }
+    /// The channel adapt() / partition() / refresh_ghost_layer() use on several ranks (not owned). See backend/transport.h.
+    void set_transport(Transport* transport) { m_transport = transport; }
 
     /// subgrid_mesh_manager.inl:144-194: `func(accessor, forest, tree_idx, element, e_idx)` fills ONE value per
     /// variable and block in a host MemoryAccessorOwn; every subcell of the block gets that value in Step 0
@@ -163,17 +166,88 @@ namespace t8gpu {
       adapt(std::vector<float_type>(refinement_criteria.begin(), refinement_criteria.end()), step);
     }
 
-    /// subgrid_mesh_manager.inl:1217-1369; identity on one rank (see MeshManager::partition)
-    void partition(step_index_type /*step*/) {
-      if (m_nb_ranks > 1) {
-        std::fprintf(stderr, "t8gpu: SubgridMeshManager::partition across ranks is driven by the RCCL repartition (amr.PartitionedSubgridAdapt)\n");
+    /// subgrid_mesh_manager.inl:1217-1369. As MeshManager::partition with whole blocks for elements: every run of adapted
+    /// blocks goes to its owner in the new equal split (t8gpu_hip_repartition_* with cells_per_element = 4^rank: the old owner
+    /// sends where the reference's new owner pulls through CUDA-IPC pointers, partition_data<<<>>> :1217-1250), the new forest is
+    /// installed and the connectivity rebuilt. Only `step` and the volumes are valid afterwards. The identity on one rank or
+    /// when no adapt() is pending.
+    void partition(step_index_type step) {
+      if (!m_pending.forest) return;
+      if (!m_transport) {
+        std::fprintf(stderr, "t8gpu: partition() on %d ranks needs a transport (SubgridMeshManager::set_transport)\n", m_nb_ranks);
         std::abort();
       }
+      constexpr size_t S = SubgridType::size;
+      const int     R = m_nb_ranks, r = m_comm_rank;
+      const int64_t n_new = t8gpu_synth_mesh_num_elements(m_pending.forest);
+      auto off = [&](int q) { return n_new * q / R; };                                   // the equal split of the NEW curve
+      const int64_t a = m_pending.have_off[r], b = m_pending.have_off[r + 1], lo = off(r), hi = off(r + 1);
+      std::vector<int32_t> sp, sf, sc, rp, rf, rc;
+      for (int q = 0; q < R; q++) {
+        const int64_t s0 = std::max(a, off(q)), s1 = std::min(b, off(q + 1));
+        if (s1 > s0) { sp.push_back(q); sf.push_back(static_cast<int32_t>(s0 - a)); sc.push_back(static_cast<int32_t>(s1 - s0)); }
+        const int64_t r0 = std::max(m_pending.have_off[q], lo), r1 = std::min(m_pending.have_off[q + 1], hi);
+        if (r1 > r0) { rp.push_back(q); rf.push_back(static_cast<int32_t>(r0 - lo)); rc.push_back(static_cast<int32_t>(r1 - r0)); }
+      }
+      HostHaloArrays        halo;
+      HostSubgridMeshArrays m = arrays_of(m_pending.forest, r, R, &halo);   // first: it says how many ghost blocks the planes need
+      this->resize(static_cast<size_t>(m.num_local_elements) + m.num_ghost_elements);
+      const size_t nh = static_cast<size_t>(std::max<int64_t>(b - a, 1));
+      float_type*  src[5];
+      float_type*  dst[5];
+      for (int k = 0; k < 5; k++) {
+        src[k] = m_pending.tmp + static_cast<size_t>(k) * S * nh;
+        dst[k] = static_cast<float_type*>(this->get_own_variable(step, static_cast<variable_index_type>(k)));
+      }
+      auto vars = [](float_type* const p[5]) {
+        if constexpr (std::is_same_v<float_type, double>) { T8gpuVars_f64 v; for (int k = 0; k < 5; k++) v.p[k] = p[k]; return v; }
+        else { T8gpuVars_f32 v; for (int k = 0; k < 5; k++) v.p[k] = p[k]; return v; }
+      };
+      m_transport->repartition(static_cast<int>(sp.size()), sp.data(), sf.data(), sc.data(), static_cast<int>(rp.size()), rp.data(), rf.data(),
+                               rc.data(), vars(src), m_pending.vol, vars(dst), this->get_own_volume(), static_cast<int>(S));
+      (void)hipFree(m_pending.tmp);
+      (void)hipFree(m_pending.vol);
+      t8gpu_synth_mesh_destroy(m_forest);
+      m_forest    = m_pending.forest;
+      m_pending   = Pending{};
+      m_halo_host = std::move(halo);
+      rebuild_connectivity(m);
+      if (m.num_ghost_elements > 0) {   // the ghost blocks' volumes come with the connectivity
+        std::vector<float_type> gv(m.volumes.begin() + m.num_local_elements, m.volumes.end());
+        T8GPU_CUDA_CHECK_ERROR(hipMemcpy(this->get_own_volume() + m.num_local_elements, gv.data(), sizeof(float_type) * gv.size(), hipMemcpyHostToDevice));
+      }
+      drop_scratch();
     }
+
+    /// Refresh the ghost BLOCKS [N, N + G) of the five planes of `step` from their owners (several ranks only; see
+    /// MeshManager::refresh_ghost_layer). The step drivers refresh what they read themselves.
+    void refresh_ghost_layer(step_index_type step) {
+      if (m_nb_ranks <= 1 || m_halo_host.peers.empty()) return;
+      if (!m_transport) {
+        std::fprintf(stderr, "t8gpu: refresh_ghost_layer() on %d ranks needs a transport (SubgridMeshManager::set_transport)\n", m_nb_ranks);
+        std::abort();
+      }
+      T8gpuHalo h{};
+      h.num_elements = m_host.num_local_elements; h.num_ghosts = m_host.num_ghost_elements;
+      h.n_peers = static_cast<int32_t>(m_halo_host.peers.size()); h.n_send = static_cast<int32_t>(m_halo_host.send_idx.size());
+      h.cells_per_element = static_cast<int32_t>(SubgridType::size);
+      h.peers = m_halo_host.peers.data(); h.send_off = m_halo_host.send_off.data(); h.recv_off = m_halo_host.recv_off.data();
+      h.send_idx = m_d_send_idx; h.sendbuf = m_d_sendbuf; h.recvbuf = m_d_recvbuf;
+      if constexpr (std::is_same_v<float_type, double>) {
+        T8gpuVars_f64 v; for (int k = 0; k < 5; k++) v.p[k] = static_cast<double*>(this->get_own_variable(step, static_cast<variable_index_type>(k)));
+        m_transport->halo_exchange(h, v);
+      } else {
+        T8gpuVars_f32 v; for (int k = 0; k < 5; k++) v.p[k] = static_cast<float*>(this->get_own_variable(step, static_cast<variable_index_type>(k)));
+        m_transport->halo_exchange(h, v);
+      }
+    }
+    [[nodiscard]] HostHaloArrays const& host_halo() const { return m_halo_host; }
+    [[nodiscard]] int comm_rank() const { return m_comm_rank; }
+    [[nodiscard]] int comm_size() const { return m_nb_ranks; }
 
     /// subgrid_mesh_manager.inl:560-961: coarse-face lists, level differences, neighbour offsets -> device arrays
     void compute_connectivity_information() {
-      if (m_forest) rebuild_connectivity(arrays_of(m_forest));
+      if (m_forest) rebuild_connectivity(arrays_of(m_forest, m_comm_rank, m_nb_ranks, m_nb_ranks > 1 ? &m_halo_host : nullptr));
     }
 
     /// SubgridMeshManager::adapt (subgrid_mesh_manager.inl:428-558), single rank: adapt callback on the per-block
@@ -183,6 +257,10 @@ namespace t8gpu {
       if (!m_forest) {
         std::fprintf(stderr, "t8gpu: adapt() needs a manager constructed from a forest\n");
         std::abort();
+      }
+      if (m_nb_ranks > 1) {
+        adapt_partitioned(refinement_criteria, step, threshold);
+        return;
       }
       constexpr size_t     S = SubgridType::size;
       std::vector<double>  crit(refinement_criteria.begin(), refinement_criteria.end());
@@ -220,16 +298,101 @@ namespace t8gpu {
       (void)hipFree(d_vol);
       t8gpu_synth_mesh_destroy(m_forest);
       m_forest = new_forest;
-      rebuild_connectivity(arrays_of(m_forest));
-      (void)hipFree(m_scratch);      // sized for the old mesh
+      rebuild_connectivity(arrays_of(m_forest, 0, 1, nullptr));
+      drop_scratch();
+    }
+
+   private:
+    /// adapt() on several ranks, the scheme of MeshManager::adapt_partitioned with blocks for elements: criteria of all ranks
+    /// gathered, the reference's adapt callback evaluated on the whole (replicated) forest, families cut by a rank boundary left
+    /// alone, this rank's blocks through the block-wise data-transfer kernel into temporary planes. partition() ships them.
+    void adapt_partitioned(std::vector<float_type> const& refinement_criteria, step_index_type step, double threshold) {
+      if (!m_transport) {
+        std::fprintf(stderr, "t8gpu: adapt() on %d ranks needs a transport (SubgridMeshManager::set_transport)\n", m_nb_ranks);
+        std::abort();
+      }
+      if (m_pending.forest) {   // adapt() twice without partition(): drop the first
+        t8gpu_synth_mesh_destroy(m_pending.forest);
+        (void)hipFree(m_pending.tmp);
+        (void)hipFree(m_pending.vol);
+        m_pending = Pending{};
+      }
+      constexpr size_t S = SubgridType::size;
+      const int     R = m_nb_ranks, r = m_comm_rank;
+      const int64_t n_glob = t8gpu_synth_mesh_num_elements(m_forest);
+      std::vector<int64_t> old_off(static_cast<size_t>(R) + 1);
+      for (int q = 0; q <= R; q++) old_off[q] = n_glob * q / R;
+      const int64_t n_mine = old_off[r + 1] - old_off[r];
+      if (static_cast<int64_t>(refinement_criteria.size()) < n_mine) std::abort();
+      std::vector<double> mine(refinement_criteria.begin(), refinement_criteria.begin() + n_mine), all(static_cast<size_t>(n_glob));
+      double *d_mine = nullptr, *d_all = nullptr;
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&d_mine, sizeof(double) * std::max<int64_t>(n_mine, 1)));
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&d_all, sizeof(double) * std::max<int64_t>(n_glob, 1)));
+      T8GPU_CUDA_CHECK_ERROR(hipMemcpy(d_mine, mine.data(), sizeof(double) * n_mine, hipMemcpyHostToDevice));
+      m_transport->allgatherv(d_mine, d_all, old_off.data());
+      T8GPU_CUDA_CHECK_ERROR(hipMemcpy(all.data(), d_all, sizeof(double) * n_glob, hipMemcpyDeviceToHost));
+      (void)hipFree(d_mine);
+      (void)hipFree(d_all);
+      std::vector<int8_t> marks(static_cast<size_t>(n_glob));
+      t8gpu_synth_mesh_marks(m_forest, all.data(), threshold, m_min_level, m_max_level, 4, marks.data());
+      t8gpu_synth_mesh_unmark_split_families(m_forest, marks.data(), old_off.data() + 1, R - 1);
+      void* new_forest = t8gpu_synth_mesh_adapt(m_forest, marks.data());
+      if (!new_forest) {
+        std::fprintf(stderr, "t8gpu: forest adaptation failed\n");
+        std::abort();
+      }
+      const int64_t        n_new = t8gpu_synth_mesh_num_elements(new_forest);
+      std::vector<int32_t> adapt_data(static_cast<size_t>(n_new) + 1);
+      if (t8gpu_synth_mesh_adapt_data(m_forest, new_forest, adapt_data.data()) != 0) std::abort();
+      m_pending.have_off.assign(static_cast<size_t>(R) + 1, n_new);
+      for (int q = 0; q < R; q++)
+        m_pending.have_off[q] = std::lower_bound(adapt_data.begin(), adapt_data.begin() + n_new, static_cast<int32_t>(old_off[q])) - adapt_data.begin();
+      const int64_t a = m_pending.have_off[r], b = m_pending.have_off[r + 1];
+      const int32_t nh = static_cast<int32_t>(b - a);
+      std::vector<int32_t> local(static_cast<size_t>(nh) + 1);
+      for (int32_t i = 0; i <= nh; i++) local[i] = adapt_data[a + i] - static_cast<int32_t>(old_off[r]);
+      int32_t* d_ad = nullptr;
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&d_ad, sizeof(int32_t) * local.size()));
+      T8GPU_CUDA_CHECK_ERROR(hipMemcpy(d_ad, local.data(), sizeof(int32_t) * local.size(), hipMemcpyHostToDevice));
+      const size_t cap = static_cast<size_t>(std::max(nh, 1));
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_pending.tmp, sizeof(float_type) * 5 * S * cap));
+      T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_pending.vol, sizeof(float_type) * cap));
+      if (nh > 0) {
+        auto old_vars = this->get_own_variables(step);
+        auto run = [&](auto o, auto n, auto fn) {
+          for (int k = 0; k < 5; k++) {
+            o.p[k] = old_vars.data(static_cast<variable_index_type>(k));
+            n.p[k] = m_pending.tmp + static_cast<size_t>(k) * S * cap;
+          }
+          T8GPU_CUDA_CHECK_ERROR(static_cast<hipError_t>(fn(SubgridType::rank, nh, d_ad, o, n, this->get_own_volume(), m_pending.vol, nullptr)));
+        };
+        if constexpr (std::is_same_v<float_type, double>)
+          run(T8gpuVars_f64{}, T8gpuVars_f64{}, t8gpu_hip_subgrid_adapt_variables_and_volume_f64);
+        else
+          run(T8gpuVars_f32{}, T8gpuVars_f32{}, t8gpu_hip_subgrid_adapt_variables_and_volume_f32);
+      }
+      T8GPU_CUDA_CHECK_ERROR(hipDeviceSynchronize());
+      (void)hipFree(d_ad);
+      m_pending.forest = new_forest;
+    }
+    void drop_scratch() {   // sized for the old mesh
+      (void)hipFree(m_scratch);
       (void)hipFree(m_scratch64);
       m_scratch   = nullptr;
       m_scratch64 = nullptr;
     }
+
+   public:
     [[nodiscard]] void const* forest() const { return m_forest; }
 
     ~SubgridMeshManager() {
       if (m_forest) t8gpu_synth_mesh_destroy(m_forest);
+      if (m_pending.forest) t8gpu_synth_mesh_destroy(m_pending.forest);
+      (void)hipFree(m_pending.tmp);
+      (void)hipFree(m_pending.vol);
+      (void)hipFree(m_d_send_idx);
+      (void)hipFree(m_d_sendbuf);
+      (void)hipFree(m_d_recvbuf);
       for (void* p : {static_cast<void*>(m_ranks), static_cast<void*>(m_indices), static_cast<void*>(m_face_neighbors),
                       static_cast<void*>(m_level_difference), static_cast<void*>(m_neighbor_offset), static_cast<void*>(m_face_normals),
                       static_cast<void*>(m_face_surfaces), static_cast<void*>(m_scratch), static_cast<void*>(m_scratch64)})
@@ -309,9 +472,20 @@ namespace t8gpu {
     int   m_min_level = min_level, m_max_level = max_level;
     int   m_nb_ranks  = 1;
 
-    static HostSubgridMeshArrays arrays_of(void* forest) {
+    static int comm_rank_of(sc_MPI_Comm comm) {
+      int r = 0, n = 1;
+      detail::comm_layout(comm, r, n);
+      return r;
+    }
+    static int comm_size_of(sc_MPI_Comm comm) {
+      int r = 0, n = 1;
+      detail::comm_layout(comm, r, n);
+      return n;
+    }
+    /// rank `rank` of `nranks`' share of the forest; `halo` (nullable) receives the ghost lists
+    static HostSubgridMeshArrays arrays_of(void* forest, int rank, int nranks, HostHaloArrays* halo) {
       constexpr int     R = SubgridType::rank;
-      T8gpuForestQuery* q = t8gpu_synth_query_create(forest, 0, 1);
+      T8gpuForestQuery* q = t8gpu_synth_query_create(forest, rank, nranks);
       void*             h = q ? t8gpu_host_connectivity_create_subgrid(q, R) : nullptr;
       if (!h) {
         std::fprintf(stderr, "t8gpu: connectivity of the synthetic forest could not be built\n");
@@ -321,6 +495,8 @@ namespace t8gpu {
       t8gpu_host_connectivity_counts(h, c);
       HostSubgridMeshArrays m;
       m.rank = R;
+      m.mpirank = rank;
+      m.first_global_element = t8gpu_synth_mesh_num_elements(forest) * rank / nranks;
       m.num_local_elements = static_cast<int32_t>(c[0]); m.num_ghost_elements = static_cast<int32_t>(c[1]);
       m.num_local_faces = static_cast<int32_t>(c[2]); m.num_local_boundary_faces = static_cast<int32_t>(c[3]);
       const size_t nf = static_cast<size_t>(c[2] + c[3]);
@@ -330,18 +506,23 @@ namespace t8gpu {
       m.volumes.resize(c[0] + c[1]);
       m.face_level_difference.resize(c[2]);
       m.face_neighbor_offset.resize(static_cast<size_t>(R) * c[2]);
-      t8gpu_host_connectivity_arrays(h, m.face_neighbors.data(), n3.data(), m.face_surfaces.data(), m.volumes.data(), nullptr, nullptr,
-                                     nullptr, nullptr);
+      HostHaloArrays hh;
+      hh.peers.resize(c[4]); hh.recv_off.resize(c[4] + 1); hh.send_off.resize(c[4] + 1); hh.send_idx.resize(c[5]);
+      t8gpu_host_connectivity_arrays(h, m.face_neighbors.data(), n3.data(), m.face_surfaces.data(), m.volumes.data(), hh.peers.data(),
+                                     hh.recv_off.data(), hh.send_off.data(), hh.send_idx.data());
+      if (halo) *halo = std::move(hh);
       t8gpu_host_connectivity_subgrid_arrays(h, m.face_level_difference.data(), m.face_neighbor_offset.data());
       t8gpu_host_connectivity_destroy(h);
       t8gpu_synth_query_destroy(q);
       m.face_normals.resize(static_cast<size_t>(R) * nf);   // the Subgrid accessors carry `rank` components
       for (size_t i = 0; i < nf; i++)
         for (int d = 0; d < R; d++) m.face_normals[R * i + d] = n3[3 * i + d];
-      void* part = t8gpu_synth_part_create(forest, 0, 1, 1, R);
+      void* part = t8gpu_synth_part_create(forest, rank, nranks, 1, R);
+      m.levels.resize(c[0] + c[1]);           // (the provider lists owned + ghost blocks; the manager keeps the owned ones)
+      m.centres.resize(3 * (c[0] + c[1]));
+      t8gpu_synth_part_elements(part, m.levels.data(), nullptr, m.centres.data());
       m.levels.resize(c[0]);
       m.centres.resize(3 * c[0]);
-      t8gpu_synth_part_elements(part, m.levels.data(), nullptr, m.centres.data());
       t8gpu_synth_part_destroy(part);
       return m;
     }
@@ -362,7 +543,32 @@ namespace t8gpu {
       upload(m_neighbor_offset, m.face_neighbor_offset);
       upload(m_face_normals, std::vector<float_type>(m.face_normals.begin(), m.face_normals.end()));
       upload(m_face_surfaces, std::vector<float_type>(m.face_surfaces.begin(), m.face_surfaces.end()));
+      (void)hipFree(m_d_send_idx);
+      (void)hipFree(m_d_sendbuf);
+      (void)hipFree(m_d_recvbuf);
+      m_d_send_idx = nullptr;
+      m_d_sendbuf = m_d_recvbuf = nullptr;
+      if (m_nb_ranks > 1 && !m_halo_host.peers.empty()) {   // device side of refresh_ghost_layer(): whole blocks on the wire
+        constexpr size_t S = SubgridType::size;
+        upload(m_d_send_idx, m_halo_host.send_idx);
+        T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_d_sendbuf, sizeof(float_type) * (5 * S * m_halo_host.send_idx.size() + 1)));
+        T8GPU_CUDA_CHECK_ERROR(hipMalloc(&m_d_recvbuf, sizeof(float_type) * (5 * S * static_cast<size_t>(m.num_ghost_elements) + 1)));
+      }
     }
+
+    // several ranks: the channel, the ghost lists of the current share, and what adapt() leaves for partition()
+    Transport*     m_transport = nullptr;
+    int            m_comm_rank = 0;
+    HostHaloArrays m_halo_host;
+    int32_t*       m_d_send_idx = nullptr;
+    float_type*    m_d_sendbuf  = nullptr;
+    float_type*    m_d_recvbuf  = nullptr;
+    struct Pending {
+      void*                forest = nullptr;   // the adapted forest (replicated)
+      float_type*          tmp    = nullptr;   // 5 planes of 4^rank x (have_off[r + 1] - have_off[r]) values: this rank's adapted blocks
+      float_type*          vol    = nullptr;   // their volumes
+      std::vector<int64_t> have_off;           // new blocks made from rank q's old ones: [have_off[q], have_off[q + 1])
+    } m_pending;
 
     HostSubgridMeshArrays m_host;
     int*                  m_ranks            = nullptr;

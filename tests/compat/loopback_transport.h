@@ -70,15 +70,17 @@ namespace t8gpu_test {
       runs<double>(n_send, send_peer, send_first, send_count, n_recv, recv_peer, recv_first, recv_count, src.p, src_volume, dst.p, dst_volume, cells);
     }
     void halo_exchange(T8gpuHalo const& halo, T8gpuVars_f32 state) override {
-      code(t8gpu_hip_halo_pack_f32(halo.n_send, 1, halo.send_idx, state, static_cast<float*>(halo.sendbuf), nullptr));
+      const int cells = halo.cells_per_element > 0 ? halo.cells_per_element : 1;
+      code(t8gpu_hip_halo_pack_f32(halo.n_send, cells, halo.send_idx, state, static_cast<float*>(halo.sendbuf), nullptr));
       deliver<float>(halo);
-      code(t8gpu_hip_halo_unpack_f32(halo.num_ghosts, halo.num_elements, 1, static_cast<float const*>(halo.recvbuf), state, nullptr));
+      code(t8gpu_hip_halo_unpack_f32(halo.num_ghosts, halo.num_elements, cells, static_cast<float const*>(halo.recvbuf), state, nullptr));
       sync_and_meet();
     }
     void halo_exchange(T8gpuHalo const& halo, T8gpuVars_f64 state) override {
-      code(t8gpu_hip_halo_pack_f64(halo.n_send, 1, halo.send_idx, state, static_cast<double*>(halo.sendbuf), nullptr));
+      const int cells = halo.cells_per_element > 0 ? halo.cells_per_element : 1;
+      code(t8gpu_hip_halo_pack_f64(halo.n_send, cells, halo.send_idx, state, static_cast<double*>(halo.sendbuf), nullptr));
       deliver<double>(halo);
-      code(t8gpu_hip_halo_unpack_f64(halo.num_ghosts, halo.num_elements, 1, static_cast<double const*>(halo.recvbuf), state, nullptr));
+      code(t8gpu_hip_halo_unpack_f64(halo.num_ghosts, halo.num_elements, cells, static_cast<double const*>(halo.recvbuf), state, nullptr));
       sync_and_meet();
     }
 
@@ -93,9 +95,10 @@ namespace t8gpu_test {
         for (int k = 0; k < o.n_peers; k++)
           if (o.peers[k] == m_rank) jj = k;
         const size_t n = static_cast<size_t>(halo.recv_off[j + 1] - halo.recv_off[j]);
+        const size_t w = 5 * static_cast<size_t>(halo.cells_per_element > 0 ? halo.cells_per_element : 1);   // values per element on the wire
         if (jj < 0 || static_cast<size_t>(o.send_off[jj + 1] - o.send_off[jj]) != n) std::abort();
-        check(hipMemcpy(static_cast<T*>(halo.recvbuf) + 5 * static_cast<size_t>(halo.recv_off[j]),
-                        static_cast<T const*>(o.sendbuf) + 5 * static_cast<size_t>(o.send_off[jj]), sizeof(T) * 5 * n, hipMemcpyDeviceToDevice));
+        check(hipMemcpy(static_cast<T*>(halo.recvbuf) + w * static_cast<size_t>(halo.recv_off[j]),
+                        static_cast<T const*>(o.sendbuf) + w * static_cast<size_t>(o.send_off[jj]), sizeof(T) * w * n, hipMemcpyDeviceToDevice));
       }
     }
     template<class T>

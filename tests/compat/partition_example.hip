@@ -142,6 +142,15 @@ int main() {
   auto forest = [] { return t8gpu_synth_mesh_create(2, 5, 5, 0.0, 1.0, 1); };   // 2D, uniform level 5, periodic: every rank its own handle
   Result one;
   run_rank(forest(), 0, 1, nullptr, &one);
+  {   // the product transport on one rank (no communicator needed: every run stays on the rank): same bits again
+    RcclTransport rccl(nullptr, 0, 1);
+    Result        again;
+    run_rank(forest(), 0, 1, &rccl, &again);
+    if (again.counts != one.counts || again.state != one.state) {
+      std::printf("partition_example FAILED: one rank through RcclTransport differs from one rank without a transport\n");
+      return 1;
+    }
+  }
   for (int nranks : {2, 3}) {
     t8gpu_test::LoopbackHub                     hub(nranks);
     std::vector<t8gpu_test::LoopbackTransport>  tr;

@@ -42,6 +42,10 @@ def test_partition_example_compiles():
     compile_example("partition_example.hip", "partition_example")
 
 
+def test_subgrid_partition_example_compiles():
+    compile_example("subgrid_partition_example.hip", "subgrid_partition_example")
+
+
 def test_subgrid_api_compiles():
     compile_example("subgrid_api.hip", "subgrid_api")
 
@@ -112,6 +116,16 @@ def test_partition_example_runs():
     exe = compile_example("partition_example.hip", "partition_example")
     res = subprocess.run([exe], capture_output=True, text=True, timeout=240)
     assert res.returncode == 0 and "partition_example OK" in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+def test_subgrid_partition_example_runs():
+    """SubgridMeshManager::adapt -> partition -> compute_connectivity_information on 2 and 3 ranks (loopback transport), whole
+    Subgrid<4,4,4> blocks on the wire (cells_per_element = 64), fused block-kernel steps with the ghost blocks refreshed per stage:
+    bitwise the single-rank run (t8gpu/mesh/subgrid_mesh_manager.inl:428-558, 1217-1369)."""
+    exe = compile_example("subgrid_partition_example.hip", "subgrid_partition_example")
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0 and "subgrid_partition_example OK" in res.stdout, res.stdout + res.stderr
 
 
 @pytest.mark.gpu
