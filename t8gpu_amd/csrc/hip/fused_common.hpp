@@ -4,10 +4,30 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "flux_math.hpp"
 #include "t8gpu_hip.h"
 
 namespace t8gpu_hip {
+
+// Compute units of the current device, asked once (0: no device). Function-local statics: the launchers are called from two
+// host threads of a rank (stepper.hip: the step driver's lanes), so their lazily initialised settings must be race-free.
+inline int device_cu_count() {
+  static const int n = [] {
+    int             dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }();
+  return n;
+}
+// a tuning variable holding workgroups per CU: 1 .. 8, anything else (or unset) = 0 = "the kernel's own default"
+inline int env_per_cu(const char* name) {
+  const char* env = std::getenv(name);
+  const int   v   = env ? std::atoi(env) : 0;
+  return (v < 0 || v > 8) ? 0 : v;
+}
 
 template <class T>
 struct FVars {

@@ -351,7 +351,9 @@ int subgrid_faces(int kind, int rank, int F, int count, const int32_t* fn, const
 
 namespace t8gpu_hip {
 StageKernelNote& stage_kernel_note() {
-  static StageKernelNote note = {{0}, -1};
+  // per host thread: the step driver's two lanes enqueue from two threads (stepper.hip); the caller's thread -- the one that asks
+  // t8gpu_hip_last_stage_kernel -- launches the interior tiles, the bulk of a stage
+  static thread_local StageKernelNote note = {{0}, -1};
   return note;
 }
 }  // namespace t8gpu_hip

@@ -312,16 +312,9 @@ int plain_patch_stage(int kind, int stage, const T8gpuPlainPlan* plan, int patch
     if (lds_tile > lds) lds = lds_tile;
     if (sizeof(T) == 8 && 3 * lds > static_cast<size_t>(156) * 1024) return -1;   // (the kernel lives on three workgroups per CU)
   }
-  static int per_cu_env = -1, cus = 0;
-  if (cus == 0) {
-    int             dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return static_cast<int>(hipErrorInvalidDevice);
-    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    const char* env = std::getenv("T8GPU_PATCH_WGS");
-    per_cu_env      = env ? std::atoi(env) : 0;
-    if (per_cu_env < 0 || per_cu_env > 8) per_cu_env = 0;
-  }
+  const int        cus        = device_cu_count();
+  static const int per_cu_env = env_per_cu("T8GPU_PATCH_WGS");
+  if (cus == 0) return static_cast<int>(hipErrorInvalidDevice);
   // persistent = true: the launch covers the whole plan -- as many patch workgroups as stay resident (3 per CU in fp64).
   // persistent = false: a class of a multi-rank stage, launched beside the pack / RCCL / unpack kernels of the exchange: one
   // patch per workgroup, so that slots free up continuously. That costs the patch kernel its software pipeline (13 % at c2

@@ -383,16 +383,9 @@ int plain_patch3_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile
   const int    rec = sizeof(T) == 8 ? (nw > 5 ? 10 : 6) : 12;
   const size_t lds = sizeof(T) * (static_cast<size_t>(5) * kP3FF + static_cast<size_t>(rec) * 512) +
                      ((sizeof(T) == 8 && kind == 0) ? 2 * kLogTabEntries * sizeof(double) : 0);
-  static int per_cu_env = -1, cus = 0;
-  if (cus == 0) {
-    int             dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return static_cast<int>(hipErrorInvalidDevice);
-    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    const char* env = std::getenv("T8GPU_PATCH_WGS");
-    per_cu_env      = env ? std::atoi(env) : 0;
-    if (per_cu_env < 0 || per_cu_env > 8) per_cu_env = 0;
-  }
+  const int        cus        = device_cu_count();
+  static const int per_cu_env = env_per_cu("T8GPU_PATCH_WGS");
+  if (cus == 0) return static_cast<int>(hipErrorInvalidDevice);
   const int  per_cu    = per_cu_env > 0 ? per_cu_env : (sizeof(T) == 8 ? 2 : 3);
   const int  resident  = cus * per_cu;
   const int  grid_size = (!persistent || tile_count < resident) ? tile_count : resident;
@@ -448,13 +441,8 @@ int plain_patch3_both_stage(int kind, int stage, const T8gpuPlainPlan* plan, int
   if (!plan->face_lr || !plan->face_orig || !plan->tile_desc) return static_cast<int>(hipErrorInvalidValue);
   if (plan->n_slots_addressed <= 0 || static_cast<unsigned long long>(plan->n_slots_addressed) * sizeof(T) >= (1ull << 32))
     return static_cast<int>(hipErrorInvalidValue);
-  int             dev = 0;
-  static int      cus = 0;
-  if (cus == 0) {
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return static_cast<int>(hipErrorInvalidDevice);
-    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int cus = device_cu_count();
+  if (cus == 0) return static_cast<int>(hipErrorInvalidDevice);
   const int resident = cus * (sizeof(T) == 8 ? 2 : 3);
   if (reg_count + irr_count < 2 * resident) return -1;
   // the resident workgroups in proportion to the work (an irregular patch costs ~1.2 regular ones), the regular share a multiple of 8

@@ -362,18 +362,8 @@ bool plain_persistent_accepts(int kind, const T8gpuPlainPlan* plan, int tile_cou
   if (sizeof(T) == 8 && 3 * lds > static_cast<size_t>(156) * 1024) return false;
   // persistent grid: enough workgroups to fill the chip at the occupancy the kernel reaches, never more than there are
   // tiles. T8GPU_PERSISTENT_WGS overrides the per-CU count (tuning).
-  static int per_cu_env = 0, cus = 0;
-  if (cus == 0) {
-    int            dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      cus = prop.multiProcessorCount;
-    else
-      cus = 256;   // (no device: the build container asking through the C-ABI; MI355X has 256 CUs)
-    const char* env = std::getenv("T8GPU_PERSISTENT_WGS");
-    per_cu_env = env ? std::atoi(env) : 0;
-    if (per_cu_env < 0 || per_cu_env > 8) per_cu_env = 0;
-  }
+  const int        cus        = device_cu_count() > 0 ? device_cu_count() : 256;   // (no device: the build container asking through the C-ABI; MI355X has 256 CUs)
+  static const int per_cu_env = env_per_cu("T8GPU_PERSISTENT_WGS");
   // resident workgroups per CU: fp64 166 VGPRs -> 3 waves per SIMD; fp32 ~100 VGPRs and half the LDS -> 5
   const int per_cu = per_cu_env > 0 ? per_cu_env : (sizeof(T) == 8 ? 3 : 5);
   // Worth it when a workgroup walks many tiles (c4: 55) or when there is at most one tile per resident workgroup anyway

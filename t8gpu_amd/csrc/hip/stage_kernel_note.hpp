@@ -1,6 +1,6 @@
 // stage_kernel_note.hpp -- which kernel did the last fused-stage call launch for most of its work? bench.py asks
 // (t8gpu_hip_last_stage_kernel) so that PMC figures taken from a committed profile are reported only for the kernel that
-// was profiled. Host-side bookkeeping only; one host thread per rank drives the library.
+// was profiled. Host-side bookkeeping only, kept per host thread (kernels_compat.hip).
 #ifndef T8GPU_HIP_STAGE_KERNEL_NOTE_HPP
 #define T8GPU_HIP_STAGE_KERNEL_NOTE_HPP
 

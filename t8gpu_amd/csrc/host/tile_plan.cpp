@@ -312,12 +312,30 @@ void find_patches3(TilePlan& P, const int32_t* fn, const double* normals, const 
   // to the origin of an aligned block -- element e0 + 1 must be its +x neighbour, e0 + 2 the +y neighbour, and so on through
   // the Morton pattern), so there is no scan order to respect. Almost every candidate fails at its first element.
   const int32_t ncand = N >= kPatchElems ? N - kPatchElems + 1 : 0;
+  // What both forms demand of a start before anything else: six faces, and the + neighbours of cell (0, 0, 0) are the block's
+  // cells (1, 0, 0), (0, 1, 0), (0, 0, 1) = e0 + 1, e0 + 2, e0 + 4, across faces e0 lists itself. Seven of eight elements of a
+  // uniform region fail this, from the face -> element pairs alone (8 bytes per face, against 40 once normals and areas are read).
+  auto may_start = [&](int32_t e0) -> bool {
+    if (deg[e0 + 1] - deg[e0] != 6) return false;
+    const int32_t* fl = &ef[deg[e0]];
+    unsigned       got = 0;
+    for (int q = 0; q < 6; q++) {
+      const int32_t f = fl[q];
+      if (f >= F || fn[2 * static_cast<size_t>(f)] != e0) continue;
+      const int32_t d = fn[2 * static_cast<size_t>(f) + 1] - e0;
+      if (d == 1) got |= 1u;
+      else if (d == 2) got |= 2u;
+      else if (d == 4) got |= 4u;
+    }
+    return got == 7u;
+  };
   std::vector<std::vector<Patch>> found(static_cast<size_t>(host_threads()));
 #pragma omp parallel num_threads(host_threads())
   {
     std::vector<Patch>& mine = found[static_cast<size_t>(omp_get_thread_num())];
 #pragma omp for schedule(static)
     for (int32_t e0 = 0; e0 < ncand; e0++) {
+      if (!may_start(e0)) continue;
       Patch pt;
       pt.dim = 3;
       pt.nh  = kPatchHalo3;
