@@ -414,9 +414,27 @@ def bench_adaptive(args, w, dts, tdtype, kindf, mode, rank, world, dist, rehears
         solver.planes[5 * solver.next:5 * solver.next + 5] = ic
     setup_s = time.time() - t0
 
+    # Several ranks on the real backend: the C++ two-lane step driver with its native RCCL exchange, as in the fixed-mesh run
+    # (main()). ONE communicator for the whole run -- made here, cross-checked once against the torch.distributed exchange and
+    # proven by two trial steps, every decision collective (make_native_halo, bring_up_native_stepper) -- and a new halo
+    # descriptor + stepper per adapted mesh (attach). Any "no": every rank steps through torch.distributed, stage by stage.
+    native_comm, driver = None, "python-driven stages (torch.distributed halo)" if dist is not None else "native C++ stepper"
+    if dist is not None and not rehearsal and mode == "fused" and os.environ.get("T8GPU_STEPPER", "native") == "native" \
+            and os.environ.get("T8GPU_HALO", "native") == "native":
+        first = make_native_halo(solver.part, tdtype, solver, HaloExchange(solver.part, tdtype, dist), dist, rank, world)
+        if first is not None:
+            dt0 = 0.1 * 2.0 ** -solver.part.mesh.finest_level
+            if bring_up_native_stepper(solver, first, dt0, solver.part, tdtype, dist, rank) is not None:
+                native_comm, driver = first.comm, "native C++ stepper (native rccl halo)"
+
     def attach(s):
+        if native_comm is not None:
+            from t8gpu_amd import native
+            if getattr(s, "stepper", None) is None:
+                s.use_native_stepper(native.NativeHalo(s.part, tdtype, native_comm))
+            return None
         halo = HaloExchange(s.part, tdtype, dist, stage_through_host=rehearsal) if world > 1 else None
-        if world == 1 and mode == "fused":
+        if world == 1 and dist is None and mode == "fused":
             s.use_native_stepper()
         return halo
 
@@ -476,7 +494,7 @@ def bench_adaptive(args, w, dts, tdtype, kindf, mode, rank, world, dist, rehears
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": dts, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['desc']}", "elements_at_end": n_end, "flux": args.flux,
-                       "kernels": mode, "adapt_every": a["every"], "adapt_cycles_timed": cycles,
+                       "kernels": mode, "driver": driver, "adapt_every": a["every"], "adapt_cycles_timed": cycles,
                        "step_ms": round(step_s / max(1, args.steps) * 1e3, 4),
                        "cycle_ms": round(cycle_s / max(1, cycles) * 1e3, 2) if cycles else None,
                        # one rank: where a cycle goes -- indicator kernels + read-back / mesh provider (t8code's share in the

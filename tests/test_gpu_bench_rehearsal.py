@@ -122,6 +122,24 @@ def test_bench_adaptive_workload_small(world):
     assert rec["value"] <= cfg["stepping_only_M_cell_updates_per_s"]
 
 
+@pytest.mark.gpu
+def test_bench_adaptive_distributed_path_on_real_rccl_with_one_rank():
+    """The adaptive loop's N > 1 branch on the REAL backend with one rank (T8GPU_BENCH_FORCE_DIST=1, as above): one native
+    communicator for the run, cross-check + trial steps with collective decisions, then a new halo descriptor and C++ stepper
+    for every adapted mesh -- no fall-back to the python-driven stages."""
+    env = dict(os.environ, T8GPU_BENCH_FORCE_DIST="1", T8GPU_C5A_LEVELS="4,6", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("T8GPU_REHEARSAL", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29656", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "45", "--warmup", "2",
+           "--workload", "c5a"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    cfg = rec["config"]
+    assert "unavailable" not in out.stderr, out.stderr[-3000:]
+    assert cfg["driver"] == "native C++ stepper (native rccl halo)" and cfg["adapt_cycles_timed"] == 2 and cfg["finite"] is True
+
+
 def test_bench_refuses_a_world_size_that_differs_from_gpus():
     """WORLD_SIZE != --gpus is an error, not a silently mislabelled run (needs no GPU: it exits before any GPU call)."""
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
