@@ -27,7 +27,11 @@ def main():
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     rank = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
-    mesh = SynthMesh(2, 7, 12, band=0.1472)
+    # T8GPU_HALO_WORKLOAD=c5: the 3D hexahedral AMR mesh of bench.py's c5 instead of c4 (pass its one-GPU ms/step as argument 4)
+    if __import__("os").environ.get("T8GPU_HALO_WORKLOAD") == "c5":
+        mesh = SynthMesh(3, 6, 8, band=0.05)
+    else:
+        mesh = SynthMesh(2, 7, 12, band=0.1472)
     part = mesh.partition(rank, world)
     dt = 0.1 * 2.0 ** -mesh.finest_level
     print(f"rank {rank}/{world}: N={part.N} G={part.G} peers={part.peers.tolist()}", flush=True)
