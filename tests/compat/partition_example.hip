@@ -4,7 +4,10 @@
 // every rank is a host thread of this process with the loopback transport of tests/compat/loopback_transport.h (one GPU, no
 // second RCCL rank available), the product uses t8gpu::RcclTransport over the same interface. Steps are the fused stage kernels
 // with the ghost layer refreshed before every stage, so the k-rank run must equal the single-rank run BIT FOR BIT, state and
-// element counts, after every cycle. Self-checking: prints "partition_example OK" and returns 0.
+// element counts, after every cycle. Further scenarios (other thresholds, 4 and 5 ranks) are run for what holds even where the k-rank
+// forest legitimately differs from the single-rank one (a family cut by a rank boundary is not coarsened): mass is conserved
+// through every adapt / partition / step, shares stay balanced to one element, every ghost slot holds its owner's value after
+// refresh_ghost_layer(). Self-checking: prints "partition_example OK" and returns 0.
 #include <t8gpu/backend/hip_fast.h>
 #include <t8gpu/mesh/mesh_manager.h>
 
@@ -87,26 +90,37 @@ struct Result {
   std::vector<float_type> state;        // this rank's final state [5][N]
   int64_t                 first = 0;
   int                     n     = 0;
+  double                  mass0 = 0, mass1 = 0;   // this rank's integral of the density: initial state, final state
+  // the ghost layer of the final density after refresh_ghost_layer(): values of the slots [N, N + G), and the lists that say whose they are
+  std::vector<float_type> ghost_rho;
+  HostHaloArrays          halo;
+};
+
+struct Scenario {
+  double threshold;   // of the adapt callback (10.0 in the reference, mesh_manager.inl:125-162)
+  int    min_level, max_level, cycles;
 };
 
 #define TRACE(what) do { if (std::getenv("T8GPU_TEST_TRACE")) std::fprintf(stderr, "[rank %d/%d] %s\n", rank, nranks, what); } while (0)
-static void run_rank(void* forest, int rank, int nranks, Transport* transport, Result* out) {
-  // (min_level = the initial level: elements are refined and refined families coarsened again, never the initial families --
-  //  a family cut by a rank boundary is not coarsened (t8gpu_synth_mesh_unmark_split_families, as t8code leaves it), which
-  //  would make the k-rank forest differ from the single-rank one for reasons that are not this test's business)
-  const int min_level = 5, max_level = 7, cycles = 3;
+static void run_rank(void* forest, int rank, int nranks, Transport* transport, Result* out, Scenario sc = {10.0, 5, 7, 3}) {
+  // (the default scenario: min_level = the initial level -- elements are refined and refined families coarsened again, never the
+  //  initial families. A family cut by a rank boundary is not coarsened (t8gpu_synth_mesh_unmark_split_families, as t8code leaves
+  //  it), which makes a k-rank forest differ from the single-rank one; the default scenario has no such family on 2 and 3 ranks)
+  const int min_level = sc.min_level, max_level = sc.max_level, cycles = sc.cycles;
   TRACE("construct");
   Manager   mm(forest, min_level, max_level, sc_MPI_Comm{rank, nranks});
   mm.set_transport(transport);
   StepList next = Step0, prev = Step3;
   TRACE("initial state");
   set_initial_state(mm);
+  hip::Reducer reduce;
+  auto mass = [&](StepList st) { return reduce.integral<float_type>(static_cast<size_t>(mm.get_num_local_elements()), mm.get_own_variable(st, Rho), mm.get_own_volume()); };
+  out->mass0 = mass(next);
   for (int cycle = 0; cycle < cycles; cycle++) {
     TRACE("criteria");
-    const std::vector<float_type>   c = criteria(mm, next);
-    thrust::host_vector<float_type> crit(c.begin(), c.end());
+    const std::vector<float_type> c = criteria(mm, next);
     TRACE("adapt");
-    mm.adapt(crit, next);
+    mm.adapt(c, next, sc.threshold);
     TRACE("partition");
     mm.partition(next);
     TRACE("connectivity");
@@ -129,12 +143,74 @@ static void run_rank(void* forest, int rank, int nranks, Transport* transport, R
     TRACE("cycle done");
   }
   TRACE("read back");
+  out->mass1 = mass(next);
+  mm.refresh_ghost_layer(next);
+  out->halo = mm.host_halo();
+  out->ghost_rho.resize(static_cast<size_t>(mm.get_num_ghost_elements()));
+  if (!out->ghost_rho.empty())
+    T8GPU_CUDA_CHECK_ERROR(hipMemcpy(out->ghost_rho.data(), mm.get_own_variable(next, Rho) + mm.get_num_local_elements(),
+                                     sizeof(float_type) * out->ghost_rho.size(), hipMemcpyDeviceToHost));
   out->n     = mm.get_num_local_elements();
   out->first = mm.host_arrays().first_global_element;
   out->state.resize(5 * static_cast<size_t>(out->n));
   for (int v = 0; v < 5; v++)
     T8GPU_CUDA_CHECK_ERROR(hipMemcpy(out->state.data() + static_cast<size_t>(v) * out->n, mm.get_own_variable(next, static_cast<VariableList>(v)),
                                      sizeof(float_type) * out->n, hipMemcpyDeviceToHost));
+}
+
+// What holds for every partitioned run, whatever its forest: mass conserved from the initial state to the end (periodic domain,
+// conservative scheme, conservative transfer), shares balanced to one element, every ghost slot = its owner's value.
+static bool invariants(std::vector<Result> const& res, char const* what) {
+  const int nranks = static_cast<int>(res.size());
+  double    m0 = 0, m1 = 0;
+  int       lo = res[0].n, hi = res[0].n;
+  for (auto const& x : res) { m0 += x.mass0; m1 += x.mass1; lo = std::min(lo, x.n); hi = std::max(hi, x.n); }
+  const double tol = sizeof(float_type) == 4 ? 2e-5 : 1e-11;
+  if (!(std::fabs(m1 - m0) <= tol * std::fabs(m0)) || !(m0 > 0)) {
+    std::printf("partition_example FAILED (%s, %d ranks): mass %.12g -> %.12g\n", what, nranks, m0, m1);
+    return false;
+  }
+  if (hi - lo > 1) {
+    std::printf("partition_example FAILED (%s, %d ranks): shares of %d .. %d elements after partition()\n", what, nranks, lo, hi);
+    return false;
+  }
+  size_t checked = 0;
+  for (int r = 0; r < nranks; r++) {
+    HostHaloArrays const& h = res[static_cast<size_t>(r)].halo;
+    for (size_t j = 0; j < h.peers.size(); j++) {
+      Result const&         o  = res[static_cast<size_t>(h.peers[j])];
+      HostHaloArrays const& oh = o.halo;
+      size_t                jj = oh.peers.size();
+      for (size_t k = 0; k < oh.peers.size(); k++)
+        if (oh.peers[k] == r) jj = k;
+      const int n = h.recv_off[j + 1] - h.recv_off[j];
+      if (jj == oh.peers.size() || oh.send_off[jj + 1] - oh.send_off[jj] != n) {
+        std::printf("partition_example FAILED (%s, %d ranks): the ghost lists of ranks %d and %d do not match\n", what, nranks, r, h.peers[j]);
+        return false;
+      }
+      for (int i = 0; i < n; i++, checked++) {
+        const float_type got = res[static_cast<size_t>(r)].ghost_rho[static_cast<size_t>(h.recv_off[j] + i)];
+        const float_type own = o.state[static_cast<size_t>(oh.send_idx[static_cast<size_t>(oh.send_off[jj] + i)])];   // (variable 0 = density)
+        if (std::memcmp(&got, &own, sizeof got) != 0) {
+          std::printf("partition_example FAILED (%s, %d ranks): ghost %d of rank %d from rank %d is stale\n", what, nranks, h.recv_off[j] + i, r, h.peers[j]);
+          return false;
+        }
+      }
+    }
+  }
+  std::printf("%s, %d ranks: mass %.12g kept to %.1e, shares %d .. %d, %zu ghost values = their owners'\n", what, nranks, m0, std::fabs(m1 - m0) / m0, lo, hi, checked);
+  return true;
+}
+
+static std::vector<Result> run_ranks(int nranks, void* (*forest)(), Scenario sc) {
+  t8gpu_test::LoopbackHub                    hub(nranks);
+  std::vector<t8gpu_test::LoopbackTransport> tr;
+  std::vector<Result>                        res(static_cast<size_t>(nranks));
+  for (int r = 0; r < nranks; r++) tr.emplace_back(hub, r);
+  std::vector<std::thread> th;
+  for (int r = 0; r < nranks; r++) th.emplace_back([&, r] { run_rank(forest(), r, nranks, &tr[static_cast<size_t>(r)], &res[static_cast<size_t>(r)], sc); });
+  for (auto& t : th) t.join();
+  return res;
 }
 
 int main() {
@@ -152,13 +228,8 @@ int main() {
     }
   }
   for (int nranks : {2, 3}) {
-    t8gpu_test::LoopbackHub                     hub(nranks);
-    std::vector<t8gpu_test::LoopbackTransport>  tr;
-    std::vector<Result>                         res(static_cast<size_t>(nranks));
-    for (int r = 0; r < nranks; r++) tr.emplace_back(hub, r);
-    std::vector<std::thread> th;
-    for (int r = 0; r < nranks; r++) th.emplace_back([&, r] { run_rank(forest(), r, nranks, &tr[static_cast<size_t>(r)], &res[static_cast<size_t>(r)]); });
-    for (auto& t : th) t.join();
+    std::vector<Result> res = run_ranks(nranks, +forest, Scenario{10.0, 5, 7, 3});
+    if (!invariants(res, "default scenario")) return 1;
     int total = 0;
     for (auto const& x : res) total += x.n;
     if (res[0].counts != one.counts || total != one.n) {
@@ -183,6 +254,22 @@ int main() {
     std::printf("%d ranks: elements per cycle %d %d %d, shares %d .. %d, state bitwise the single-rank run\n", nranks, res[0].counts[0], res[0].counts[1],
                 res[0].counts[2], lo, hi);
   }
+  // further scenarios: lower thresholds (more refinement, families coarsened where the sheet has moved on), coarsening below the
+  // initial level (min_level 4: families cut by a rank boundary stay), 4 and 5 ranks. The forests may differ from the single-rank
+  // run's here, so only the invariants are demanded -- and that at least one scenario really has a differing forest.
+  bool differed = false;
+  for (Scenario sc : {Scenario{10.0, 4, 7, 3}, Scenario{4.0, 4, 6, 4}, Scenario{2.0, 5, 7, 3}}) {
+    Result ref;
+    run_rank(forest(), 0, 1, nullptr, &ref, sc);
+    for (int nranks : {2, 3, 4, 5}) {
+      char what[96];
+      std::snprintf(what, sizeof what, "threshold %g levels %d-%d", sc.threshold, sc.min_level, sc.max_level);
+      std::vector<Result> res = run_ranks(nranks, +forest, sc);
+      if (!invariants(res, what)) return 1;
+      differed = differed || res[0].counts != ref.counts;
+    }
+  }
+  std::printf("a k-rank forest differed from the single-rank one in some scenario: %s\n", differed ? "yes" : "no");
   if (!(one.counts[0] > 1024 && one.counts[2] != one.counts[0])) {
     std::printf("partition_example FAILED: the mesh did not change (%d %d %d)\n", one.counts[0], one.counts[1], one.counts[2]);
     return 1;

@@ -111,7 +111,9 @@ def test_subgrid_api_runs(tmp_path):
 def test_partition_example_runs():
     """MeshManager::adapt -> partition -> compute_connectivity_information on 2 and 3 ranks (host threads of one process, loopback
     transport: tests/compat/loopback_transport.h) with fused steps in between: bitwise the single-rank run, shares balanced to one
-    element (t8gpu/mesh/mesh_manager.inl:196-330, 626-723). The product's transport is t8gpu::RcclTransport over the same interface
+    element (t8gpu/mesh/mesh_manager.inl:196-330, 626-723). Three further scenarios on 2 - 5 ranks -- coarsening below the initial
+    level, where a family cut by a rank boundary stays and the forests legitimately differ -- for the invariants: mass conserved,
+    balanced shares, every ghost slot equal to its owner's value after refresh_ghost_layer(). The product's transport is t8gpu::RcclTransport over the same interface
     (t8gpu_hip_repartition_*, t8gpu_hip_comm_allgatherv_f64, t8gpu_hip_halo_exchange_*)."""
     exe = compile_example("partition_example.hip", "partition_example")
     res = subprocess.run([exe], capture_output=True, text=True, timeout=240)
@@ -122,7 +124,8 @@ def test_partition_example_runs():
 def test_subgrid_partition_example_runs():
     """SubgridMeshManager::adapt -> partition -> compute_connectivity_information on 2 and 3 ranks (loopback transport), whole
     Subgrid<4,4,4> blocks on the wire (cells_per_element = 64), fused block-kernel steps with the ghost blocks refreshed per stage:
-    bitwise the single-rank run (t8gpu/mesh/subgrid_mesh_manager.inl:428-558, 1217-1369)."""
+    bitwise the single-rank run (t8gpu/mesh/subgrid_mesh_manager.inl:428-558, 1217-1369); the reference's threshold and half of it
+    on 2 - 4 ranks (forests differ where a family is cut) for mass, balance and ghost blocks."""
     exe = compile_example("subgrid_partition_example.hip", "subgrid_partition_example")
     res = subprocess.run([exe], capture_output=True, text=True, timeout=240)
     assert res.returncode == 0 and "subgrid_partition_example OK" in res.stdout, res.stdout + res.stderr
