@@ -178,6 +178,13 @@ namespace t8gpu::hip {
       m_plan.ell        = up(ell);
       m_plan.geo_idx    = ngeo ? up(geo_idx) : nullptr;
       m_plan.geo_table  = ngeo ? up(std::vector<ft>(table.begin(), table.end())) : nullptr;
+      if (ngeo) {   // the dictionary's tangent rows by the device's own routine (t8gpu_hip.h: same bits as per-face geometry rows)
+        if constexpr (sizeof(ft) == 4)
+          T8GPU_HIP_CHECK_ABI(t8gpu_hip_plain_geo_frames_f32(const_cast<void*>(static_cast<const void*>(m_plan.geo_table)), static_cast<int>(ngeo), nullptr));
+        else
+          T8GPU_HIP_CHECK_ABI(t8gpu_hip_plain_geo_frames_f64(const_cast<void*>(static_cast<const void*>(m_plan.geo_table)), static_cast<int>(ngeo), nullptr));
+        T8GPU_CUDA_CHECK_ERROR(hipStreamSynchronize(nullptr));
+      }
       m_plan.ntiles = static_cast<int32_t>(nt); m_plan.n_interior_tiles = static_cast<int32_t>(sz[7]);
       m_plan.max_elems = static_cast<int32_t>(sz[4]); m_plan.max_halo = static_cast<int32_t>(sz[5]);
       m_plan.max_faces = static_cast<int32_t>(sz[6]); m_plan.ell_width = static_cast<int32_t>(w);

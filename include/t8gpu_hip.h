@@ -220,6 +220,14 @@ int t8gpu_hip_plain_persistent_accepts(const T8gpuPlainPlan* plan, int flux_kind
  * (ELL rows + tile descriptors), whose callers need not upload the CSR lists: the launcher's own test, from the plan's
  * integer fields and the NULL-ness of ell / tile_desc alone; no GPU is needed. */
 int t8gpu_hip_plain_needs_csr(const T8gpuPlainPlan* plan);
+/* The tangent rows of a geometry dictionary ALREADY ON THE DEVICE (`geo_table`: n_geo rows {n, area} {t1, .} {t2, .} of the
+ * plan's float type), recomputed from its normals by the routine the per-face kernels use (flux_math.hpp: face_basis_fast --
+ * the frame of kernels.cu:174-193 with one reciprocal square root instead of a square root and three divisions). Plan builders
+ * call it once after the upload, so that a tile evaluated with the dictionary and the same face evaluated with per-face
+ * geometry rows (a partition of the mesh, another tile cap) see the same bits; the host planner's own frames
+ * (t8gpu_plan_plain_compressed) differ from these in the last bit on oblique normals. */
+int t8gpu_hip_plain_geo_frames_f32(void* geo_table, int n_geo, void* stream);
+int t8gpu_hip_plain_geo_frames_f64(void* geo_table, int n_geo, void* stream);
 
 /* ---- ghost-layer exchange (device side) ----------------------------------------------------------
  * Replaces the reference's cross-rank pointer sharing (cudaIpc*, t8gpu/memory/shared_device_vector.inl:

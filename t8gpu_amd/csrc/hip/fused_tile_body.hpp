@@ -241,7 +241,7 @@ T8_DEV void plain_tile_body(const T8gpuPlainPlan& P, int pos, const FVars<T>& pr
         t1[0] = b1.x; t1[1] = b1.y; t1[2] = b1.z;
         t2[0] = b2.x; t2[1] = b2.y; t2[2] = b2.z;
       } else {
-        face_basis<T>(n, t1, t2);
+        face_basis_fast<T>(n, t1, t2);
       }
       if (KIND == 0) {
         Prim<T> L, R;

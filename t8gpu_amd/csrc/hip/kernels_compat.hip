@@ -363,7 +363,7 @@ using namespace t8gpu_hip;
 extern "C" {
 
 const char* t8gpu_hip_last_stage_kernel(void) { return stage_kernel_note().name; }
-int t8gpu_hip_abi_version(void) { return 7; }   // 2: T8gpuPlainPlan.tile_desc; 3: T8gpuSubgridPlan row format (far-cell recipes), n_blocks_addressed, family records; 4: T8gpuPlainPlan.n_patch_tiles; 5: T8gpuPlainPlan.ell holds rows for generic tiles only (tile_desc word 6), patch_dim; 6: T8gpuPlainPlan.n_irregular_tiles; 7: T8gpuPlainPlan ghost window (ghost_buf, send_map, send_list, send_buf, n_owned)
+int t8gpu_hip_abi_version(void) { return 8; }   // 2: T8gpuPlainPlan.tile_desc; 3: T8gpuSubgridPlan row format (far-cell recipes), n_blocks_addressed, family records; 4: T8gpuPlainPlan.n_patch_tiles; 5: T8gpuPlainPlan.ell holds rows for generic tiles only (tile_desc word 6), patch_dim; 6: T8gpuPlainPlan.n_irregular_tiles; 7: T8gpuPlainPlan ghost window (ghost_buf, send_map, send_list, send_buf, n_owned); 8: t8gpu_hip_plain_geo_frames_* (plan builders must call it)
 int t8gpu_hip_device_count(int* count) { return static_cast<int>(hipGetDeviceCount(count)); }
 int t8gpu_hip_set_device(int device) { return static_cast<int>(hipSetDevice(device)); }
 const char* t8gpu_hip_error_string(int code) {

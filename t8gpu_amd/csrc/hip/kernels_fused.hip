@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_plain_fused(T8gpuPlainPlan P, int tile_
     const int      r = wall ? l : r16;
     const T        n[3] = {gm.x, gm.y, gm.z};
     T              t1[3], t2[3], g[5], spd = T(0);
-    face_basis<T>(n, t1, t2);
+    face_basis_fast<T>(n, t1, t2);
     if (KIND == 0) {
       Prim<T> L, R;
       L.rho = pe[0 * LE + l]; L.vx = pe[1 * LE + l]; L.vy = pe[2 * LE + l]; L.vz = pe[3 * LE + l]; L.p = pe[4 * LE + l];
@@ -340,7 +340,32 @@ int plain_fused_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile_
 
 }  // namespace t8gpu_hip
 
+namespace t8gpu_hip {
+template <class T>
+__global__ __launch_bounds__(128) void k_geo_frames(T* __restrict__ table, int n_geo) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_geo) return;
+  T* const row  = table + 12 * static_cast<size_t>(i);
+  const T  n[3] = {row[0], row[1], row[2]};
+  T        t1[3], t2[3];
+  face_basis_fast<T>(n, t1, t2);
+  for (int k = 0; k < 3; k++) {
+    row[4 + k] = t1[k];
+    row[8 + k] = t2[k];
+  }
+}
+template <class T>
+int geo_frames(void* table, int n_geo, void* stream) {
+  if (n_geo < 0 || (n_geo > 0 && !table)) return static_cast<int>(hipErrorInvalidValue);
+  if (n_geo == 0) return 0;
+  hipLaunchKernelGGL((k_geo_frames<T>), dim3((n_geo + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream), static_cast<T*>(table), n_geo);
+  return static_cast<int>(hipGetLastError());
+}
+}  // namespace t8gpu_hip
+
 extern "C" {
+int t8gpu_hip_plain_geo_frames_f32(void* geo_table, int n_geo, void* stream) { return t8gpu_hip::geo_frames<float>(geo_table, n_geo, stream); }
+int t8gpu_hip_plain_geo_frames_f64(void* geo_table, int n_geo, void* stream) { return t8gpu_hip::geo_frames<double>(geo_table, n_geo, stream); }
 int t8gpu_hip_plain_needs_csr(const T8gpuPlainPlan* plan) { return plan && t8gpu_hip::plain_tiles_pipelined(plan) ? 0 : 1; }
 int t8gpu_hip_plain_fused_stage_f32(int kind, int stage, const T8gpuPlainPlan* plan, int tile_begin, int tile_count,
                                     T8gpuVars_f32 prev, T8gpuVars_f32 mid, T8gpuVars_f32 out, const float* volume,

@@ -185,6 +185,8 @@ class PlainPlan:
                 t = hostmem.to_device(a)
                 self._keep[name] = t
                 setattr(c, name, t.data_ptr())
+            if c.n_geo > 0:   # the dictionary's tangent rows by the device's own routine (t8gpu_hip.h: same bits as per-face geometry)
+                hip.call("t8gpu_hip_plain_geo_frames", dtype, hip.ptr(self._keep["geo_table"]), int(c.n_geo), hip.stream_ptr())
         c.ntiles, c.n_interior_tiles = self.host.ntiles, self.host.n_interior
         c.max_elems, c.max_halo, c.max_faces = self.host.max_elems, self.host.max_halo, self.host.max_faces
         c.max_slots, c.n_deep_tiles = self.host.max_slots, self.host.n_deep

@@ -6,7 +6,7 @@ import numpy as np
 
 from . import build as _build
 
-ABI_VERSION = 7   # t8gpu_hip_abi_version() of include/t8gpu_hip.h: the layout of the plan structs mirrored in fused.py
+ABI_VERSION = 8   # t8gpu_hip_abi_version() of include/t8gpu_hip.h: the layout of the plan structs mirrored in fused.py
 KEPES, HLL, HLLC = 0, 1, 2   # HLLC is an addition: the reference has none
 
 
