@@ -10,6 +10,7 @@
 //                third of the divisions. Used by the fused tile kernels.
 #pragma once
 
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include "log_table.hpp"
@@ -362,6 +363,35 @@ T8_DEV double t8_sqrt_ratio(double y, double x) {
   const double a  = (y + y) * h;                         // y / sqrt(y x)
   const double d  = __builtin_fma(-a, a * x, y);         // residual y - a^2 x; 1 / (2 a x) = h
   return __builtin_fma(d, h, a);
+}
+
+// Stage results and the previous step's state are touched ONCE per stage kernel. Where the planes of a stage (previous, source,
+// result: 15 of them) are much larger than the 256 MB Infinity Cache, caching them only evicts what is about to be re-read (the
+// source states of neighbouring tiles): non-temporal accesses there (NT instantiations of the patch and family kernels: c4 fp64
+// +2.6 %, fp32 +4.9 %, c3 +2 - 3 %, c5 +2.5 %) and ordinary ones where the working set stays resident (c2, 1.03 M elements: -8 % with
+// non-temporal stores; c5u -1.5 %). A compile-time choice: as a wave-uniform run-time branch the two arms have to be kept apart
+// with scheduling barriers (the optimiser merges them and drops the hint otherwise), which cost 2 - 5 % -- more than the gain.
+template <bool NT, class T>
+T8_DEV T stream_load(const T* p) {
+  if constexpr (NT)
+    return __builtin_nontemporal_load(p);
+  else
+    return *p;
+}
+template <bool NT, class T>
+T8_DEV void stream_store(T* p, T v) {
+  if constexpr (NT)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
+}
+// The launchers' test: T8GPU_STREAM_MB = the threshold in MB (default 384 = 1.5 x the cache), 0 = never.
+inline bool stream_hint(long long cells, size_t float_size) {
+  static const long long mb = [] {
+    const char* env = std::getenv("T8GPU_STREAM_MB");
+    return env ? std::atoll(env) : 384ll;
+  }();
+  return mb > 0 && cells > 0 && 15ll * cells * static_cast<long long>(float_size) > mb * (1ll << 20);
 }
 
 // 1 / sqrt(x) for the fast tier (x > 0, normal range): the hardware seed (v_rsq_f64: ~2^-23) and two Newton steps, ~1 ulp;

@@ -39,7 +39,7 @@ namespace t8gpu_hip {
 // chunk = 0: persistent walk -- the XCD's workgroups stride through its share together (tiles j, j + n, ...); chunk = c > 0:
 // workgroup j of the XCD takes the c CONSECUTIVE tiles [j c, j c + c) of the share and leaves (a grid of ~count / c
 // workgroups that the hardware hands out as slots free up: what a launch beside other kernels wants, see plain_patch_stage)
-template <class T, int KIND, int STAGE>
+template <class T, int KIND, int STAGE, bool NT>
 T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_count, int wg, int nwg, int chunk, const FVars<T>& prev,
                              const FVars<T>& src, const FVars<T>& out, const T* __restrict__ vol, T dt, T* __restrict__ speed) {
   constexpr int NW  = KIND == 0 ? kPrimWords : 5;
@@ -157,7 +157,7 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
     T         pv[5] = {T(0), T(0), T(0), T(0), T(0)};
     if (STAGE > 1) {
 #pragma unroll
-      for (int k = 0; k < 5; k++) pv[k] = at32<T>(prev.p[k], static_cast<unsigned>(e));
+      for (int k = 0; k < 5; k++) pv[k] = stream_load<NT>(&at32<T>(prev.p[k], static_cast<unsigned>(e)));
     }
     // (patches of uniform volume carry it in their descriptor: 8 of ~130 bytes per element and stage less to load)
     const T volume = (d0.flags & 0x400) ? static_cast<T>(d0.vol) : at32<T>(vol, static_cast<unsigned>(e));
@@ -184,7 +184,7 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
     }
     if (res_e >= 0) {   // results of the previous patch: behind this iteration's first wait (vmcnt retires in order)
 #pragma unroll
-      for (int k = 0; k < 5; k++) at32<T>(out.p[k], static_cast<unsigned>(res_e)) = res[k];
+      for (int k = 0; k < 5; k++) stream_store<NT>(&at32<T>(out.p[k], static_cast<unsigned>(res_e)), res[k]);
     }
     __syncthreads();
 
@@ -247,31 +247,31 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
   }
   if (res_e >= 0) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) at32<T>(out.p[k], static_cast<unsigned>(res_e)) = res[k];
+    for (int k = 0; k < 5; k++) stream_store<NT>(&at32<T>(out.p[k], static_cast<unsigned>(res_e)), res[k]);
     if (P.send_map) ghost_window_send<T>(P, res_e, res);   // (one patch per workgroup there: this is its only store)
   }
 }
 
 // (second launch bound = waves per SIMD the register allocation must allow: 3 workgroups per CU in fp64, 5 in fp32)
-template <class T, int KIND, int STAGE>
+template <class T, int KIND, int STAGE, bool NT>
 __global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_patch(T8gpuPlainPlan P, int tile_begin, int tile_count, int chunk, FVars<T> prev,
                                                                                 FVars<T> src, FVars<T> out, const T* __restrict__ vol, T dt,
                                                                                 T* __restrict__ speed) {
-  plain_patch_body<T, KIND, STAGE>(P, tile_begin, tile_count, blockIdx.x, gridDim.x, chunk, prev, src, out, vol, dt, speed);
+  plain_patch_body<T, KIND, STAGE, NT>(P, tile_begin, tile_count, blockIdx.x, gridDim.x, chunk, prev, src, out, vol, dt, speed);
 }
 
 // ONE launch per stage for a range of tile_order that holds patch tiles AND generic tiles: the first `patch_wgs`
 // workgroups walk the patch tiles, every further workgroup takes one generic tile (fused_tile_body.hpp). As two launches
 // the generic tiles of the benchmark mesh -- 3 % of its elements -- cost 9 % of the stage: a launch of their own, started
 // when the patch launch has drained. Here they start as the persistent patch workgroups finish and fill the ragged end.
-template <class T, int KIND, int STAGE>
+template <class T, int KIND, int STAGE, bool NT>
 __global__ __launch_bounds__(256, sizeof(T) == 8 ? 3 : 5) void k_plain_stage(T8gpuPlainPlan P, int patch_begin, int patch_count, int patch_wgs, int chunk,
                                                                                 int tile_begin, int tile_count, FVars<T> prev, FVars<T> src,
                                                                                 FVars<T> out, const T* __restrict__ vol, T dt,
                                                                                 T* __restrict__ speed) {
   const int b = blockIdx.x;
   if (b < patch_wgs) {
-    plain_patch_body<T, KIND, STAGE>(P, patch_begin, patch_count, b, patch_wgs, chunk, prev, src, out, vol, dt, speed);
+    plain_patch_body<T, KIND, STAGE, NT>(P, patch_begin, patch_count, b, patch_wgs, chunk, prev, src, out, vol, dt, speed);
   } else {
 #ifdef T8GPU_EXP_TILEMOD
     const int pos = tile_begin + xcd_position(b - patch_wgs, tile_count) % T8GPU_EXP_TILEMOD;
@@ -346,16 +346,26 @@ int plain_patch_stage(int kind, int stage, const T8gpuPlainPlan* plan, int patch
     patch_wgs       = 8 * ((share + chunk - 1) / chunk);
   }
   const dim3 grid(patch_wgs + (tile_count > 0 ? tile_count : 0)), block(256);
-  note_stage_kernel(patch_count + (tile_count > 0 ? tile_count : 0), tile_count > 0 ? "k_plain_stage<T, K, S>" : "k_plain_patch<T, K, S>",
+  // non-temporal stage results / previous-state loads where the stage's planes are a stream for the caches (flux_math.hpp)
+  const bool nt = stream_hint(plan->n_slots_addressed, sizeof(T));
+  note_stage_kernel(patch_count + (tile_count > 0 ? tile_count : 0),
+                    tile_count > 0 ? (nt ? "k_plain_stage<T, K, S, true>" : "k_plain_stage<T, K, S, false>") : (nt ? "k_plain_patch<T, K, S, true>" : "k_plain_patch<T, K, S, false>"),
                     static_cast<int>(sizeof(T)), kind, stage);
-#define T8_PA(K, S)                                                                                                               \
+#define T8_PAN(K, S, N)                                                                                                           \
   do {                                                                                                                            \
     if (tile_count > 0)                                                                                                           \
-      hipLaunchKernelGGL((k_plain_stage<T, K, S>), grid, block, lds, stream, *plan, patch_begin, patch_count, patch_wgs, chunk, tile_begin, \
+      hipLaunchKernelGGL((k_plain_stage<T, K, S, N>), grid, block, lds, stream, *plan, patch_begin, patch_count, patch_wgs, chunk, tile_begin, \
                          tile_count, prev, mid, out, volume, dt, speed);                                                          \
     else                                                                                                                          \
-      hipLaunchKernelGGL((k_plain_patch<T, K, S>), grid, block, lds, stream, *plan, patch_begin, patch_count, chunk, prev, mid, out, volume, dt, \
+      hipLaunchKernelGGL((k_plain_patch<T, K, S, N>), grid, block, lds, stream, *plan, patch_begin, patch_count, chunk, prev, mid, out, volume, dt, \
                          speed);                                                                                                  \
+  } while (0)
+#define T8_PA(K, S)        \
+  do {                     \
+    if (nt)                \
+      T8_PAN(K, S, true);  \
+    else                   \
+      T8_PAN(K, S, false); \
   } while (0)
 #define T8_PAS(K)          \
   do {                     \
@@ -374,6 +384,7 @@ int plain_patch_stage(int kind, int stage, const T8gpuPlainPlan* plan, int patch
     T8_PAS(2);
 #undef T8_PAS
 #undef T8_PA
+#undef T8_PAN
   return static_cast<int>(hipGetLastError());
 }
 

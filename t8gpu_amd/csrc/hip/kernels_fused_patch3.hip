@@ -77,7 +77,7 @@ T8_DEV int patch3_fresh(int v) {
 // instantiation: the regular one keeps its register budget.
 // workgroup `wg` of the `nwg` that share the patch tiles [tile_begin, tile_begin + tile_count) of tile_order (nwg a multiple of 8
 // or < 8: wg & 7 must be the workgroup's XCD)
-template <class T, int KIND, int STAGE, bool IRR>
+template <class T, int KIND, int STAGE, bool IRR, bool NT>
 T8_DEV void plain_patch3_body(const T8gpuPlainPlan& P, int tile_begin, int tile_count, int wg, int nwg, const FVars<T>& prev,
                               const FVars<T>& src, const FVars<T>& out, const T* __restrict__ vol, T dt, T* __restrict__ speed) {
   constexpr int NW  = KIND == 0 ? kPrimWords : 5;
@@ -182,7 +182,7 @@ T8_DEV void plain_patch3_body(const T8gpuPlainPlan& P, int tile_begin, int tile_
     if (!side) {
       if (STAGE > 1) {
 #pragma unroll
-        for (int k = 0; k < 5; k++) pv[k] = at32<T>(prev.p[k], static_cast<unsigned>(e));
+        for (int k = 0; k < 5; k++) pv[k] = stream_load<NT>(&at32<T>(prev.p[k], static_cast<unsigned>(e)));
       }
       volume = (d0.flags & 0x400) ? static_cast<T>(d0.vol) : at32<T>(vol, static_cast<unsigned>(e));   // (uniform patch volume from the descriptor)
     }
@@ -307,7 +307,7 @@ T8_DEV void plain_patch3_body(const T8gpuPlainPlan& P, int tile_begin, int tile_
       }
       const T scale = dt / volume;
 #pragma unroll
-      for (int k = 0; k < 5; k++) at32<T>(out.p[k], static_cast<unsigned>(e)) = rk_stage_update<T, STAGE>(pv[k], cur[k], scale, acc[k]);
+      for (int k = 0; k < 5; k++) stream_store<NT>(&at32<T>(out.p[k], static_cast<unsigned>(e)), rk_stage_update<T, STAGE>(pv[k], cur[k], scale, acc[k]));
     } else if (!side) {
       const bool yx = f_yx ? (d0.flags & 1) != 0 : r_yx;   // -y before -x
       const bool zx = f_zx ? (d0.flags & 2) != 0 : r_zx;   // -z before -x
@@ -328,7 +328,7 @@ T8_DEV void plain_patch3_body(const T8gpuPlainPlan& P, int tile_begin, int tile_
       }
       const T scale = dt / volume;
 #pragma unroll
-      for (int k = 0; k < 5; k++) at32<T>(out.p[k], static_cast<unsigned>(e)) = rk_stage_update<T, STAGE>(pv[k], cur[k], scale, acc[k]);
+      for (int k = 0; k < 5; k++) stream_store<NT>(&at32<T>(out.p[k], static_cast<unsigned>(e)), rk_stage_update<T, STAGE>(pv[k], cur[k], scale, acc[k]));
     }
 #pragma unroll
     for (int k = 0; k < 5; k++) cur[k] = nxt[k];
@@ -344,11 +344,11 @@ T8_DEV void plain_patch3_body(const T8gpuPlainPlan& P, int tile_begin, int tile_
 
 // (second launch bound = wavefronts per SIMD the register allocation must allow: two 8-wave workgroups per CU in fp64 --
 //  77 KB of LDS each --, three in fp32)
-template <class T, int KIND, int STAGE, bool IRR>
+template <class T, int KIND, int STAGE, bool IRR, bool NT>
 __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8gpuPlainPlan P, int tile_begin, int tile_count, FVars<T> prev,
                                                                                  FVars<T> src, FVars<T> out, const T* __restrict__ vol, T dt,
                                                                                  T* __restrict__ speed) {
-  plain_patch3_body<T, KIND, STAGE, IRR>(P, tile_begin, tile_count, blockIdx.x, gridDim.x, prev, src, out, vol, dt, speed);
+  plain_patch3_body<T, KIND, STAGE, IRR, NT>(P, tile_begin, tile_count, blockIdx.x, gridDim.x, prev, src, out, vol, dt, speed);
 }
 
 // REGULAR and IRREGULAR patches of one class in ONE launch (round 4): the first `reg_wgs` workgroups (a multiple of 8) walk the
@@ -356,16 +356,16 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3(T8
 // (the regular body's 114, the irregular one's 128: nothing is live across the branch, so neither spills; both forms behind a
 // per-PATCH branch inside one loop cost 13-30 spills, round 3). As two launches the second one starts when the first has
 // drained: one tail and one launch gap per stage less.
-template <class T, int KIND, int STAGE>
+template <class T, int KIND, int STAGE, bool NT>
 __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_plain_patch3_both(T8gpuPlainPlan P, int reg_begin, int reg_count, int reg_wgs,
                                                                                       int irr_begin, int irr_count, FVars<T> prev, FVars<T> src,
                                                                                       FVars<T> out, const T* __restrict__ vol, T dt,
                                                                                       T* __restrict__ speed) {
   const int b = blockIdx.x;
   if (b < reg_wgs)
-    plain_patch3_body<T, KIND, STAGE, false>(P, reg_begin, reg_count, b, reg_wgs, prev, src, out, vol, dt, speed);
+    plain_patch3_body<T, KIND, STAGE, false, NT>(P, reg_begin, reg_count, b, reg_wgs, prev, src, out, vol, dt, speed);
   else
-    plain_patch3_body<T, KIND, STAGE, true>(P, irr_begin, irr_count, b - reg_wgs, static_cast<int>(gridDim.x) - reg_wgs, prev, src, out, vol, dt, speed);
+    plain_patch3_body<T, KIND, STAGE, true, NT>(P, irr_begin, irr_count, b - reg_wgs, static_cast<int>(gridDim.x) - reg_wgs, prev, src, out, vol, dt, speed);
 }
 
 // tiles [tile_begin, tile_begin + tile_count) of tile_order must all be 3D patch tiles. persistent = false: one patch per
@@ -390,24 +390,30 @@ int plain_patch3_stage(int kind, int stage, const T8gpuPlainPlan* plan, int tile
   const int  resident  = cus * per_cu;
   const int  grid_size = (!persistent || tile_count < resident) ? tile_count : resident;
   const dim3 grid(grid_size), block(512);
-  note_stage_kernel(tile_count, irregular ? "k_plain_patch3<T, K, S, true>" : "k_plain_patch3<T, K, S, false>", static_cast<int>(sizeof(T)), kind,
+  const bool nt = stream_hint(plan->n_slots_addressed, sizeof(T));   // (flux_math.hpp: stream_store)
+  note_stage_kernel(tile_count, irregular ? (nt ? "k_plain_patch3<T, K, S, true, true>" : "k_plain_patch3<T, K, S, true, false>")
+                                          : (nt ? "k_plain_patch3<T, K, S, false, true>" : "k_plain_patch3<T, K, S, false, false>"), static_cast<int>(sizeof(T)), kind,
                     stage);
-#define T8_P3I(K, S, I)                                                                                                      \
+#define T8_P3I(K, S, I, N)                                                                                                     \
   do {                                                                                                                       \
     if (lds > 64 * 1024) {                                                                                                   \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_plain_patch3<T, K, S, I>),                         \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_plain_patch3<T, K, S, I, N>),                         \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                 \
       if (e != hipSuccess) return static_cast<int>(e);                                                                       \
     }                                                                                                                        \
-    hipLaunchKernelGGL((k_plain_patch3<T, K, S, I>), grid, block, lds, stream, *plan, tile_begin, tile_count, prev, mid, out, volume, \
+    hipLaunchKernelGGL((k_plain_patch3<T, K, S, I, N>), grid, block, lds, stream, *plan, tile_begin, tile_count, prev, mid, out, volume, \
                        dt, speed);                                                                                           \
   } while (0)
-#define T8_P3(K, S)          \
-  do {                       \
-    if (irregular)           \
-      T8_P3I(K, S, true);    \
-    else                     \
-      T8_P3I(K, S, false);   \
+#define T8_P3(K, S)                  \
+  do {                               \
+    if (irregular && nt)             \
+      T8_P3I(K, S, true, true);      \
+    else if (irregular)              \
+      T8_P3I(K, S, true, false);     \
+    else if (nt)                     \
+      T8_P3I(K, S, false, true);     \
+    else                             \
+      T8_P3I(K, S, false, false);    \
   } while (0)
 #define T8_P3S(K)          \
   do {                     \
@@ -455,16 +461,24 @@ int plain_patch3_both_stage(int kind, int stage, const T8gpuPlainPlan* plan, int
   const size_t lds = sizeof(T) * (static_cast<size_t>(5) * kP3FF + static_cast<size_t>(rec) * 512) +
                      ((sizeof(T) == 8 && kind == 0) ? 2 * kLogTabEntries * sizeof(double) : 0);
   const dim3 grid(resident), block(512);
-  note_stage_kernel(reg_count + irr_count, "k_plain_patch3_both<T, K, S>", static_cast<int>(sizeof(T)), kind, stage);
-#define T8_P3B(K, S)                                                                                                          \
+  const bool nt = stream_hint(plan->n_slots_addressed, sizeof(T));   // (flux_math.hpp: stream_store)
+  note_stage_kernel(reg_count + irr_count, nt ? "k_plain_patch3_both<T, K, S, true>" : "k_plain_patch3_both<T, K, S, false>", static_cast<int>(sizeof(T)), kind, stage);
+#define T8_P3BN(K, S, N)                                                                                                         \
   do {                                                                                                                       \
     if (lds > 64 * 1024) {                                                                                                   \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_plain_patch3_both<T, K, S>),                       \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_plain_patch3_both<T, K, S, N>),                       \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                 \
       if (e != hipSuccess) return static_cast<int>(e);                                                                       \
     }                                                                                                                        \
-    hipLaunchKernelGGL((k_plain_patch3_both<T, K, S>), grid, block, lds, stream, *plan, reg_begin, reg_count, reg_wgs, irr_begin, irr_count, \
+    hipLaunchKernelGGL((k_plain_patch3_both<T, K, S, N>), grid, block, lds, stream, *plan, reg_begin, reg_count, reg_wgs, irr_begin, irr_count, \
                        prev, mid, out, volume, dt, speed);                                                                   \
+  } while (0)
+#define T8_P3B(K, S)        \
+  do {                      \
+    if (nt)                 \
+      T8_P3BN(K, S, true);  \
+    else                    \
+      T8_P3BN(K, S, false); \
   } while (0)
 #define T8_P3BS(K)         \
   do {                     \
@@ -483,6 +497,7 @@ int plain_patch3_both_stage(int kind, int stage, const T8gpuPlainPlan* plan, int
     T8_P3BS(2);
 #undef T8_P3BS
 #undef T8_P3B
+#undef T8_P3BN
   return static_cast<int>(hipGetLastError());
 }
 

@@ -239,7 +239,7 @@ T8_DEV void block_sync() {
 // One wavefront's work on its block(s): `pos_base` = the wavefront's position in the launch (RANK 3: the block record;
 // RANK 2: four records), c = lane, pe / xb = the wavefront's LDS slices ([NW][64 + BPW * PF] cells of the block(s) then
 // the far cells of their + faces; [5][64] flux exchange buffer).
-template <class T, int KIND, int STAGE, int RANK, bool EARLY_PREV, bool WIDE, bool WAVE_ONLY>
+template <class T, int KIND, int STAGE, int RANK, bool EARLY_PREV, bool WIDE, bool WAVE_ONLY, bool NT = false>
 T8_DEV void subgrid_block(const T8gpuSubgridPlan& P, int block_begin, int block_count, int pos_base, int c, const SVars<T>& prev,
                           const SVars<T>& src, const SVars<T>& out, const T* __restrict__ volumes, T dt, T* pe, T* xb) {
   // (pe / xb carry no __restrict__: other lanes write what this lane reads, and a no-alias pointer would let the
@@ -286,7 +286,7 @@ T8_DEV void subgrid_block(const T8gpuSubgridPlan& P, int block_begin, int block_
   T pv[5] = {T(0), T(0), T(0), T(0), T(0)};
   if (STAGE > 1 && EARLY_PREV) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) pv[k] = at<WIDE>(prev.p[k], o);
+    for (int k = 0; k < 5; k++) pv[k] = stream_load<NT>(&at<WIDE>(prev.p[k], o));
   }
   const PlusFace<T> fx = plus_face<T>(brec[1], live), fy = plus_face<T>(brec[2], live),
                     fz = RANK == 3 ? plus_face<T>(brec[3], live) : PlusFace<T>{false, false, 0, 0, T(0)};
@@ -457,12 +457,12 @@ T8_DEV void subgrid_block(const T8gpuSubgridPlan& P, int block_begin, int block_
   if (live) {
     if (STAGE > 1 && !EARLY_PREV) {
 #pragma unroll
-      for (int k = 0; k < 5; k++) pv[k] = at<WIDE>(prev.p[k], o);
+      for (int k = 0; k < 5; k++) pv[k] = stream_load<NT>(&at<WIDE>(prev.p[k], o));
     }
     const T scale = dt / (vol / T(S));
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-      at<WIDE>(out.p[k], o) = rk_stage_update<T, STAGE>(pv[k], s0[k], scale, acc[k]);
+      stream_store<NT>(&at<WIDE>(out.p[k], o), rk_stage_update<T, STAGE>(pv[k], s0[k], scale, acc[k]));
     }
   }
 }
@@ -504,7 +504,7 @@ T8_DEV int fam_expand(int j, int d) { return d == 0 ? j << 1 : (d == 1 ? (j & 1)
 
 // (second launch bound = wavefronts per SIMD the register allocation must allow: 3 workgroups per CU in fp32 (80 VGPRs),
 //  2 in fp64 (128 VGPRs; its 66 KB of LDS allow no more))
-template <class T, int KIND, int STAGE, bool WIDE>
+template <class T, int KIND, int STAGE, bool WIDE, bool NT>
 __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_subgrid_family(T8gpuSubgridPlan P, SVars<T> prev, SVars<T> src, SVars<T> out,
                                                         const T* __restrict__ volumes, T dt) {
   constexpr int  NW    = CellData<T, KIND>::words;
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_subgrid_family(
       T8gpuSubgridPlan R = P;
       R.block_rec        = P.rest_rec;
       T* const mine_lds  = lds + w * BLK_WORDS;
-      subgrid_block<T, KIND, STAGE, 3, sizeof(T) == 4, WIDE, true>(R, 0, P.n_rest, pos, c, prev, src, out, volumes, dt, mine_lds,
+      subgrid_block<T, KIND, STAGE, 3, sizeof(T) == 4, WIDE, true, NT>(R, 0, P.n_rest, pos, c, prev, src, out, volumes, dt, mine_lds,
                                                                   mine_lds + NW * 112);
     }
     return;
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_subgrid_family(
   T pv[5] = {T(0), T(0), T(0), T(0), T(0)};
   if (STAGE > 1 && EARLY) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) pv[k] = at<WIDE>(prev.p[k], o);
+    for (int k = 0; k < 5; k++) pv[k] = stream_load<NT>(&at<WIDE>(prev.p[k], o));
   }
 
   const CellData<T, KIND> mine = cell_from_state<T, KIND>(s0);
@@ -665,11 +665,11 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_subgrid_family(
   // ---- RK stage ---------------------------------------------------------------------------------------------------------
   if (STAGE > 1 && !EARLY) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) pv[k] = at<WIDE>(prev.p[k], o);
+    for (int k = 0; k < 5; k++) pv[k] = stream_load<NT>(&at<WIDE>(prev.p[k], o));
   }
   const T scale = dt / (vol / T(64));
 #pragma unroll
-  for (int k = 0; k < 5; k++) at<WIDE>(out.p[k], o) = rk_stage_update<T, STAGE>(pv[k], s0[k], scale, acc[k]);
+  for (int k = 0; k < 5; k++) stream_store<NT>(&at<WIDE>(out.p[k], o), rk_stage_update<T, STAGE>(pv[k], s0[k], scale, acc[k]));
 }
 
 // (Round 4, measured and dropped: a PERSISTENT form of this kernel -- a resident grid of 2 (fp64) / 3 (fp32) workgroups per CU
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(512, sizeof(T) == 8 ? 4 : 6) void k_subgrid_family(
 // the + faces in lanes 0-15, 16 behind the - faces in lanes 16-31: one half-filled primitive round instead of the block
 // kernel's two). Same fluxes, same summation order: bitwise equal to the block kernel. The blocks outside every square run
 // behind the squares in the same launch (four per wavefront, the block algorithm).
-template <class T, int KIND, int STAGE, bool WIDE>
+template <class T, int KIND, int STAGE, bool WIDE, bool NT>
 __global__ __launch_bounds__(64) void k_subgrid_family2(T8gpuSubgridPlan P, SVars<T> prev, SVars<T> src, SVars<T> out,
                                                         const T* __restrict__ volumes, T dt) {
   constexpr int  NW        = CellData<T, KIND>::words;
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(64) void k_subgrid_family2(T8gpuSubgridPlan P, SVar
   if (static_cast<int>(blockIdx.x) >= P.n_families) {   // the blocks outside every square: four per wavefront
     T8gpuSubgridPlan R = P;
     R.block_rec        = P.rest_rec;
-    subgrid_block<T, KIND, STAGE, 2, EARLY, WIDE, false>(R, 0, P.n_rest, static_cast<int>(blockIdx.x) - P.n_families, c, prev, src, out,
+    subgrid_block<T, KIND, STAGE, 2, EARLY, WIDE, false, NT>(R, 0, P.n_rest, static_cast<int>(blockIdx.x) - P.n_families, c, prev, src, out,
                                                          volumes, dt, lds, lds + NW * 96);
     return;
   }
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(64) void k_subgrid_family2(T8gpuSubgridPlan P, SVar
   T pv[5] = {T(0), T(0), T(0), T(0), T(0)};
   if (STAGE > 1 && EARLY) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) pv[k] = at<WIDE>(prev.p[k], o);
+    for (int k = 0; k < 5; k++) pv[k] = stream_load<NT>(&at<WIDE>(prev.p[k], o));
   }
 
   const CellData<T, KIND> mine = cell_from_state<T, KIND>(s0);
@@ -822,11 +822,11 @@ __global__ __launch_bounds__(64) void k_subgrid_family2(T8gpuSubgridPlan P, SVar
   }
   if (STAGE > 1 && !EARLY) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) pv[k] = at<WIDE>(prev.p[k], o);
+    for (int k = 0; k < 5; k++) pv[k] = stream_load<NT>(&at<WIDE>(prev.p[k], o));
   }
   const T scale = dt / (vol / T(16));
 #pragma unroll
-  for (int k = 0; k < 5; k++) at<WIDE>(out.p[k], o) = rk_stage_update<T, STAGE>(pv[k], s0[k], scale, acc[k]);
+  for (int k = 0; k < 5; k++) stream_store<NT>(&at<WIDE>(out.p[k], o), rk_stage_update<T, STAGE>(pv[k], s0[k], scale, acc[k]));
 }
 
 template <class T, class V>
@@ -909,6 +909,8 @@ int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, int b
     }
     return static_cast<int>(hipGetLastError());
   }
+  // non-temporal stage results / previous-state loads where the stage's planes are a stream for the caches (flux_math.hpp)
+  const bool nt = stream_hint(cells, sizeof(T));
   const int n_rest_here = block_count - nf;   // the leading rows of rest_rec that belong to this launch
   T8gpuSubgridPlan fam = *plan;
   fam.n_rest           = n_rest_here;
@@ -918,23 +920,30 @@ int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, int b
   const dim3 grid(plan->n_families + (n_rest_here + restb - 1) / restb), block(plan->rank == 3 ? 512 : 64);
   {
     char pat[96];
-    std::snprintf(pat, sizeof(pat), "%s<T, K, S, %s>", plan->rank == 3 ? "k_subgrid_family" : "k_subgrid_family2", wide ? "true" : "false");
+    std::snprintf(pat, sizeof(pat), "%s<T, K, S, %s, %s>", plan->rank == 3 ? "k_subgrid_family" : "k_subgrid_family2", wide ? "true" : "false", nt ? "true" : "false");
     note_stage_kernel(block_count, pat, static_cast<int>(sizeof(T)), kind, stage);
   }
-#define T8_FM(K, S)                                                                                                          \
-  do {                                                                                                                       \
-    if (plan->rank == 3 && wide)                                                                                             \
-      hipLaunchKernelGGL((k_subgrid_family<T, K, S, true>), grid, block, 0, s, fam, smk<T>(prev), smk<T>(mid), smk<T>(out),   \
-                         volumes, dt);                                                                                       \
-    else if (plan->rank == 3)                                                                                                \
-      hipLaunchKernelGGL((k_subgrid_family<T, K, S, false>), grid, block, 0, s, fam, smk<T>(prev), smk<T>(mid), smk<T>(out),  \
-                         volumes, dt);                                                                                       \
-    else if (wide)                                                                                                           \
-      hipLaunchKernelGGL((k_subgrid_family2<T, K, S, true>), grid, block, 0, s, fam, smk<T>(prev), smk<T>(mid), smk<T>(out),  \
-                         volumes, dt);                                                                                       \
-    else                                                                                                                     \
-      hipLaunchKernelGGL((k_subgrid_family2<T, K, S, false>), grid, block, 0, s, fam, smk<T>(prev), smk<T>(mid), smk<T>(out), \
-                         volumes, dt);                                                                                       \
+#define T8_FMN(K, S, N)                                                                                                         \
+  do {                                                                                                                          \
+    if (plan->rank == 3 && wide)                                                                                                \
+      hipLaunchKernelGGL((k_subgrid_family<T, K, S, true, N>), grid, block, 0, s, fam, smk<T>(prev), smk<T>(mid), smk<T>(out),   \
+                         volumes, dt);                                                                                          \
+    else if (plan->rank == 3)                                                                                                   \
+      hipLaunchKernelGGL((k_subgrid_family<T, K, S, false, N>), grid, block, 0, s, fam, smk<T>(prev), smk<T>(mid), smk<T>(out),  \
+                         volumes, dt);                                                                                          \
+    else if (wide)                                                                                                              \
+      hipLaunchKernelGGL((k_subgrid_family2<T, K, S, true, N>), grid, block, 0, s, fam, smk<T>(prev), smk<T>(mid), smk<T>(out),  \
+                         volumes, dt);                                                                                          \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((k_subgrid_family2<T, K, S, false, N>), grid, block, 0, s, fam, smk<T>(prev), smk<T>(mid), smk<T>(out), \
+                         volumes, dt);                                                                                          \
+  } while (0)
+#define T8_FM(K, S)        \
+  do {                     \
+    if (nt)                \
+      T8_FMN(K, S, true);  \
+    else                   \
+      T8_FMN(K, S, false); \
   } while (0)
   if (kind == 0) {
     if (stage == 1) T8_FM(0, 1); else if (stage == 2) T8_FM(0, 2); else T8_FM(0, 3);
@@ -944,6 +953,7 @@ int subgrid_fused_stage(int kind, int stage, const T8gpuSubgridPlan* plan, int b
     if (stage == 1) T8_FM(2, 1); else if (stage == 2) T8_FM(2, 2); else T8_FM(2, 3);
   }
 #undef T8_FM
+#undef T8_FMN
   return static_cast<int>(hipGetLastError());
 }
 

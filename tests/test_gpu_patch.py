@@ -5,6 +5,8 @@ kernels; built without (patches=False / T8GPU_PATCH=0) every element goes throug
 face with the same function on the same operands and add a cell's fluxes in ascending face id, so the two agree BIT FOR
 BIT -- states and speed estimates -- and both meet the oracle within the parity tolerance
 (examples/compressible_euler/kernels.cu:135-309, ssp_runge_kutta.inl:30-99)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -14,6 +16,8 @@ from _gpu import NP, TOL1, TOL10, perturbed_state, rel_err
 from t8gpu_amd import hip
 from t8gpu_amd.solver import PlainSolver
 from t8gpu_amd.synth import SynthMesh
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 DTYPES = [torch.float64, torch.float32]
@@ -195,3 +199,42 @@ def test_patch_plan_on_a_partition_is_bitwise_the_single_rank_run(mesh_args):
     torch.cuda.synchronize()
     full = torch.cat([s.state() for s in solvers], dim=1)
     assert torch.equal(full, ref.state())
+
+
+_STREAM_CHILD = r"""
+import hashlib, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from t8gpu_amd.solver import PlainSolver, SubgridSolver
+from t8gpu_amd.synth import SynthMesh
+out = []
+for what, mesh, sub in (("2d", SynthMesh(2, 4, 7, band=0.12), False), ("3d", SynthMesh(3, 3, 5, band=0.1), False), ("sg", SynthMesh(3, 2, 3, band=0.12), True)):
+    for dt_ in (torch.float64, torch.float32):
+        part = mesh.partition(subgrid=True) if sub else mesh.partition()
+        s = (SubgridSolver if sub else PlainSolver)(part, dt_, mode="fused")
+        dt = 0.1 * 2.0 ** -(mesh.finest_level + (2 if sub else 0))
+        for _ in range(3):
+            s.iterate(dt)
+        torch.cuda.synchronize()
+        out.append(f"{what} {dt_} {hashlib.sha256(s.state().cpu().numpy().tobytes()).hexdigest()}")
+print("\n".join(out))
+"""
+
+
+@pytest.mark.gpu
+def test_non_temporal_instantiations_give_the_same_bits(tmp_path):
+    """The patch kernels (2D, 3D) and the Subgrid family kernels exist twice: with ordinary and with non-temporal stores of the stage
+    results / loads of the previous state (flux_math.hpp: stream_store; chosen per launch from the size of the stage's planes,
+    T8GPU_STREAM_MB). Same arithmetic, so the same bits: small meshes through both (threshold 1 MB = always, 0 = never), in
+    child processes (the threshold is read once)."""
+    import subprocess
+    import sys
+    script = tmp_path / "stream_child.py"
+    script.write_text(_STREAM_CHILD)
+    outs = {}
+    for mb in ("0", "1"):
+        env = dict(os.environ, T8GPU_STREAM_MB=mb)
+        res = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=280, env=env)
+        assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+        outs[mb] = [" ".join(ln.split()[:3]) for ln in res.stdout.strip().splitlines()]
+    assert len(outs["0"]) == 6 and outs["0"] == outs["1"], (outs["0"], outs["1"])
