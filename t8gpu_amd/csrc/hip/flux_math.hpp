@@ -533,6 +533,19 @@ T8_DEV double ln_mean_dlog_rs(double aL, double aR, double dlog, double s, doubl
   const double den = small ? t8_fma(u, t8_fma(u, t8_fma(u, 15.0, 21.0), 35.0), 105.0) : dlog;
   return t8_div(num, den);
 }
+// 1 / (logarithmic mean), same arguments: den / num in ONE division where 1 / (num / den) takes a division and a reciprocal (the
+// flux needs the mean of beta only through its reciprocal: kernels.inl:60-75, `1 / beta_hat`). num is never 0: it is the
+// difference of two values at least 2 % apart, or 52.5 times their sum.
+T8_DEV double ln_mean_inv_dlog_rs(double aL, double aR, double dlog, double s, double rs) {
+#pragma clang fp contract(off)
+  const double d = aR - aL;
+  const double f = t8_div_by(d, s, rs);
+  const double u = f * f;
+  const bool   small = u < 1.0e-4;
+  const double num = small ? s * 52.50 : d;
+  const double den = small ? t8_fma(u, t8_fma(u, t8_fma(u, 15.0, 21.0), 35.0), 105.0) : dlog;
+  return t8_div(den, num);
+}
 // fp32: a difference of stored logs would cost accuracy near the branch switch; v_log_f32 is cheap.
 T8_DEV float ln_mean_dlog(float aL, float aR, float /*dlog*/) {
 #pragma clang fp contract(off)
@@ -555,6 +568,16 @@ T8_DEV float ln_mean_dlog_rs(float aL, float aR, float /*dlog*/, float s, float 
   const float den = small ? t8_fma(u, t8_fma(u, t8_fma(u, 15.0f, 21.0f), 35.0f), 105.0f) : t8_log_fast(t8_div(aR, aL));
   return t8_div(num, den);
 }
+T8_DEV float ln_mean_inv_dlog_rs(float aL, float aR, float /*dlog*/, float s, float rs) {
+#pragma clang fp contract(off)
+  const float d = aR - aL;
+  const float f = d * rs;
+  const float u = f * f;
+  const bool  small = u < 1.0e-4f;
+  const float num = small ? s * 52.50f : d;
+  const float den = small ? t8_fma(u, t8_fma(u, t8_fma(u, 15.0f, 21.0f), 35.0f), 105.0f) : t8_log_fast(t8_div(aR, aL));
+  return t8_div(den, num);
+}
 
 // KEPES flux through a face with unit normal n (basis n, t1, t2), scaled by `area`, in xyz.
 // mirror => the right state is the wall reflection of L (R is ignored).
@@ -569,8 +592,7 @@ T8_DEV void kepes_core(const Prim<T>& L, const Prim<T>& R, T uL, T vL, T wL, T u
 
   const T bsum = L.beta + R.beta, rbs = t8_rcp_shared(bsum);   // serves the log mean of beta and the pressure mean
   const T rho  = ln_mean_dlog(L.rho, R.rho, R.lrho - L.lrho);
-  const T bhat = ln_mean_dlog_rs(L.beta, R.beta, R.lbeta - L.lbeta, bsum, rbs);
-  const T ib   = t8_rcp(bhat);
+  const T ib   = ln_mean_inv_dlog_rs(L.beta, R.beta, R.lbeta - L.lbeta, bsum, rbs);   // 1 / (logarithmic mean of beta)
   const T rho_mean = half * (L.rho + R.rho);
   const T u = half * (uL + uR), v = half * (vL + vR), w = half * (wL + wR);
   const T a  = t8_sqrt_ratio(kappa * half * (L.p + R.p), rho);
