@@ -598,7 +598,8 @@ T8_DEV void kepes_core(const Prim<T>& L, const Prim<T>& R, T uL, T vL, T wL, T u
   const T rho_mean = half * (L.rho + R.rho);
   const T u = half * (uL + uR), v = half * (vL + vR), w = half * (wL + wR);
   const T a  = t8_sqrt_ratio(kappa * half * (L.p + R.p), rho);
-  const T h  = t8_fma(kappa / (T(2) * km1), ib, half * t8_fma(uL, uR, t8_fma(vL, vR, wL * wR)));
+  const T dot = t8_fma(uL, uR, t8_fma(vL, vR, wL * wR));   // vL . vR: in the enthalpy mean and in |v_mean|^2 below
+  const T h   = t8_fma(kappa / (T(2) * km1), ib, half * dot);
   const T p1 = t8_div_by(rho_mean, bsum, rbs);
 
   const T Fs0 = rho * u;
@@ -624,7 +625,8 @@ T8_DEV void kepes_core(const Prim<T>& L, const Prim<T>& R, T uL, T vL, T wL, T u
   const T J4 = rpL - rpR;
 
   const T ua = u * a;
-  const T hm = h - ua, hp = h + ua, k2 = half * t8_fma(u, u, t8_fma(v, v, w * w));
+  // |v_mean|^2 / 2 with v_mean = (vL + vR) / 2: (|vL|^2 + |vR|^2 + 2 vL . vR) / 8 = (q2 + vL . vR) / 4 -- both terms are at hand
+  const T hm = h - ua, hp = h + ua, k2 = T(0.25) * (q2 + dot);
   const T c  = t8_fma(w, J3, t8_fma(v, J2, J0));  // common part of the three acoustic/entropy columns
   const T d0 = D0 * t8_fma(hm, J4, t8_fma(u - a, J1, c));
   const T d1 = D1 * t8_fma(k2, J4, t8_fma(u, J1, c));
