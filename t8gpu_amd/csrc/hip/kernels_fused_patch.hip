@@ -235,7 +235,8 @@ T8_DEV void plain_patch_body(const T8gpuPlainPlan& P, int tile_begin, int tile_c
       acc[k] = __builtin_fma(T(-1), ff[k * kPatchFF + tid], acc[k]);
       acc[k] = __builtin_fma(T(-1), gy[k], acc[k]);
     }
-    const T scale = dt / volume;
+    // (a patch of uniform volume: its operands are wave-uniform -- the power-of-two test runs on scalar registers)
+    const T scale = (d0.flags & 0x400) ? rk_scale(dt, static_cast<T>(d0.vol)) : dt / volume;
 #pragma unroll
     for (int k = 0; k < 5; k++) res[k] = rk_stage_update<T, STAGE>(pv[k], cur.s0[k], scale, acc[k]);
     res_e = e;

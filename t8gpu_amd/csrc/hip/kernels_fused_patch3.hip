@@ -305,7 +305,7 @@ T8_DEV void plain_patch3_body(const T8gpuPlainPlan& P, int tile_begin, int tile_
 #pragma unroll
         for (int k = 0; k < 5; k++) acc[k] = __builtin_fma(sg, ff[k * kP3FF + pos], acc[k]);
       }
-      const T scale = dt / volume;
+      const T scale = dt / volume;   // (rk_scale's test would cost this kernel registers it does not have: 14 - 21 spills)
 #pragma unroll
       for (int k = 0; k < 5; k++) stream_store<NT>(&at32<T>(out.p[k], static_cast<unsigned>(e)), rk_stage_update<T, STAGE>(pv[k], cur[k], scale, acc[k]));
     } else if (!side) {
@@ -326,7 +326,7 @@ T8_DEV void plain_patch3_body(const T8gpuPlainPlan& P, int tile_begin, int tile_
         acc[k] = __builtin_fma(T(-1), ff[k * kP3FF + 256 + c], acc[k]);
         acc[k] = __builtin_fma(T(-1), ff[k * kP3FF + 512 + c], acc[k]);
       }
-      const T scale = dt / volume;
+      const T scale = dt / volume;   // (rk_scale's test would cost this kernel registers it does not have: 14 - 21 spills)
 #pragma unroll
       for (int k = 0; k < 5; k++) stream_store<NT>(&at32<T>(out.p[k], static_cast<unsigned>(e)), rk_stage_update<T, STAGE>(pv[k], cur[k], scale, acc[k]));
     }
